@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+Metric: Mray/s (fwd+bwd) on the Cornell box of /root/reference/src/render.cpp:26-59,
+512x512, 64 spp, depth 8 (`-b 8 -p 1`), gradients w.r.t. the material albedos + emission
+(BASELINE config 3).  A "step" is one full render call: every path of the frame traced forward
+through the wavefront pipeline, the tape swept backward, gradients reduced.  ray = one raycast
+(camera ray included), exactly what the reference's Pathtracer::raycast counts.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Multi-GPU: one process per GPU; the frame's rows are dealt to the ranks in interleaved bands
+and spp is multiplied by N, so every rank traces the same 512*512*64 paths whatever N is (weak
+scaling); the only collective is one RCCL all-reduce of the P x 3 gradient vector per step.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic bytes per ray segment, f32 queues
+BYTES_PER_UNIT = {"intersect": 40.0, "shade_fwd": 104.0, "shade_bwd": 108.0, "backward": 20.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=16)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, a.gpus):
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = entry.load_package()
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(a.width, a.height)
+    backward = not a.forward_only
+    rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
+                          shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths)
+
+    r = pkg.HipRenderer(local_rank)          # raises without libdrt_hip.so / a device: no fallback
+    r.upload_scene(scene)
+    dev = torch.device("cuda", local_rank)
+    out_rgb = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device=dev)
+    grad = torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev)
+    ext = torch.cuda.ExternalStream(r.stream, device=dev)
+
+    def step(timing=False):
+        st = r.render_device(cam, rp, out_rgb.data_ptr(), grad.data_ptr() if backward else 0,
+                             backward=backward, timing=timing, sync=False)
+        if world > 1 and backward:
+            with torch.cuda.stream(ext):
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        return st
+
+    def fence():
+        r.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event timing (events on the context's own stream), same workload, same
+    # process, right after the timed region; also yields the segment count of one step
+    kernel_ms = {k: 0.0 for k in pkg.KERNEL_NAMES}
+    kernel_launches = {k: 0 for k in pkg.KERNEL_NAMES}
+    n_prof = max(1, min(a.steps, 5))
+    stats = None
+    for _ in range(n_prof):
+        stats = step(timing=True)
+        for k in pkg.KERNEL_NAMES:
+            kernel_ms[k] += stats["kernels"][k]["ms"]
+            kernel_launches[k] += stats["kernels"][k]["launches"]
+    fence()
+    segments = stats["segments"]
+    paths = stats["paths"]
+    if world > 1:
+        t = torch.tensor([segments, paths], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_segments, total_paths = float(t[0].item()), float(t[1].item())
+    else:
+        total_segments, total_paths = float(segments), float(paths)
+
+    ms_per_step = elapsed / a.steps * 1e3
+    value = total_segments * a.steps / elapsed * 1e-6   # Mray/s, whole job
+
+    # dominant kernel and its roofline (rank 0's device; every rank runs the same work)
+    units = {"intersect": segments, "shade": segments, "backward": segments,
+             "raygen": paths, "film": paths, "gradreduce": 0}
+    bpu = {"intersect": BYTES_PER_UNIT["intersect"],
+           "shade": BYTES_PER_UNIT["shade_bwd" if backward else "shade_fwd"],
+           "backward": BYTES_PER_UNIT["backward"], "raygen": 48.0, "film": 16.0, "gradreduce": 0.0}
+    per_kernel = {}
+    for k in pkg.KERNEL_NAMES:
+        ms = kernel_ms[k] / n_prof
+        if kernel_launches[k] == 0:
+            continue
+        gbs = units[k] * bpu[k] / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
+        per_kernel[k] = {"ms_per_step": round(ms, 4), "launches_per_step": kernel_launches[k] // n_prof,
+                         "bytes_per_unit": bpu[k], "achieved_GBs": round(gbs, 1),
+                         "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    dominant = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else "shade"
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant)
+        except Exception:
+            traffic = None
+    dk = per_kernel.get(dominant, {"achieved_GBs": 0.0, "launches_per_step": 1, "ms_per_step": 0.0})
+    roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": dk["achieved_GBs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(dk["ms_per_step"] / max(1, dk["launches_per_step"]), 4),
+                "traversal_kernel": per_kernel.get("intersect"), "kernels": per_kernel}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        oracle = entry.load_oracle()
+        crp = pkg.RenderParams(spp=a.cpu_spp, min_bounces=a.depth, absorb=1.0, seed=1)
+        t1 = time.perf_counter()
+        ref = oracle.render(scene, cam, crp, backward=backward)
+        dt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(ref["stats"]["segments"] / dt * 1e-6, 3), "unit": "Mray/s",
+                        "cores": 1, "kind": "port",
+                        "sample": f"same scene and frame {a.width}x{a.height}, {a.cpu_spp} of the {a.spp} spp, "
+                                  f"depth {a.depth}, {'fwd+bwd' if backward else 'fwd'}: "
+                                  f"{ref['stats']['segments']} rays in {dt:.1f} s (fp64 C restatement, 1 thread)"}
+        # parity of this very workload's gradients against the CPU restatement (same RNG keys):
+        # the first cpu_spp samples of every pixel are the same paths on both sides only when
+        # spp matches, so run the device once more at the sample's spp
+        if backward:
+            img_d, g_d, _ = r.render(cam, crp, backward=True)
+            gerr = float(np.abs(g_d - ref["grads"]).max() / np.abs(ref["grads"]).max())
+            cpu_baseline["grad_max_rel_err_vs_cpu"] = gerr
+
+    if rank == 0:
+        line = {
+            "metric": "Mray/s (fwd+bwd), Cornell 512x512 @64spp depth 8" if backward else "Mray/s (fwd), Cornell 512x512 @64spp depth 8",
+            "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cornell box (render.cpp:26-59) {a.width}x{a.height}, "
+                                   f"{a.spp} spp per GPU, depth {a.depth} (-b {a.depth} -p 1), "
+                                   f"{'fwd + radiative-backprop grads of 4 params' if backward else 'fwd only'}",
+                       "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
+                       "parallelism": f"pixel-row bands x{world}, 1 grad all-reduce" if world > 1 else "1 GPU",
+                       "batches_per_step": stats["batches"]},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,466 @@
+"""Host-side Python mirror of the drt_hip C ABI (include/drt_hip.h).
+
+This package is plumbing for tests and bench.py: it describes scenes with the same vocabulary
+as the reference's plugin classes (Plane / Sphere, DiffuseBxDF / SpecularBxDF, AreaEmitter,
+Camera.look_at, Pathtracer(absorb, min_bounces) -- /root/reference/include/drt/*.hpp), flattens
+them to the POD records of the ABI and calls libdrt_hip.so through ctypes.  There is no CPU
+fallback: if the HIP library or a device is missing, HipRenderer raises.
+
+The directory name contains a hyphen, so it is loaded with importlib under the module name
+``differentiable_renderer_amd`` (see __graft_entry__.load_package()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libdrt_hip.so")
+
+# ---- enums / flags (include/drt_hip.h) ------------------------------------------------------
+SHAPE_PLANE, SHAPE_SPHERE = 0, 1
+BXDF_DIFFUSE, BXDF_SPECULAR = 0, 1
+RENDER_BACKWARD = 0x1
+RENDER_DEVICE_OUT = 0x2
+RENDER_SYNC = 0x4
+RENDER_TIMING = 0x8
+RENDER_F64 = 0x10
+K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
+KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce"]
+
+STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3: "DRT_ERR_HIP",
+                -4: "DRT_ERR_NO_SCENE", -5: "DRT_ERR_OOM", -6: "DRT_ERR_UNSUPPORTED"}
+
+
+class ShapeDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("emitter", C.c_int32),
+                ("reserved", C.c_int32), ("p", C.c_double * 4)]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("param", C.c_int32), ("exponent", C.c_double)]
+
+
+class EmitterDesc(C.Structure):
+    _fields_ = [("param", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_shapes", C.c_int32), ("n_materials", C.c_int32), ("n_emitters", C.c_int32),
+                ("n_params", C.c_int32),
+                ("shapes", C.POINTER(ShapeDesc)), ("materials", C.POINTER(MaterialDesc)),
+                ("emitters", C.POINTER(EmitterDesc)), ("params", C.POINTER(C.c_double)),
+                ("requires_grad", C.POINTER(C.c_uint8))]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("vfov", C.c_double),
+                ("eye", C.c_double * 3), ("forward", C.c_double * 3),
+                ("right", C.c_double * 3), ("up", C.c_double * 3)]
+
+
+class RenderParamsDesc(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("min_bounces", C.c_int32), ("absorb", C.c_double),
+                ("max_depth", C.c_int32), ("seed", C.c_uint32),
+                ("shard", C.c_int32), ("n_shards", C.c_int32), ("band_rows", C.c_int32),
+                ("flags", C.c_uint32), ("batch_paths", C.c_int64)]
+
+
+class HipStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("batches", C.c_uint64),
+                ("ms_total", C.c_double), ("ms_kernel", C.c_double * K_COUNT),
+                ("launches", C.c_uint64 * K_COUNT), ("units", C.c_uint64 * K_COUNT)]
+
+    def as_dict(self) -> dict:
+        d = {"paths": int(self.paths), "segments": int(self.segments),
+             "batches": int(self.batches), "ms_total": float(self.ms_total), "kernels": {}}
+        for k, name in enumerate(KERNEL_NAMES):
+            d["kernels"][name] = {"ms": float(self.ms_kernel[k]), "launches": int(self.launches[k]),
+                                  "units": int(self.units[k])}
+        return d
+
+
+# ---- scene vocabulary (mirrors the reference's plugin classes) ------------------------------
+@dataclass
+class Scene:
+    """Flattened drt::Scene<T> (pathtracer.hpp:12-13) + its materials, emitters, parameters."""
+    params: List[Tuple[float, float, float]] = field(default_factory=list)
+    requires_grad: List[bool] = field(default_factory=list)
+    param_names: List[str] = field(default_factory=list)
+    materials: List[Tuple[int, int, float]] = field(default_factory=list)   # type, param, exponent
+    emitters: List[int] = field(default_factory=list)                       # param
+    shapes: List[Tuple[int, int, int, Tuple[float, float, float, float]]] = field(default_factory=list)
+
+    # Vector<T,3,true>(value, requires_grad), vector.hpp:228-234
+    def parameter(self, rgb: Sequence[float], requires_grad: bool = True, name: str = "") -> int:
+        self.params.append(tuple(float(v) for v in rgb))
+        self.requires_grad.append(bool(requires_grad))
+        self.param_names.append(name or f"param{len(self.params) - 1}")
+        return len(self.params) - 1
+
+    # DiffuseBxDF(color), bxdf.hpp:58-61
+    def diffuse(self, param: int) -> int:
+        self.materials.append((BXDF_DIFFUSE, param, 0.0))
+        return len(self.materials) - 1
+
+    # SpecularBxDF(color, exponent), bxdf.hpp:87-91
+    def specular(self, param: int, exponent: float) -> int:
+        self.materials.append((BXDF_SPECULAR, param, float(exponent)))
+        return len(self.materials) - 1
+
+    # AreaEmitter(emission), emitter.hpp:17
+    def area_emitter(self, param: int) -> int:
+        self.emitters.append(param)
+        return len(self.emitters) - 1
+
+    # Plane(normal, offset, bxdf, emitter), shape.hpp:40-47
+    def plane(self, normal: Sequence[float], offset: float, material: int = -1, emitter: int = -1) -> int:
+        self.shapes.append((SHAPE_PLANE, material, emitter,
+                            (float(normal[0]), float(normal[1]), float(normal[2]), float(offset))))
+        return len(self.shapes) - 1
+
+    # Sphere(center, radius, bxdf, emitter), shape.hpp:69-76
+    def sphere(self, center: Sequence[float], radius: float, material: int = -1, emitter: int = -1) -> int:
+        self.shapes.append((SHAPE_SPHERE, material, emitter,
+                            (float(center[0]), float(center[1]), float(center[2]), float(radius))))
+        return len(self.shapes) - 1
+
+    @property
+    def n_params(self) -> int:
+        return len(self.params)
+
+    def to_desc(self):
+        """-> (SceneDesc, keepalive list). Pointers stay valid while keepalive is referenced."""
+        shapes = (ShapeDesc * max(1, len(self.shapes)))()
+        for i, (t, m, e, p) in enumerate(self.shapes):
+            shapes[i].type, shapes[i].material, shapes[i].emitter = t, m, e
+            for j in range(4):
+                shapes[i].p[j] = p[j]
+        mats = (MaterialDesc * max(1, len(self.materials)))()
+        for i, (t, p, ex) in enumerate(self.materials):
+            mats[i].type, mats[i].param, mats[i].exponent = t, p, ex
+        emis = (EmitterDesc * max(1, len(self.emitters)))()
+        for i, p in enumerate(self.emitters):
+            emis[i].param = p
+        params = (C.c_double * max(1, 3 * len(self.params)))()
+        for i, rgb in enumerate(self.params):
+            for j in range(3):
+                params[3 * i + j] = rgb[j]
+        rg = (C.c_uint8 * max(1, len(self.params)))()
+        for i, r in enumerate(self.requires_grad):
+            rg[i] = 1 if r else 0
+        d = SceneDesc(len(self.shapes), len(self.materials), len(self.emitters), len(self.params),
+                      shapes, mats, emis, params, rg)
+        return d, [shapes, mats, emis, params, rg]
+
+
+def cornell_box(front_specular: bool = False, emissive_wall: bool = False) -> Scene:
+    """The hard-coded scene of /root/reference/src/render.cpp:26-59 (same order, same values).
+
+    front_specular: sphere_front uses SpecularBxDF(white, 30) (render.cpp:35 creates it, the
+    reference scene leaves it unused; BASELINE config 5 uses it).
+    emissive_wall: the back plane additionally carries an emitter (a shape with BOTH a BxDF and
+    an emitter: several emission terms per path)."""
+    s = Scene()
+    red = s.parameter((0.5, 0, 0), True, "red")                 # render.cpp:26
+    green = s.parameter((0, 0.5, 0), True, "green")             # :27
+    white = s.parameter((0.5, 0.5, 0.5), True, "white")         # :28
+    emission = s.parameter((1, 1, 1), True, "emission")         # :29
+    diffuse_red = s.diffuse(red)                                # :32
+    diffuse_green = s.diffuse(green)                            # :33
+    diffuse_white = s.diffuse(white)                            # :34
+    specular_white = s.specular(white, 30)                      # :35
+    emitter = s.area_emitter(emission)                          # :36
+    s.sphere((0., 0., 3.), 1., specular_white if front_specular else diffuse_white)  # :39
+    s.sphere((-1., 1., 4.5), 1., diffuse_white)                 # :40
+    s.plane((-1., 0., 0.), -3., diffuse_red)                    # :41 left
+    s.plane((1., 0., 0.1), -3., diffuse_green)                  # :42 right (normal NOT unit)
+    if emissive_wall:
+        glow = s.parameter((0.05, 0.1, 0.2), True, "glow")
+        s.plane((0., 0., -1.), -6., diffuse_white, s.area_emitter(glow))
+    else:
+        s.plane((0., 0., -1.), -6., diffuse_white)              # :43 back
+    s.plane((0, 0, 1), 0, diffuse_white)                        # :44 front
+    s.plane((0., 1., 0.), -3., diffuse_white)                   # :45 ground
+    s.plane((0., -1., 0.), -3., diffuse_white)                  # :46 ceiling
+    s.sphere((0., 3., 3.), 1., -1, emitter)                     # :47 light (no BxDF)
+    return s
+
+
+def random_scene(seed: int, n_spheres: int = 5, specular: bool = True, n_lights: int = 2) -> Scene:
+    """A closed box with random spheres, random albedos, optional specular lobes and several
+    lights (some lights also carry a BxDF). Test input only; deterministic in `seed`."""
+    rng = np.random.RandomState(seed)
+    s = Scene()
+    mats, diffuse_mats = [], []
+    for i in range(4):
+        col = s.parameter(rng.uniform(0.05, 0.9, 3), bool(rng.rand() < 0.8) or i == 0, f"albedo{i}")
+        diffuse_mats.append(s.diffuse(col))
+        mats.append(diffuse_mats[-1])
+        if specular and i % 2 == 1:
+            mats.append(s.specular(col, float(rng.choice([5.0, 30.0, 80.0]))))
+    lights = []
+    for i in range(n_lights):
+        e = s.parameter(rng.uniform(0.5, 4.0, 3), True, f"emission{i}")
+        lights.append(s.area_emitter(e))
+    for i in range(n_spheres):
+        c = (rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(2, 5))
+        s.sphere(c, rng.uniform(0.3, 0.9), mats[rng.randint(len(mats))],
+                 lights[0] if (i == 0 and n_lights > 1) else -1)
+    # walls: un-normalised normals on purpose (the reference never normalises them); diffuse
+    # only -- the reference's specular lobe takes sqrt(1 - dot(n, h)^2) (bxdf.hpp:98), NaN for |n| > 1
+    wall = lambda: diffuse_mats[rng.randint(len(diffuse_mats))]
+    s.plane((-1., 0., 0.), -3., wall())
+    s.plane((1., 0.05, 0.1), -3., wall())
+    s.plane((0., 0., -1.), -6., wall())
+    s.plane((0., 0., 1.), -0.5, wall())
+    s.plane((0., 2., 0.), -6., wall())
+    s.plane((0., -1., 0.), -3., wall())
+    s.sphere((rng.uniform(-1, 1), 3., rng.uniform(2, 4)), 1., -1, lights[-1])
+    return s
+
+
+def scene_by_name(name: str) -> Scene:
+    """Named test/bench scenes (the names the golden fixtures record)."""
+    if name == "cornell":
+        return cornell_box()
+    if name == "cornell_specular":
+        return cornell_box(front_specular=True)
+    if name == "cornell_emissive_wall":
+        return cornell_box(emissive_wall=True)
+    if name.startswith("random"):
+        return random_scene(int(name[len("random"):]))
+    raise KeyError(name)
+
+
+def _normalize(v):
+    n = math.sqrt(((0.0 + v[0] * v[0]) + v[1] * v[1]) + v[2] * v[2])
+    return (v[0] / n, v[1] / n, v[2] / n)
+
+
+def _cross(a, b):
+    return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+
+@dataclass
+class Camera:
+    """drt::Camera<T> (camera.hpp:10-70): same ctor defaults, same look_at arithmetic."""
+    width: int
+    height: int
+    vfov: float = 1.3963
+    eye: Tuple[float, float, float] = (0., 0., 0.)
+    forward: Tuple[float, float, float] = (0., 0., -1.)
+    right: Tuple[float, float, float] = (1., 0., 0.)
+    up: Tuple[float, float, float] = (0., 1., 0.)
+
+    def look_at(self, eye, at, up=(0., 1., 0.)) -> "Camera":   # camera.hpp:29-37
+        self.eye = tuple(float(v) for v in eye)
+        self.forward = _normalize(tuple(at[i] - eye[i] for i in range(3)))
+        self.right = _normalize(_cross(self.forward, up))
+        self.up = _cross(self.right, self.forward)
+        return self
+
+    def to_desc(self) -> CameraDesc:
+        d = CameraDesc()
+        d.width, d.height, d.vfov = self.width, self.height, self.vfov
+        for i in range(3):
+            d.eye[i], d.forward[i], d.right[i], d.up[i] = self.eye[i], self.forward[i], self.right[i], self.up[i]
+        return d
+
+
+def cornell_camera(width: int, height: int) -> Camera:
+    """render.cpp:64-65."""
+    return Camera(width, height).look_at((0, 0, 0), (0, 0, 1))
+
+
+@dataclass
+class RenderParams:
+    """Pathtracer(absorb, min_bounces) (pathtracer.hpp:56-57) + the CLI's -n (args.hpp:36-59)
+    + the extensions of the ABI (seed, max_depth, sharding, batching)."""
+    spp: int = 100
+    min_bounces: int = 1
+    absorb: float = 0.5
+    max_depth: int = 0
+    seed: int = 1
+    shard: int = 0
+    n_shards: int = 1
+    band_rows: int = 16
+    flags: int = 0
+    batch_paths: int = 0
+
+    def to_desc(self) -> RenderParamsDesc:
+        return RenderParamsDesc(self.spp, self.min_bounces, self.absorb, self.max_depth, self.seed,
+                                self.shard, self.n_shards, self.band_rows, self.flags, self.batch_paths)
+
+
+def shard_rows(height: int, band_rows: int, n_shards: int, shard: int) -> np.ndarray:
+    """Rows of the image owned by `shard`: bands of band_rows rows dealt round-robin."""
+    y = np.arange(height)
+    if n_shards <= 1:
+        return y
+    return y[(y // max(1, band_rows)) % n_shards == shard]
+
+
+# ---- native build + loader ------------------------------------------------------------------
+HIP_SOURCES = ["csrc/drt_hip.hip"]
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> libdrt_hip.so, in-tree (cross-compiles without a GPU)."""
+    srcs = [os.path.join(PKG_DIR, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(PKG_DIR, "csrc", f) for f in os.listdir(os.path.join(PKG_DIR, "csrc"))
+                   if f.endswith((".h", ".hpp", ".hip"))] + [os.path.join(REPO_ROOT, "include", "drt_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class DrtHipError(RuntimeError):
+    pass
+
+
+_ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_destroy",
+                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render", "drt_hip_stream",
+                "drt_hip_synchronize", "drt_hip_last_error", "drt_hip_kernel_name"]
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libdrt_hip.so and declare the ABI. Raises if the library or a symbol is missing."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise DrtHipError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    for s in _ABI_SYMBOLS:
+        if not hasattr(lib, s):
+            raise DrtHipError(f"{path} does not export {s}")
+    lib.drt_hip_abi_version.restype = C.c_int
+    lib.drt_hip_device_count.restype = C.c_int
+    lib.drt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.drt_hip_destroy.argtypes = [C.c_void_p]
+    lib.drt_hip_destroy.restype = None
+    lib.drt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    lib.drt_hip_update_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.drt_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
+    lib.drt_hip_stream.argtypes = [C.c_void_p]
+    lib.drt_hip_stream.restype = C.c_void_p
+    lib.drt_hip_synchronize.argtypes = [C.c_void_p]
+    lib.drt_hip_last_error.argtypes = [C.c_void_p]
+    lib.drt_hip_last_error.restype = C.c_char_p
+    lib.drt_hip_kernel_name.argtypes = [C.c_int]
+    lib.drt_hip_kernel_name.restype = C.c_char_p
+    return lib
+
+
+class HipRenderer:
+    """One context = one MI355X device + one stream (drt_hip_ctx)."""
+
+    def __init__(self, device: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        self.ctx = C.c_void_p()
+        rc = self.lib.drt_hip_create(device, C.byref(self.ctx))
+        if rc != 0:
+            raise DrtHipError(f"drt_hip_create(device={device}) failed: {STATUS_NAMES.get(rc, rc)}")
+        self.device = device
+        self.scene: Optional[Scene] = None
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.drt_hip_last_error(self.ctx)
+            raise DrtHipError(f"{what}: {STATUS_NAMES.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def upload_scene(self, scene: Scene):
+        desc, keep = scene.to_desc()
+        self._check(self.lib.drt_hip_upload_scene(self.ctx, C.byref(desc)), "drt_hip_upload_scene")
+        self.scene = scene
+
+    def update_params(self, params: np.ndarray):
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        assert self.scene is not None and p.size == 3 * self.scene.n_params
+        self._check(self.lib.drt_hip_update_params(self.ctx, p.ctypes.data_as(C.POINTER(C.c_double))),
+                    "drt_hip_update_params")
+
+    def render(self, cam: Camera, rp: RenderParams, backward: bool = False,
+               adjoint: Optional[np.ndarray] = None, timing: bool = False, f64: bool = False):
+        """Host-buffer render. -> (image float32 [H,W,3], grads float64 [P,3] or None, stats dict)."""
+        assert self.scene is not None
+        flags = rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC)
+        if backward:
+            flags |= RENDER_BACKWARD
+        if timing:
+            flags |= RENDER_TIMING
+        if f64:
+            flags |= RENDER_F64
+        d = rp.to_desc()
+        d.flags = flags
+        img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        grads = np.zeros((self.scene.n_params, 3), dtype=np.float64) if backward else None
+        adj_ptr = None
+        if adjoint is not None:
+            adjoint = np.ascontiguousarray(adjoint, dtype=np.float32)
+            assert adjoint.shape == (cam.height, cam.width, 3)
+            adj_ptr = adjoint.ctypes.data_as(C.c_void_p)
+        stats = HipStats()
+        cd = cam.to_desc()
+        rc = self.lib.drt_hip_render(self.ctx, C.byref(cd), C.byref(d), adj_ptr,
+                                     img.ctypes.data_as(C.c_void_p),
+                                     grads.ctypes.data_as(C.c_void_p) if backward else None,
+                                     C.byref(stats))
+        self._check(rc, "drt_hip_render")
+        return img, grads, stats.as_dict()
+
+    def render_device(self, cam: Camera, rp: RenderParams, out_rgb_ptr: int, out_grad_ptr: int,
+                      adjoint_ptr: int = 0, backward: bool = True, timing: bool = False,
+                      sync: bool = False, want_stats: Optional[bool] = None) -> dict:
+        """Device-pointer render (outputs stay in HBM, enqueued on the context's stream).
+        Without stats/timing/sync the call returns right after enqueueing (no host round trip)."""
+        if want_stats is None:
+            want_stats = timing
+        flags = (rp.flags | RENDER_DEVICE_OUT) & ~RENDER_SYNC
+        if backward:
+            flags |= RENDER_BACKWARD
+        if timing:
+            flags |= RENDER_TIMING
+        if sync:
+            flags |= RENDER_SYNC
+        d = rp.to_desc()
+        d.flags = flags
+        stats = HipStats()
+        cd = cam.to_desc()
+        rc = self.lib.drt_hip_render(self.ctx, C.byref(cd), C.byref(d),
+                                     C.c_void_p(adjoint_ptr) if adjoint_ptr else None,
+                                     C.c_void_p(out_rgb_ptr) if out_rgb_ptr else None,
+                                     C.c_void_p(out_grad_ptr) if out_grad_ptr else None,
+                                     C.byref(stats) if want_stats else None)
+        self._check(rc, "drt_hip_render")
+        return stats.as_dict() if want_stats else {}
+
+    def synchronize(self):
+        self._check(self.lib.drt_hip_synchronize(self.ctx), "drt_hip_synchronize")
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.drt_hip_stream(self.ctx) or 0)
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.drt_hip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

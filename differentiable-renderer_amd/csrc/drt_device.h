@@ -1,0 +1,158 @@
+// drt_device.h -- device-side records and math for the gfx950 wavefront path tracer.
+// Written for CDNA4 only (wave64, no portability layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "drt_hip.h"
+
+#define DRT_MAX_SHAPES 64
+#define DRT_MAX_MATERIALS 64
+#define DRT_MAX_EMITTERS 64
+#define DRT_LDS_PARAMS 256       // parameters staged in LDS by K3/K6 (more: read from L2)
+#define DRT_FAST_PARAMS 8        // parameter ids accumulated in registers by K6
+#define DRT_ID_NONE 0xFFFFu
+#define DRT_BLOCK 256
+#define DRT_WAVE 64
+
+// ---- scene records (one instance per compute type, built by drt_hip_upload_scene) ----------
+template <typename R>
+struct DevShape {           // float: 32 B, one s_load_dwordx8 in K2's uniform loop
+    R p[4];                 // PLANE n.xyz, offset | SPHERE c.xyz, radius
+    int type, material, emitter, pad;
+};
+
+template <typename R>
+struct DevMaterial {
+    int type, param;
+    R exponent;
+    R norm;                 // (exponent + 2) / (2 pi), bxdf.hpp:101,118
+};
+
+template <typename R>
+struct DevScene {
+    int n_shapes, n_materials, n_emitters, n_params;
+    DevShape<R> shapes[DRT_MAX_SHAPES];
+    DevMaterial<R> materials[DRT_MAX_MATERIALS];
+    int emitter_param[DRT_MAX_EMITTERS];
+};
+
+// ---- 16-byte (f32) / 32-byte (f64) queue lanes ----------------------------------------------
+template <typename R> struct Q4;
+template <> struct Q4<float> { typedef float4 T; };
+template <> struct Q4<double> { typedef double4 T; };
+
+template <typename R> struct HitRec;
+template <> struct __attribute__((aligned(8))) HitRec<float> { float t; int prim; };
+template <> struct __attribute__((aligned(16))) HitRec<double> { double t; int prim; int pad; };
+
+__device__ inline float pid_pack(float, uint32_t pid) { return __uint_as_float(pid); }
+__device__ inline double pid_pack(double, uint32_t pid) { return (double)pid; }
+__device__ inline uint32_t pid_unpack(float v) { return __float_as_uint(v); }
+__device__ inline uint32_t pid_unpack(double v) { return (uint32_t)v; }
+
+// ---- small vector math -----------------------------------------------------------------------
+template <typename R>
+struct V3 {
+    R x, y, z;
+};
+template <typename R> __device__ inline V3<R> mk(R x, R y, R z) { V3<R> v = {x, y, z}; return v; }
+template <typename R> __device__ inline V3<R> operator+(V3<R> a, V3<R> b) { return mk<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename R> __device__ inline V3<R> operator-(V3<R> a, V3<R> b) { return mk<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename R> __device__ inline V3<R> operator*(V3<R> a, V3<R> b) { return mk<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename R> __device__ inline V3<R> operator*(V3<R> a, R s) { return mk<R>(a.x * s, a.y * s, a.z * s); }
+template <typename R> __device__ inline V3<R> operator-(V3<R> a) { return mk<R>(-a.x, -a.y, -a.z); }
+template <typename R> __device__ inline R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename R> __device__ inline V3<R> cross(V3<R> a, V3<R> b)
+{
+    return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ inline float rsqrt_r(float x) { return 1.0f / sqrtf(x); }
+__device__ inline double rsqrt_r(double x) { return 1.0 / sqrt(x); }
+__device__ inline float sqrt_r(float x) { return sqrtf(x); }
+__device__ inline double sqrt_r(double x) { return sqrt(x); }
+__device__ inline float abs_r(float x) { return fabsf(x); }
+__device__ inline double abs_r(double x) { return fabs(x); }
+__device__ inline float pow_r(float x, float y) { return powf(x, y); }
+__device__ inline double pow_r(double x, double y) { return pow(x, y); }
+__device__ inline void sincospi_r(float x, float* s, float* c) { sincospif(x, s, c); }
+__device__ inline void sincospi_r(double x, double* s, double* c) { sincospi(x, s, c); }
+template <typename R> __device__ inline V3<R> normalize(V3<R> a) { return a * rsqrt_r(dot(a, a)); }
+// vector.hpp:602-606
+template <typename R> __device__ inline V3<R> reflect(V3<R> v, V3<R> n) { return n * (R(2) * dot(n, v)) - v; }
+
+#define DRT_PI 3.14159265358979323846
+#define DRT_RAND_MAX_D 2147483647.0
+
+// ---- shapes: shape.hpp:49-59 (Plane), 78-106 (Sphere) ----------------------------------------
+// Same predicates as the reference (t > 0, NaN never hits); the caller keeps the first shape on
+// ties (pathtracer.hpp:80).
+template <typename R>
+__device__ inline bool shape_intersect(const DevShape<R>& s, V3<R> o, V3<R> d, R& t)
+{
+    if (s.type == DRT_SHAPE_PLANE) {
+        V3<R> n = mk<R>(s.p[0], s.p[1], s.p[2]);
+        R h = dot(o, n) - s.p[3];
+        t = h / -dot(d, n);
+        return t > R(0);
+    }
+    V3<R> oc = o - mk<R>(s.p[0], s.p[1], s.p[2]);
+    R b = R(2) * dot(oc, d);
+    R c = dot(oc, oc) - s.p[3] * s.p[3];
+    R disc = b * b - R(4) * c;
+    if (disc < R(0))
+        return false;
+    R sq = sqrt_r(disc);
+    R t1 = (-b - sq) * R(0.5);
+    R t2 = (-b + sq) * R(0.5);
+    if (t1 > R(0) && t2 > R(0)) {
+        t = t2 < t1 ? t2 : t1;
+        return true;
+    }
+    if (t1 > R(0)) {
+        t = t1;
+        return true;
+    }
+    if (t2 > R(0)) {
+        t = t2;
+        return true;
+    }
+    return false;
+}
+
+template <typename R>
+__device__ inline V3<R> shape_normal(const DevShape<R>& s, V3<R> p)
+{
+    if (s.type == DRT_SHAPE_PLANE)
+        return mk<R>(s.p[0], s.p[1], s.p[2]);           // as stored, not normalised
+    return normalize(p - mk<R>(s.p[0], s.p[1], s.p[2]));
+}
+
+// bxdf.hpp:29-41 make_frame: Gram-Schmidt against e1 or e2, frame[2] = normal AS GIVEN
+template <typename R>
+__device__ inline void make_frame(V3<R> n, V3<R>& t, V3<R>& b)
+{
+    if (abs_r(n.x) < abs_r(n.y))
+        t = normalize(mk<R>(R(1) - n.x * n.x, -n.y * n.x, -n.z * n.x));
+    else
+        t = normalize(mk<R>(-n.x * n.y, R(1) - n.y * n.y, -n.z * n.y));
+    b = normalize(cross(n, t));
+}
+
+// ---- wave64 queue append: ballot + mbcnt prefix, one atomic per wave (K4 fused into K1/K3) ---
+// Every lane of the wave must call this (convergent).
+__device__ inline uint32_t wave_append(uint32_t* counter, bool alive)
+{
+    const uint64_t mask = __ballot(alive);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t base = 0;
+    if (mask != 0) {
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        if ((int)(threadIdx.x & (DRT_WAVE - 1)) == leader)
+            base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+    }
+    return base + rank;
+}

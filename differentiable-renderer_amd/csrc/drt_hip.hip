@@ -1,0 +1,627 @@
+// drt_hip.hip -- host runtime of libdrt_hip.so: the C ABI of include/drt_hip.h over the
+// wavefront kernels of drt_kernels.h.  One context = one gfx950 device + one stream; every
+// bounce is two launches (K2, K3) on persistent grids that read their queue length from device
+// memory, so a whole render is enqueued without a single host round trip.
+#include "drt_kernels.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct TimedLaunch {
+    int kernel;
+    hipEvent_t e0, e1;
+};
+
+} // namespace
+
+struct drt_hip_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    bool has_scene = false;
+    int n_params = 0, n_shapes = 0;
+    std::vector<uint8_t> requires_grad;
+    std::vector<drt_material_desc> materials;
+    DevScene<float>* d_scene_f = nullptr;
+    DevScene<double>* d_scene_d = nullptr;
+    float* d_params_f = nullptr;
+    double* d_params_d = nullptr;
+
+    DevBuf ray_a[2], ray_b[2], hit, lacc, rec, ids, nv, counts, film, gpart, grad, adjoint, out;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    std::vector<TimedLaunch> timed;
+    std::vector<uint32_t> h_counts;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return e_ == hipErrorOutOfMemory ? DRT_ERR_OOM : DRT_ERR_HIP;                     \
+        }                                                                                     \
+    } while (0)
+
+int fail(drt_hip_ctx* ctx, int code, const char* msg)
+{
+    ctx->err = msg;
+    return code;
+}
+
+int ensure(drt_hip_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return DRT_OK;
+    if (b.p) {
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        e = hipMalloc(&b.p, want);
+    }
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return DRT_ERR_OOM;
+    }
+    b.cap = want;
+    return DRT_OK;
+}
+
+void release(DevBuf& b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+template <typename R>
+void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s)
+{
+    memset(&ds, 0, sizeof ds);
+    ds.n_shapes = s->n_shapes;
+    ds.n_materials = s->n_materials;
+    ds.n_emitters = s->n_emitters;
+    ds.n_params = s->n_params;
+    for (int i = 0; i < s->n_shapes; ++i) {
+        for (int j = 0; j < 4; ++j)
+            ds.shapes[i].p[j] = (R)s->shapes[i].p[j];
+        ds.shapes[i].type = s->shapes[i].type;
+        ds.shapes[i].material = s->shapes[i].material;
+        ds.shapes[i].emitter = s->shapes[i].emitter;
+    }
+    for (int i = 0; i < s->n_materials; ++i) {
+        ds.materials[i].type = s->materials[i].type;
+        ds.materials[i].param = s->materials[i].param;
+        ds.materials[i].exponent = (R)s->materials[i].exponent;
+        ds.materials[i].norm = (R)((s->materials[i].exponent + 2.0) / (2.0 * DRT_PI));
+    }
+    for (int i = 0; i < s->n_emitters; ++i)
+        ds.emitter_param[i] = s->emitters[i].param;
+    params.resize((size_t)s->n_params * 3);
+    for (size_t i = 0; i < params.size(); ++i)
+        params[i] = (R)s->params[i];
+}
+
+// event-bracketed launch bookkeeping (DRT_RENDER_TIMING)
+int timing_begin(drt_hip_ctx* ctx, bool on, int kernel)
+{
+    if (!on)
+        return DRT_OK;
+    while (ctx->event_pool.size() < ctx->events_used + 2) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ctx->event_pool.push_back(e);
+    }
+    TimedLaunch t;
+    t.kernel = kernel;
+    t.e0 = ctx->event_pool[ctx->events_used++];
+    t.e1 = ctx->event_pool[ctx->events_used++];
+    HIPCHK(ctx, hipEventRecord(t.e0, ctx->stream));
+    ctx->timed.push_back(t);
+    return DRT_OK;
+}
+
+int timing_end(drt_hip_ctx* ctx, bool on)
+{
+    if (!on)
+        return DRT_OK;
+    HIPCHK(ctx, hipEventRecord(ctx->timed.back().e1, ctx->stream));
+    return DRT_OK;
+}
+
+int grid_for(const drt_hip_ctx* ctx, uint64_t work)
+{
+    uint64_t blocks = (work + DRT_BLOCK - 1) / DRT_BLOCK;
+    uint64_t cap = (uint64_t)ctx->n_cu * 8;   // persistent grid: 8 x 256-thread blocks per CU
+    if (blocks > cap)
+        blocks = cap;
+    if (blocks < 1)
+        blocks = 1;
+    return (int)blocks;
+}
+
+template <typename R>
+int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                const float* d_adjoint, float* d_out_rgb, bool backward, bool timing,
+                drt_hip_stats* st, uint32_t n_local_pixels, int depth_cap, size_t* n_count_words,
+                double* film)
+{
+    typedef typename Q4<R>::T R4;
+    const DevScene<R>* d_scene = sizeof(R) == 4 ? (const DevScene<R>*)ctx->d_scene_f
+                                                : (const DevScene<R>*)ctx->d_scene_d;
+    const R* d_params = sizeof(R) == 4 ? (const R*)ctx->d_params_f : (const R*)ctx->d_params_d;
+    const int spp = rp->spp;
+    const uint64_t total_paths = (uint64_t)n_local_pixels * (uint64_t)spp;
+    uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
+    if (const char* e = getenv("DRT_HIP_BATCH_PATHS")) {
+        long long v = atoll(e);
+        if (v > 0)
+            cap = (uint64_t)v;
+    }
+    if (cap > total_paths)
+        cap = total_paths;
+    if (cap < 1)
+        cap = 1;
+    if (cap > 0x7FFFFFFFull)
+        cap = 0x7FFFFFFFull;
+    uint32_t Pb = (uint32_t)(cap / (uint64_t)spp);
+    if (Pb < 1) Pb = 1;
+    if (Pb > n_local_pixels) Pb = n_local_pixels;
+    uint32_t Sb = (uint32_t)(cap / Pb);
+    if (Sb > (uint32_t)spp) Sb = (uint32_t)spp;
+    if (Sb < 1) Sb = 1;
+    const size_t N = (size_t)Pb * Sb;   // batch capacity in paths
+    const int D = depth_cap;
+
+    int rc;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ray_b[i], N * sizeof(R4))) != DRT_OK) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->rec, N * sizeof(R4) * (backward ? (size_t)(D > 0 ? D : 1) : 1))) != DRT_OK) return rc;
+    if (backward) {
+        if ((rc = ensure(ctx, ctx->ids, N * sizeof(uint32_t) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
+    }
+    const uint64_t n_pix_batches = (n_local_pixels + Pb - 1) / Pb;
+    const uint64_t n_s_batches = ((uint64_t)spp + Sb - 1) / Sb;
+    const uint64_t n_batches = n_pix_batches * n_s_batches;
+    const size_t cw = (size_t)(D + 2);
+    *n_count_words = (size_t)n_batches * cw;
+    if ((rc = ensure(ctx, ctx->counts, *n_count_words * sizeof(uint32_t))) != DRT_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->counts.p, 0, *n_count_words * sizeof(uint32_t), ctx->stream));
+    const int bwd_grid = grid_for(ctx, N);
+    if (backward)
+        if ((rc = ensure(ctx, ctx->gpart, (size_t)bwd_grid * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
+
+    BatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = cam->width; a.H = cam->height; a.spp = spp;
+    a.shard = rp->n_shards > 1 ? rp->shard : 0;
+    a.n_shards = rp->n_shards > 1 ? rp->n_shards : 1;
+    a.band = rp->band_rows > 0 ? rp->band_rows : 1;
+    a.min_bounces = rp->min_bounces;
+    a.depth_cap = D;
+    a.absorb = rp->absorb;
+    a.seed = rp->seed;
+    for (int i = 0; i < 3; ++i) {
+        a.eye[i] = cam->eye[i]; a.fwd[i] = cam->forward[i];
+        a.right[i] = cam->right[i]; a.up[i] = cam->up[i];
+    }
+    a.tan_half = tan(cam->vfov / 2.);
+    a.aspect = (double)cam->width / (double)cam->height;
+
+    R4* ra[2] = {(R4*)ctx->ray_a[0].p, (R4*)ctx->ray_a[1].p};
+    R4* rb[2] = {(R4*)ctx->ray_b[0].p, (R4*)ctx->ray_b[1].p};
+    HitRec<R>* hit = (HitRec<R>*)ctx->hit.p;
+    R4* lacc = (R4*)ctx->lacc.p;
+    R4* rec = (R4*)ctx->rec.p;
+    uint32_t* ids = (uint32_t*)ctx->ids.p;
+    uint32_t* nv = backward ? (uint32_t*)ctx->nv.p : nullptr;
+    double* grad = (double*)ctx->grad.p;
+    double* gpart = (double*)ctx->gpart.p;
+    const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
+
+    uint64_t batch = 0;
+    for (uint32_t p0 = 0; p0 < n_local_pixels; p0 += Pb) {
+        for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += Sb, ++batch) {
+            a.p0 = p0; a.s0 = s0;
+            a.Pb = (n_local_pixels - p0) < Pb ? (n_local_pixels - p0) : Pb;
+            a.Sb = ((uint32_t)spp - s0) < Sb ? ((uint32_t)spp - s0) : Sb;
+            a.n_paths = a.Pb * a.Sb;
+            uint32_t* counts = (uint32_t*)ctx->counts.p + batch * cw;
+            const int g = grid_for(ctx, a.n_paths);
+
+            if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
+            hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
+                               lacc, nv, counts);
+            if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+            st->launches[DRT_K_RAYGEN]++;
+            st->units[DRT_K_RAYGEN] += a.n_paths;
+
+            for (int k = 0; k < D; ++k) {
+                const int cur = k & 1, nxt = cur ^ 1;
+                if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_intersect<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, d_scene,
+                                   ra[cur], rb[cur], hit, counts + k);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_INTERSECT]++;
+
+                R4* rec_in = backward ? rec + (size_t)(k > 0 ? k - 1 : 0) * a.n_paths : rec;
+                R4* rec_out = backward ? rec + (size_t)k * a.n_paths : rec;
+                uint32_t* ids_k = backward ? ids + (size_t)k * a.n_paths : nullptr;
+                if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
+                if (backward)
+                    hipLaunchKernelGGL((k_shade<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
+                                       d_scene, d_params, ra[cur], rb[cur], hit, ra[nxt], rb[nxt], rec_in,
+                                       rec_out, ids_k, nv, lacc, counts);
+                else
+                    hipLaunchKernelGGL((k_shade<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
+                                       d_scene, d_params, ra[cur], rb[cur], hit, ra[nxt], rb[nxt], rec_in,
+                                       rec_out, ids_k, nv, lacc, counts);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_SHADE]++;
+            }
+
+            if (film) {
+                if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
+                                   lacc, film);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_FILM]++;
+                st->units[DRT_K_FILM] += a.n_paths;
+            }
+            if (backward && D > 0) {
+                if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_backward<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                   d_params, rec, ids, nv, d_adjoint, gpart, grad);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_BACKWARD]++;
+                if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, g, n_fast,
+                                   grad);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_GRADREDUCE]++;
+                st->units[DRT_K_GRADREDUCE] += (uint64_t)g;
+            }
+        }
+    }
+    st->batches = batch;
+    st->paths = total_paths;
+    if (film && d_out_rgb) {
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
+                           a, n_local_pixels, film, d_out_rgb);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return DRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int drt_hip_abi_version(void) { return DRT_HIP_ABI_VERSION; }
+
+int drt_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int drt_hip_create(int device_id, drt_hip_ctx** out)
+{
+    if (!out)
+        return DRT_ERR_INVALID;
+    *out = nullptr;
+    int n = drt_hip_device_count();
+    if (n <= 0 || device_id < 0 || device_id >= n)
+        return DRT_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess)
+        return DRT_ERR_NO_DEVICE;
+    drt_hip_ctx* ctx = new drt_hip_ctx();
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return DRT_ERR_HIP;
+    }
+    *out = ctx;
+    return DRT_OK;
+}
+
+void drt_hip_destroy(drt_hip_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->hit, &ctx->lacc,
+                      &ctx->rec, &ctx->ids, &ctx->nv, &ctx->counts, &ctx->film, &ctx->gpart, &ctx->grad,
+                      &ctx->adjoint, &ctx->out};
+    for (DevBuf* b : bufs)
+        release(*b);
+    if (ctx->d_scene_f) (void)hipFree(ctx->d_scene_f);
+    if (ctx->d_scene_d) (void)hipFree(ctx->d_scene_d);
+    if (ctx->d_params_f) (void)hipFree(ctx->d_params_f);
+    if (ctx->d_params_d) (void)hipFree(ctx->d_params_d);
+    for (hipEvent_t e : ctx->event_pool)
+        (void)hipEventDestroy(e);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (!s || s->n_shapes < 0 || s->n_shapes > DRT_MAX_SHAPES || s->n_materials < 0 ||
+        s->n_materials > DRT_MAX_MATERIALS || s->n_emitters < 0 || s->n_emitters > DRT_MAX_EMITTERS ||
+        s->n_params < 0 || s->n_params >= (int)DRT_ID_NONE ||
+        (s->n_shapes && !s->shapes) || (s->n_materials && !s->materials) ||
+        (s->n_emitters && !s->emitters) || (s->n_params && !s->params))
+        return fail(ctx, DRT_ERR_INVALID, "scene: bad counts or null arrays");
+    for (int i = 0; i < s->n_shapes; ++i) {
+        const drt_shape_desc& sh = s->shapes[i];
+        if (sh.type == DRT_SHAPE_MESH)
+            return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: DRT_SHAPE_MESH is reserved, not built yet");
+        if (sh.type != DRT_SHAPE_PLANE && sh.type != DRT_SHAPE_SPHERE)
+            return fail(ctx, DRT_ERR_INVALID, "scene: unknown shape type");
+        if (sh.material < -1 || sh.material >= s->n_materials || sh.emitter < -1 || sh.emitter >= s->n_emitters)
+            return fail(ctx, DRT_ERR_INVALID, "scene: shape material/emitter index out of range");
+    }
+    for (int i = 0; i < s->n_materials; ++i) {
+        if (s->materials[i].type == DRT_BXDF_MIRROR)
+            return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: DRT_BXDF_MIRROR is reserved (the reference's does not compile)");
+        if (s->materials[i].type != DRT_BXDF_DIFFUSE && s->materials[i].type != DRT_BXDF_SPECULAR)
+            return fail(ctx, DRT_ERR_INVALID, "scene: unknown material type");
+        if (s->materials[i].param < 0 || s->materials[i].param >= s->n_params)
+            return fail(ctx, DRT_ERR_INVALID, "scene: material parameter index out of range");
+    }
+    for (int i = 0; i < s->n_emitters; ++i)
+        if (s->emitters[i].param < 0 || s->emitters[i].param >= s->n_params)
+            return fail(ctx, DRT_ERR_INVALID, "scene: emitter parameter index out of range");
+
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    DevScene<float>* hf = new DevScene<float>();
+    DevScene<double>* hd = new DevScene<double>();
+    std::vector<float> pf;
+    std::vector<double> pd;
+    fill_scene(*hf, pf, s);
+    fill_scene(*hd, pd, s);
+    int rc = DRT_OK;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e == hipSuccess && bytes)
+            e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ctx->err = std::string("scene upload: ") + hipGetErrorString(e);
+            return DRT_ERR_HIP;
+        }
+        return DRT_OK;
+    };
+    if (rc == DRT_OK) rc = up((void**)&ctx->d_scene_f, hf, sizeof *hf);
+    if (rc == DRT_OK) rc = up((void**)&ctx->d_scene_d, hd, sizeof *hd);
+    if (rc == DRT_OK) rc = up((void**)&ctx->d_params_f, pf.data(), pf.size() * sizeof(float));
+    if (rc == DRT_OK) rc = up((void**)&ctx->d_params_d, pd.data(), pd.size() * sizeof(double));
+    delete hf;
+    delete hd;
+    if (rc != DRT_OK)
+        return rc;
+    ctx->n_params = s->n_params;
+    ctx->n_shapes = s->n_shapes;
+    ctx->requires_grad.assign((size_t)s->n_params, 1);
+    if (s->requires_grad)
+        for (int i = 0; i < s->n_params; ++i)
+            ctx->requires_grad[i] = s->requires_grad[i] ? 1 : 0;
+    ctx->has_scene = true;
+    return DRT_OK;
+}
+
+int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (!ctx->has_scene)
+        return fail(ctx, DRT_ERR_NO_SCENE, "update_params before upload_scene");
+    if (!params)
+        return fail(ctx, DRT_ERR_INVALID, "params is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<float> pf((size_t)ctx->n_params * 3);
+    for (size_t i = 0; i < pf.size(); ++i)
+        pf[i] = (float)params[i];
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(ctx->d_params_f, pf.data(), pf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->d_params_d, params, pf.size() * sizeof(double), hipMemcpyHostToDevice));
+    return DRT_OK;
+}
+
+int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                   const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (!ctx->has_scene)
+        return fail(ctx, DRT_ERR_NO_SCENE, "render before upload_scene");
+    if (!cam || !rp || cam->width <= 0 || cam->height <= 0 || rp->spp <= 0 || rp->min_bounces < 0 ||
+        !(rp->absorb >= 0.0 && rp->absorb <= 1.0))
+        return fail(ctx, DRT_ERR_INVALID, "render: bad camera or render parameters");
+    if ((uint64_t)cam->width * (uint64_t)cam->height >= 0xFFFFFFFFull)
+        return fail(ctx, DRT_ERR_INVALID, "render: image too large");
+    const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;
+    const int band = rp->band_rows > 0 ? rp->band_rows : 1;
+    if (n_shards > 1 && (rp->shard < 0 || rp->shard >= n_shards))
+        return fail(ctx, DRT_ERR_INVALID, "render: shard out of range");
+    const bool backward = (rp->flags & DRT_RENDER_BACKWARD) != 0;
+    const bool dev_out = (rp->flags & DRT_RENDER_DEVICE_OUT) != 0;
+    const bool timing = (rp->flags & DRT_RENDER_TIMING) != 0;
+    const bool f64 = (rp->flags & DRT_RENDER_F64) != 0;
+    if (backward && !out_param_grad)
+        return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
+
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    // rows owned by this shard
+    uint32_t local_rows = 0;
+    for (int y = 0; y < cam->height; ++y)
+        if (n_shards == 1 || (y / band) % n_shards == rp->shard)
+            ++local_rows;
+    const uint32_t n_local_pixels = local_rows * (uint32_t)cam->width;
+
+    // deepest vertex a path can reach: absorb == 1 kills every path at depth min_bounces
+    int depth_cap = rp->max_depth > 0 ? rp->max_depth : 64;
+    if (rp->absorb >= 1.0 && rp->min_bounces < depth_cap)
+        depth_cap = rp->min_bounces;
+
+    drt_hip_stats st;
+    memset(&st, 0, sizeof st);
+    ctx->events_used = 0;
+    ctx->timed.clear();
+
+    int rc;
+    const size_t npix_all = (size_t)cam->width * cam->height;
+    float* d_out = nullptr;
+    const float* d_adj = nullptr;
+    if (out_rgb) {
+        if ((rc = ensure(ctx, ctx->film, (size_t)(n_local_pixels ? n_local_pixels : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->film.p, 0, (size_t)(n_local_pixels ? n_local_pixels : 1) * 3 * sizeof(double), ctx->stream));
+        if (dev_out) {
+            d_out = out_rgb;
+        } else {
+            if ((rc = ensure(ctx, ctx->out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+            d_out = (float*)ctx->out.p;
+            if (n_shards > 1)   // rows of other shards must come back untouched
+                HIPCHK(ctx, hipMemcpyAsync(d_out, out_rgb, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    if (backward) {
+        if ((rc = ensure(ctx, ctx->grad, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double), ctx->stream));
+        if (adjoint_rgb) {
+            if (dev_out) {
+                d_adj = adjoint_rgb;
+            } else {
+                if ((rc = ensure(ctx, ctx->adjoint, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->adjoint.p, adjoint_rgb, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                d_adj = (const float*)ctx->adjoint.p;
+            }
+        }
+    }
+    size_t n_count_words = 0;
+    double* d_film = out_rgb ? (double*)ctx->film.p : nullptr;   // no image requested: skip K5
+    rc = DRT_OK;
+    if (n_local_pixels > 0) {
+        if (f64)
+            rc = render_impl<double>(ctx, cam, rp, d_adj, d_out, backward, timing, &st, n_local_pixels,
+                                     depth_cap, &n_count_words, d_film);
+        else
+            rc = render_impl<float>(ctx, cam, rp, d_adj, d_out, backward, timing, &st, n_local_pixels,
+                                    depth_cap, &n_count_words, d_film);
+    }
+    if (rc != DRT_OK)
+        return rc;
+
+    // parameters that do not require grad keep a zero gradient (vector.hpp:156-162)
+    if (backward && dev_out) {
+        for (int p = 0; p < ctx->n_params; ++p)
+            if (!ctx->requires_grad[p])
+                HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)p * 3, 0, 3 * sizeof(double), ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+
+    const bool sync = !dev_out || (rp->flags & DRT_RENDER_SYNC) || timing || stats;
+    if (!dev_out) {
+        if (out_rgb)
+            HIPCHK(ctx, hipMemcpyAsync(out_rgb, d_out, npix_all * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (backward)
+            HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_params * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (stats && n_count_words) {
+        ctx->h_counts.resize(n_count_words);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts.data(), ctx->counts.p, n_count_words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (sync)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!dev_out && backward)
+        for (int p = 0; p < ctx->n_params; ++p)
+            if (!ctx->requires_grad[p])
+                out_param_grad[p * 3] = out_param_grad[p * 3 + 1] = out_param_grad[p * 3 + 2] = 0.0;
+
+    if (stats) {
+        const size_t cw = (size_t)depth_cap + 2;
+        for (size_t b = 0; b * cw < n_count_words; ++b)
+            for (int k = 0; k < depth_cap; ++k)
+                st.segments += ctx->h_counts[b * cw + (size_t)k];
+        st.units[DRT_K_INTERSECT] = st.segments;
+        st.units[DRT_K_SHADE] = st.segments;
+        st.units[DRT_K_BACKWARD] = backward ? st.segments : 0;
+        if (timing) {
+            for (const TimedLaunch& t : ctx->timed) {
+                float ms = 0;
+                HIPCHK(ctx, hipEventElapsedTime(&ms, t.e0, t.e1));
+                st.ms_kernel[t.kernel] += (double)ms;
+            }
+        }
+        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *stats = st;
+    }
+    return DRT_OK;
+}
+
+void* drt_hip_stream(drt_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int drt_hip_synchronize(drt_hip_ctx* ctx)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DRT_OK;
+}
+
+const char* drt_hip_last_error(drt_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char* drt_hip_kernel_name(int k)
+{
+    static const char* names[DRT_K_COUNT] = {"k_raygen", "k_intersect", "k_shade", "k_film",
+                                             "k_backward", "k_gradreduce", "", ""};
+    return (k >= 0 && k < DRT_K_COUNT) ? names[k] : "";
+}
+
+} // extern "C"

@@ -1,0 +1,477 @@
+// drt_kernels.h -- the wavefront kernels K1..K7 (gfx950 / wave64).
+//
+//   K1 raygen      Camera::sample (camera.hpp:51-60) + depth-0 roulette (pathtracer.hpp:128)
+//   K2 intersect   Pathtracer::raycast (pathtracer.hpp:72-89) over Plane/Sphere records
+//   K3 shade       Pathtracer::scatter (pathtracer.hpp:91-115): emission, BxDF sample + eval,
+//                  throughput update, next-depth roulette, tape write, and the queue append
+//                  (K4: wave ballot + prefix, one atomic per wave)
+//   K5 film        the per-pixel mean of render.cpp:76-82
+//   K6 backward    reverse sweep of the per-bounce tape = the backward functors of
+//                  vector.hpp:418-484 in closed form
+//   K7 gradreduce  VariableNode::backward's `m_grad += grad` (vector.hpp:185-188), fixed order
+//
+// Data layout in HBM (R = float, 16-byte lanes; R = double doubles every lane):
+//   ray_a[2][N]  (o.x, o.y, o.z, d.x)         dense by queue slot, ping-pong per bounce
+//   ray_b[2][N]  (d.y, d.z, path index, -)
+//   hit[N]       (t, shape index | -1)         dense by queue slot
+//   rec[D][N]    (T_{k+1}.rgb, m_k)            by path index; D = 1 (in place) when forward only
+//   ids[D][N]    colour param | emission param << 16      (backward only)
+//   nv[N]        vertices of the path                      (backward only)
+//   lacc[N]      (L.rgb, -) radiance accumulated along the path, by path index
+//   counts[D+1]  queue lengths per depth (device-resident: no host round trip per bounce)
+// Path index i of a batch = (s - s0) * Pb + (pixel - p0): sample-major, so neighbouring lanes
+// are neighbouring pixels (coherent rays, coalesced film reads).
+#pragma once
+
+#include "drt_device.h"
+
+struct BatchArgs {
+    // batch geometry
+    uint32_t n_paths;        // Pb * Sb
+    uint32_t Pb, p0;         // pixels in the batch, first shard-local pixel
+    uint32_t Sb, s0;         // samples in the batch, first sample
+    // image / sharding
+    int32_t W, H, spp;
+    int32_t shard, n_shards, band;
+    // integrator
+    int32_t min_bounces, depth_cap;
+    double absorb;
+    uint32_t seed;
+    // camera (double: per-path work, not per-segment)
+    double eye[3], fwd[3], right[3], up[3];
+    double tan_half, aspect;
+};
+
+// shard-local pixel -> global pixel (y * W + x); rows are dealt to shards in bands
+__device__ inline uint32_t global_pixel(const BatchArgs& a, uint32_t lp)
+{
+    uint32_t ly = lp / (uint32_t)a.W, x = lp - ly * (uint32_t)a.W;
+    uint32_t y = ly;
+    if (a.n_shards > 1) {
+        uint32_t b = ly / (uint32_t)a.band, r = ly - b * (uint32_t)a.band;
+        y = (b * (uint32_t)a.n_shards + (uint32_t)a.shard) * (uint32_t)a.band + r;
+    }
+    return y * (uint32_t)a.W + x;
+}
+
+// index of the first BxDF draw at depth k: 2 camera draws, 2 per earlier vertex, one roulette
+// draw per depth >= min_bounces up to and including k (draw order: SURVEY 3.1)
+__device__ inline uint32_t draw_index(int k, int min_bounces)
+{
+    int rr = k - min_bounces + 1;
+    return 2u + 2u * (uint32_t)k + (uint32_t)(rr > 0 ? rr : 0);
+}
+
+// ---- K1 ---------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* __restrict__ ray_b,
+         typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
+{
+    typedef typename Q4<R>::T R4;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < a.n_paths; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < a.n_paths;
+        bool alive = valid;
+        R4 ra, rb;
+        if (valid) {
+            const uint32_t sl = i / a.Pb, pl = i - sl * a.Pb;
+            const uint32_t gpix = global_pixel(a, a.p0 + pl);
+            const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
+            const uint32_t key = drt_rng_path_key(a.seed, path);
+            const uint32_t y = gpix / (uint32_t)a.W, x = gpix - y * (uint32_t)a.W;
+            // camera.hpp:53-58
+            const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
+            const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
+            const double s = ((double)x + u1) / (double)a.W;
+            const double t = ((double)y + u2) / (double)a.H;
+            const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
+            const double ct = (2. * t - 1.) * a.tan_half;
+            double dx = a.fwd[0] + cs * a.right[0] - ct * a.up[0];
+            double dy = a.fwd[1] + cs * a.right[1] - ct * a.up[1];
+            double dz = a.fwd[2] + cs * a.right[2] - ct * a.up[2];
+            const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+            dx *= inv; dy *= inv; dz *= inv;
+            // pathtracer.hpp:128 at depth 0
+            if (a.depth_cap <= 0)
+                alive = false;
+            else if (a.min_bounces <= 0 &&
+                     (double)drt_rng_draw(key, 2) / DRT_RAND_MAX_D < a.absorb)
+                alive = false;
+            ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dx;
+            rb.x = (R)dy; rb.y = (R)dz; rb.z = pid_pack(R(0), i); rb.w = R(0);
+            R4 zero; zero.x = zero.y = zero.z = zero.w = R(0);
+            lacc[i] = zero;
+            if (nv && !alive)
+                nv[i] = 0;
+        }
+        const uint32_t slot = wave_append(&counts[0], alive);
+        if (alive) {
+            ray_a[slot] = ra;
+            ray_b[slot] = rb;
+        }
+    }
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------
+// Streaming kernel: 2 x 16-byte loads, 1 x 8-byte store per ray; the shape loop index is
+// wave-uniform so the records arrive through the scalar cache into SGPRs.
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_intersect(const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
+            const typename Q4<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
+            const uint32_t* __restrict__ count)
+{
+    typedef typename Q4<R>::T R4;
+    const uint32_t n = *count;
+    const int n_shapes = sc->n_shapes;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
+        const R4 ra = ray_a[slot];
+        const R4 rb = ray_b[slot];
+        const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+        const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+        R tmin = (R)INFINITY;
+        int prim = -1;
+        for (int s = 0; s < n_shapes; ++s) {
+            R t;
+            if (shape_intersect(sc->shapes[s], o, d, t) && !(t >= tmin)) {
+                tmin = t;
+                prim = s;
+            }
+        }
+        HitRec<R> h;
+        h.t = tmin;
+        h.prim = prim;
+        hit[slot] = h;
+    }
+}
+
+// ---- K3 ---------------------------------------------------------------------------------------
+template <typename R>
+struct SceneLds {
+    DevScene<R> sc;
+    R params[DRT_LDS_PARAMS * 3];
+};
+
+template <typename R>
+__device__ inline void stage_scene(SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
+                                   const R* __restrict__ params)
+{
+    const int* src = reinterpret_cast<const int*>(sc);
+    int* dst = reinterpret_cast<int*>(&lds.sc);
+    for (int i = threadIdx.x; i < (int)(sizeof(DevScene<R>) / sizeof(int)); i += blockDim.x)
+        dst[i] = src[i];
+    const int np = sc->n_params < DRT_LDS_PARAMS ? sc->n_params : DRT_LDS_PARAMS;
+    for (int i = threadIdx.x; i < np * 3; i += blockDim.x)
+        lds.params[i] = params[i];
+    __syncthreads();
+}
+
+template <typename R>
+__device__ inline V3<R> load_param(const SceneLds<R>& lds, const R* __restrict__ params, int id)
+{
+    if (id < DRT_LDS_PARAMS)
+        return mk<R>(lds.params[id * 3], lds.params[id * 3 + 1], lds.params[id * 3 + 2]);
+    return mk<R>(params[id * 3], params[id * 3 + 1], params[id * 3 + 2]);
+}
+
+template <typename R, bool BWD>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
+        const typename Q4<R>::T* __restrict__ ray_a, const typename Q4<R>::T* __restrict__ ray_b,
+        const HitRec<R>* __restrict__ hit,
+        typename Q4<R>::T* __restrict__ next_a, typename Q4<R>::T* __restrict__ next_b,
+        const typename Q4<R>::T* rec_in,   // rec[k-1] (may alias rec_out when forward only)
+        typename Q4<R>::T* rec_out,        // rec[k]
+        uint32_t* __restrict__ ids_k, uint32_t* __restrict__ nv,
+        typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ counts)
+{
+    typedef typename Q4<R>::T R4;
+    __shared__ SceneLds<R> lds;
+    stage_scene(lds, sc, params);
+
+    const uint32_t n = counts[k];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
+    const R inv_pk = R(1) / pk;
+    const uint32_t n_theta = draw_index(k, a.min_bounces);
+    const bool next_rr = (k + 1) >= a.min_bounces;
+    const bool next_cap = (k + 1) >= a.depth_cap;
+
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t slot = base + threadIdx.x;
+        bool alive = false;
+        R4 na, nb;
+        if (slot < n) {
+            const R4 ra = ray_a[slot];
+            const R4 rb = ray_b[slot];
+            const HitRec<R> h = hit[slot];
+            const uint32_t pid = pid_unpack(rb.z);
+            if (h.prim < 0) {
+                if (BWD) nv[pid] = (uint32_t)k;               // miss: pathtracer.hpp:135
+            } else {
+                const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+                const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+                const DevShape<R>& sh = lds.sc.shapes[h.prim];
+                const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
+                const V3<R> nrm = shape_normal(sh, P);
+                V3<R> T = mk<R>(R(1), R(1), R(1));
+                if (k > 0) {
+                    const R4 r = rec_in[pid];
+                    T = mk<R>(r.x, r.y, r.z);
+                }
+                uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
+                if (sh.emitter >= 0) {                         // pathtracer.hpp:113-114
+                    eid = (uint32_t)lds.sc.emitter_param[sh.emitter];
+                    const V3<R> E = load_param(lds, params, (int)eid);
+                    R4 L = lacc[pid];
+                    L.x += T.x * E.x * inv_pk;
+                    L.y += T.y * E.y * inv_pk;
+                    L.z += T.z * E.z * inv_pk;
+                    lacc[pid] = L;
+                }
+                if (sh.material < 0) {
+                    // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
+                    // continuation contributes exactly 0, the path ends here
+                    if (BWD) {
+                        ids_k[pid] = DRT_ID_NONE | (eid << 16);
+                        nv[pid] = (uint32_t)k + 1u;
+                    }
+                } else {
+                    const DevMaterial<R>& m = lds.sc.materials[sh.material];
+                    cid = (uint32_t)m.param;
+                    const uint32_t key = drt_rng_path_key(
+                        a.seed, (uint64_t)global_pixel(a, a.p0 + pid % a.Pb) * (uint64_t)a.spp +
+                                    (uint64_t)(a.s0 + pid / a.Pb));
+                    const double u1 = (double)drt_rng_draw(key, n_theta) / DRT_RAND_MAX_D;
+                    const R u2 = (R)((double)drt_rng_draw(key, n_theta + 1) / DRT_RAND_MAX_D);
+                    R sphi, cphi;
+                    sincospi_r(R(2) * u2, &sphi, &cphi);       // phi = 2 pi u2
+                    V3<R> tg, bt;
+                    make_frame(nrm, tg, bt);
+                    V3<R> wo;
+                    R q, bs;
+                    if (m.type == DRT_BXDF_DIFFUSE) {
+                        // bxdf.hpp:69-79: theta = asin(sqrt(u1)) => sin = sqrt(u1), cos = sqrt(1-u1)
+                        // (1 - u1 formed in double so cos never rounds to 0: pdf > 0)
+                        const R st = sqrt_r((R)u1), ct = sqrt_r((R)(1.0 - u1));
+                        wo = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
+                        q = ct * (R)(1.0 / DRT_PI);
+                        bs = (R)(1.0 / DRT_PI);                // bxdf.hpp:63-67: color / pi
+                    } else {
+                        // bxdf.hpp:106-120: cos^2(theta) = u1^(2/(e+2)); sin^2 formed in double
+                        const double c2 = pow(u1, 2.0 / ((double)m.exponent + 2.0));
+                        const R ct = sqrt_r((R)c2), st = sqrt_r((R)(1.0 - c2));
+                        const V3<R> wi = -d;
+                        V3<R> hv = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
+                        if (dot(hv, wi) < R(0))
+                            hv = reflect(hv, nrm);
+                        wo = reflect(wi, hv);
+                        q = m.norm * pow_r(ct, m.exponent + R(1)) * st;
+                        // bxdf.hpp:91-104
+                        const V3<R> hw = normalize(wi + wo);
+                        const R ch = dot(nrm, hw);
+                        R s2 = (R(1) - ch) * (R(1) + ch);
+                        s2 = s2 > R(0) ? s2 : R(0);
+                        bs = m.norm * pow_r(ch, m.exponent) * sqrt_r(s2);
+                    }
+                    const R c = dot(nrm, wo);                  // pathtracer.hpp:103
+                    const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
+                    const V3<R> col = load_param(lds, params, (int)cid);
+                    const V3<R> Tn = T * col * mk_;
+                    // roulette / cap of depth k+1, decided here so dead rays are never queued
+                    alive = !next_cap;
+                    if (alive && next_rr)
+                        alive = !((double)drt_rng_draw(key, n_theta + 2) / DRT_RAND_MAX_D < a.absorb);
+                    if (BWD || alive) {
+                        R4 r; r.x = Tn.x; r.y = Tn.y; r.z = Tn.z; r.w = mk_;
+                        rec_out[pid] = r;
+                    }
+                    if (BWD) {
+                        ids_k[pid] = cid | (eid << 16);
+                        if (!alive) nv[pid] = (uint32_t)k + 1u;
+                    }
+                    const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
+                    na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
+                    nb.x = wo.y; nb.y = wo.z; nb.z = rb.z; nb.w = R(0);
+                }
+            }
+        }
+        const uint32_t ns = wave_append(&counts[k + 1], alive);
+        if (alive) {
+            next_a[ns] = na;
+            next_b[ns] = nb;
+        }
+    }
+}
+
+// ---- K5 ---------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_film(BatchArgs a, const typename Q4<R>::T* __restrict__ lacc, double* __restrict__ film)
+{
+    typedef typename Q4<R>::T R4;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.Pb; j += stride) {
+        double r = 0, g = 0, b = 0;
+        for (uint32_t s = 0; s < a.Sb; ++s) {
+            const R4 L = lacc[(size_t)s * a.Pb + j];
+            r += (double)L.x; g += (double)L.y; b += (double)L.z;
+        }
+        double* f = film + (size_t)(a.p0 + j) * 3;
+        f[0] += r; f[1] += g; f[2] += b;
+    }
+}
+
+// film (sums, shard-local) -> out_rgb (means, global row-major float)
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float* __restrict__ out)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const double inv = 1.0 / (double)a.spp;
+    for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < n_pixels; lp += stride) {
+        const uint32_t gp = global_pixel(a, lp);
+        out[(size_t)gp * 3 + 0] = (float)(film[(size_t)lp * 3 + 0] * inv);
+        out[(size_t)gp * 3 + 1] = (float)(film[(size_t)lp * 3 + 1] * inv);
+        out[(size_t)gp * 3 + 2] = (float)(film[(size_t)lp * 3 + 2] * inv);
+    }
+}
+
+// ---- K6 ---------------------------------------------------------------------------------------
+// One thread per path, vertices walked deepest-first with the suffix radiance in registers:
+//   L_k = E_k / p_k + color_k * m_k * L_{k+1}
+//   d/dE_k     += g * T_k / p_k
+//   d/dcolor_k += g * T_k * m_k * L_{k+1}
+// Parameter ids < DRT_FAST_PARAMS accumulate in registers (compare-select, no atomics, fixed
+// order => bitwise reproducible); other ids use fp64 atomics on the gradient vector.
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
+           const typename Q4<R>::T* __restrict__ rec, const uint32_t* __restrict__ ids,
+           const uint32_t* __restrict__ nv, const float* __restrict__ adjoint,
+           double* __restrict__ gpart, double* __restrict__ grad)
+{
+    typedef typename Q4<R>::T R4;
+    __shared__ SceneLds<R> lds;
+    __shared__ double red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+    stage_scene(lds, sc, params);
+
+    R acc[DRT_FAST_PARAMS][3];
+#pragma unroll
+    for (int p = 0; p < DRT_FAST_PARAMS; ++p)
+        acc[p][0] = acc[p][1] = acc[p][2] = R(0);
+
+    const size_t N = a.n_paths;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
+        const int K = (int)nv[i];
+        if (K <= 0)
+            continue;
+        V3<R> g = mk<R>(R(1), R(1), R(1));                     // render.cpp:80
+        if (adjoint) {
+            const uint32_t gp = global_pixel(a, a.p0 + i % a.Pb);
+            g = mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1],
+                      (R)adjoint[(size_t)gp * 3 + 2]);
+        }
+        V3<R> Ln = mk<R>(R(0), R(0), R(0));
+        R m_k = rec[(size_t)(K - 1) * N + i].w;
+        for (int k = K - 1; k >= 0; --k) {
+            const uint32_t id = ids[(size_t)k * N + i];
+            const uint32_t cid = id & 0xFFFFu, eid = id >> 16;
+            V3<R> T = mk<R>(R(1), R(1), R(1));
+            R m_prev = R(0);
+            if (k > 0) {
+                const R4 r = rec[(size_t)(k - 1) * N + i];
+                T = mk<R>(r.x, r.y, r.z);
+                m_prev = r.w;
+            }
+            const R inv_pk = k >= a.min_bounces ? (R)(1.0 / (1.0 - a.absorb)) : R(1);
+            const V3<R> adj = g * T;
+            V3<R> Lk = mk<R>(R(0), R(0), R(0));
+            if (eid != DRT_ID_NONE) {
+                const V3<R> gE = adj * inv_pk;
+                if (eid < DRT_FAST_PARAMS) {
+#pragma unroll
+                    for (int p = 0; p < DRT_FAST_PARAMS; ++p) {
+                        const bool hitp = eid == (uint32_t)p;
+                        acc[p][0] += hitp ? gE.x : R(0);
+                        acc[p][1] += hitp ? gE.y : R(0);
+                        acc[p][2] += hitp ? gE.z : R(0);
+                    }
+                } else {
+                    atomicAdd(&grad[eid * 3 + 0], (double)gE.x);
+                    atomicAdd(&grad[eid * 3 + 1], (double)gE.y);
+                    atomicAdd(&grad[eid * 3 + 2], (double)gE.z);
+                }
+                Lk = load_param(lds, params, (int)eid) * inv_pk;
+            }
+            if (cid != DRT_ID_NONE) {
+                const V3<R> w = Ln * m_k;
+                const V3<R> gC = adj * w;
+                if (cid < DRT_FAST_PARAMS) {
+#pragma unroll
+                    for (int p = 0; p < DRT_FAST_PARAMS; ++p) {
+                        const bool hitp = cid == (uint32_t)p;
+                        acc[p][0] += hitp ? gC.x : R(0);
+                        acc[p][1] += hitp ? gC.y : R(0);
+                        acc[p][2] += hitp ? gC.z : R(0);
+                    }
+                } else {
+                    atomicAdd(&grad[cid * 3 + 0], (double)gC.x);
+                    atomicAdd(&grad[cid * 3 + 1], (double)gC.y);
+                    atomicAdd(&grad[cid * 3 + 2], (double)gC.z);
+                }
+                Lk = Lk + load_param(lds, params, (int)cid) * w;
+            }
+            Ln = Lk;
+            m_k = m_prev;
+        }
+    }
+
+    // block reduction in fp64: lanes -> wave (shuffles) -> block (LDS), fixed order
+    const int lane = threadIdx.x & (DRT_WAVE - 1), wave = threadIdx.x / DRT_WAVE;
+#pragma unroll
+    for (int p = 0; p < DRT_FAST_PARAMS; ++p) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = (double)acc[p][c];
+#pragma unroll
+            for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
+                v += __shfl_down(v, off);
+            if (lane == 0)
+                red[wave][p * 3 + c] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < DRT_FAST_PARAMS * 3) {
+        double v = 0;
+        for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
+            v += red[w][threadIdx.x];
+        gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
+    }
+}
+
+// ---- K7 ---------------------------------------------------------------------------------------
+// grad[p] += sum over blocks of gpart[block][p], blocks in index order (deterministic)
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_gradreduce(const double* __restrict__ gpart, int n_blocks, int n_fast, double* __restrict__ grad)
+{
+    __shared__ double red[DRT_BLOCK];
+    for (int p = 0; p < n_fast * 3; ++p) {
+        double v = 0;
+        for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
+            v += gpart[(size_t)b * (DRT_FAST_PARAMS * 3) + p];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off)
+                red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            grad[p] += red[0];
+        __syncthreads();
+    }
+}

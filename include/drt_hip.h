@@ -1,0 +1,201 @@
+/*
+ * drt_hip.h -- C ABI of libdrt_hip.so: the MI355X (gfx950) wavefront replacement for the
+ * per-pixel forward integrator + reverse-mode gradient accumulator of
+ * thalesfm/differentiable-renderer.
+ *
+ * What each entry point replaces in the reference (all paths relative to /root/reference):
+ *
+ *   drt_hip_upload_scene    the scene block of src/render.cpp:26-59 (parameters, materials,
+ *                           shapes, Scene vector) flattened to POD records; plugin types are
+ *                           include/drt/shape.hpp:37-111 (Plane, Sphere),
+ *                           include/drt/bxdf.hpp:56-124 (DiffuseBxDF, SpecularBxDF),
+ *                           include/drt/emitter.hpp:15-25 (AreaEmitter).
+ *   drt_hip_update_params   re-assigning the Vector<T,3,true> scene parameters
+ *                           (src/render.cpp:26-29) between optimisation steps.
+ *   drt_hip_render          the pixel x sample loop src/render.cpp:72-86: Camera::sample
+ *                           (include/drt/camera.hpp:51-60) -> Pathtracer::trace
+ *                           (include/drt/pathtracer.hpp:121-136) -> radiance.detach() /
+ *                           radiance.backward(g) (include/drt/vector.hpp:256-284), with the
+ *                           gradient accumulator VariableNode::backward
+ *                           (include/drt/vector.hpp:185-188) as out_param_grad.
+ *
+ * Conventions: every function returns 0 on success or a negative drt_status; nothing throws
+ * across the ABI; the caller owns every host buffer; the context owns device memory and its
+ * stream; a context is not thread-safe; calls are synchronous unless DRT_RENDER_DEVICE_OUT is
+ * set (then outputs are device pointers, written on the context's stream, and the call returns
+ * after enqueueing unless DRT_RENDER_SYNC is also set).
+ *
+ * There is NO CPU fallback behind this ABI: without a HIP device drt_hip_create fails with
+ * DRT_ERR_NO_DEVICE.
+ */
+#ifndef DRT_HIP_H
+#define DRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRT_HIP_ABI_VERSION 1
+
+typedef enum drt_status {
+    DRT_OK = 0,
+    DRT_ERR_INVALID = -1,     /* bad argument / malformed scene */
+    DRT_ERR_NO_DEVICE = -2,   /* no HIP device / device id out of range */
+    DRT_ERR_HIP = -3,         /* a HIP runtime call failed, see drt_hip_last_error */
+    DRT_ERR_NO_SCENE = -4,    /* render before upload_scene */
+    DRT_ERR_OOM = -5,         /* device allocation failed */
+    DRT_ERR_UNSUPPORTED = -6  /* feature reserved in the ABI but not built yet */
+} drt_status;
+
+/* ---- scene description (host-side POD, doubles: the reference computes in double,
+ *      src/render.cpp:22; the device converts to its compute type) ------------------------ */
+
+enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2 /* reserved */ };
+enum { DRT_BXDF_DIFFUSE = 0, DRT_BXDF_SPECULAR = 1, DRT_BXDF_MIRROR = 2 /* reserved */ };
+
+typedef struct drt_shape_desc {
+    int32_t type;      /* DRT_SHAPE_* */
+    int32_t material;  /* index into materials, -1 = no BxDF (shape.hpp:26-27 returns nullptr) */
+    int32_t emitter;   /* index into emitters,  -1 = no emitter (shape.hpp:29-30) */
+    int32_t reserved;
+    double p[4];       /* PLANE: normal.xyz (NOT normalised, shape.hpp:58-59), offset
+                          SPHERE: center.xyz, radius */
+} drt_shape_desc;
+
+typedef struct drt_material_desc {
+    int32_t type;      /* DRT_BXDF_* */
+    int32_t param;     /* index of the colour parameter (bxdf.hpp:82,122 m_color) */
+    double exponent;   /* SPECULAR only (bxdf.hpp:123), not differentiable */
+} drt_material_desc;
+
+typedef struct drt_emitter_desc {
+    int32_t param;     /* index of the emission parameter (emitter.hpp:24) */
+    int32_t reserved;
+} drt_emitter_desc;
+
+typedef struct drt_scene_desc {
+    int32_t n_shapes, n_materials, n_emitters, n_params;
+    const drt_shape_desc* shapes;        /* order = Scene order: first shape wins ties,
+                                            pathtracer.hpp:80 */
+    const drt_material_desc* materials;
+    const drt_emitter_desc* emitters;
+    const double* params;                /* n_params x 3 (RGB) */
+    const uint8_t* requires_grad;        /* n_params, NULL = all true */
+} drt_scene_desc;
+
+typedef struct drt_camera_desc {
+    int32_t width, height;
+    double vfov;                          /* camera.hpp:15 default 1.3963 */
+    double eye[3], forward[3], right[3], up[3];   /* as stored by Camera / look_at,
+                                                     camera.hpp:29-37 */
+} drt_camera_desc;
+
+/* render flags */
+#define DRT_RENDER_BACKWARD   0x1u  /* also run the tape backward pass -> out_param_grad */
+#define DRT_RENDER_DEVICE_OUT 0x2u  /* out_rgb / out_param_grad / adjoint are DEVICE pointers */
+#define DRT_RENDER_SYNC       0x4u  /* with DEVICE_OUT: synchronise the stream before return */
+#define DRT_RENDER_TIMING     0x8u  /* bracket every kernel launch with HIP events -> stats */
+#define DRT_RENDER_F64        0x10u /* compute in double on the device (verification mode) */
+
+typedef struct drt_render_params {
+    int32_t spp;            /* samples per pixel            (args.hpp:36-43, -n) */
+    int32_t min_bounces;    /* Pathtracer ctor              (args.hpp:44-51, -b) */
+    double absorb;          /* Pathtracer ctor              (args.hpp:52-59, -p) */
+    int32_t max_depth;      /* extension: hard cap on path vertices; <=0 = default 64.
+                               The reference has none (termination by roulette only). */
+    uint32_t seed;          /* key of the counter RNG, see drt_rng_u31 */
+    int32_t shard, n_shards, band_rows;  /* pixel sharding: image rows are cut into bands of
+                               band_rows rows dealt round-robin to n_shards; this call renders
+                               the bands of `shard`. n_shards <= 1 renders everything. */
+    uint32_t flags;         /* DRT_RENDER_* */
+    int64_t batch_paths;    /* paths in flight per wavefront batch, <=0 = default */
+} drt_render_params;
+
+enum {
+    DRT_K_RAYGEN = 0,    /* K1 */
+    DRT_K_INTERSECT = 1, /* K2 */
+    DRT_K_SHADE = 2,     /* K3 (+ K4 compaction fused: ballot/prefix-sum queue append) */
+    DRT_K_FILM = 3,      /* K5 */
+    DRT_K_BACKWARD = 4,  /* K6 */
+    DRT_K_GRADREDUCE = 5,/* K7 */
+    DRT_K_COUNT = 8
+};
+
+typedef struct drt_hip_stats {
+    uint64_t paths;                 /* camera samples traced by this call */
+    uint64_t segments;              /* ray segments = raycast calls, camera ray included,
+                                       zero-direction continuations excluded */
+    uint64_t batches;
+    double ms_total;                /* wall time of the call (host clock) */
+    double ms_kernel[DRT_K_COUNT];  /* summed HIP-event time per kernel (DRT_RENDER_TIMING) */
+    uint64_t launches[DRT_K_COUNT];
+    uint64_t units[DRT_K_COUNT];    /* segments (K2,K3,K6) or paths (K1,K5) processed */
+} drt_hip_stats;
+
+typedef struct drt_hip_ctx drt_hip_ctx;
+
+int drt_hip_abi_version(void);
+int drt_hip_device_count(void);
+int drt_hip_create(int device_id, drt_hip_ctx** out);
+void drt_hip_destroy(drt_hip_ctx* ctx);
+int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* scene);
+int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3 */);
+/* out_rgb: width*height*3 floats, row-major, mean over spp; only the rows of this shard are
+ *          written (others untouched). May be NULL.
+ * adjoint_rgb: width*height*3 floats, the seed every sample of that pixel is back-propagated
+ *          with; NULL = all ones (src/render.cpp:80 `radiance.backward(Vec3(1))`).
+ * out_param_grad: n_params*3 doubles, SUM over this shard's samples (the caller adds it to its
+ *          accumulator like vector.hpp:187 does; across shards: one sum all-reduce). */
+int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                   const float* adjoint_rgb, float* out_rgb, double* out_param_grad,
+                   drt_hip_stats* stats);
+/* stream the context launches on (a hipStream_t), for event timing / interop */
+void* drt_hip_stream(drt_hip_ctx* ctx);
+int drt_hip_synchronize(drt_hip_ctx* ctx);
+const char* drt_hip_last_error(drt_hip_ctx* ctx);
+const char* drt_hip_kernel_name(int k);
+
+/* ---- the per-path counter RNG (part of the contract: the oracle, the reference harness and
+ *      the device all draw from it) --------------------------------------------------------
+ * Replaces drt::random::uniform (include/drt/random.hpp:7-10): the n-th rand() call made while
+ * tracing camera sample `path` (= pixel*spp + sample, pixel = y*width + x) returns
+ * drt_rng_u31(seed, path, n) in [0, 2^31-1]; uniform = r / 2147483647.0 (RAND_MAX). */
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define DRT_HD __host__ __device__ static inline
+#else
+#define DRT_HD static inline
+#endif
+
+DRT_HD uint32_t drt_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+/* per-path part of the key (hoisted out of the per-draw hash) */
+DRT_HD uint32_t drt_rng_path_key(uint32_t seed, uint64_t path)
+{
+    uint32_t hi = (uint32_t)(path >> 32), lo = (uint32_t)path;
+    uint32_t h = drt_mix32(seed + 0x9E3779B9u * (hi + 1u));
+    return drt_mix32(h ^ lo);
+}
+
+DRT_HD uint32_t drt_rng_draw(uint32_t path_key, uint32_t n)
+{
+    return drt_mix32(path_key + 0x9E3779B9u * (n + 1u)) >> 1;
+}
+
+DRT_HD uint32_t drt_rng_u31(uint32_t seed, uint64_t path, uint32_t n)
+{
+    return drt_rng_draw(drt_rng_path_key(seed, path), n);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRT_HIP_H */

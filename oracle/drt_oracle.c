@@ -1,0 +1,400 @@
+/*
+ * drt_oracle.c -- TEST INFRASTRUCTURE ONLY (see drt_oracle.h).
+ *
+ * fp64 restatement of the reference hot path.  The reference builds a per-sample autodiff
+ * graph by recursion (pathtracer.hpp:121-136, vector.hpp:488-557) and walks it backwards
+ * (vector.hpp:418-484); this file unrolls the same arithmetic, IN THE SAME OPERATION ORDER,
+ * into a per-path vertex list with a reverse sweep for the radiance and a forward sweep for
+ * the adjoints, so results are bit-identical to the reference (same libm, no FP contraction).
+ * Every function cites the reference lines it follows (paths relative to /root/reference).
+ */
+#include "drt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { double v[3]; } v3;
+
+/* ---- Vector<T,3> algebra, vector.hpp:18-118, 327-370, 573-606 ---------------------------- */
+static v3 v3_make(double x, double y, double z) { v3 r = {{x, y, z}}; return r; }
+static v3 v3_add(v3 a, v3 b) { return v3_make(a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]); }
+static v3 v3_sub(v3 a, v3 b) { return v3_make(a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2]); }
+static v3 v3_mul(v3 a, v3 b) { return v3_make(a.v[0] * b.v[0], a.v[1] * b.v[1], a.v[2] * b.v[2]); }
+/* vector.hpp:95-100: x * s for either operand order */
+static v3 v3_scale(v3 a, double s) { return v3_make(a.v[0] * s, a.v[1] * s, a.v[2] * s); }
+/* vector.hpp:109-114 */
+static v3 v3_div(v3 a, double s) { return v3_make(a.v[0] / s, a.v[1] / s, a.v[2] / s); }
+/* vector.hpp:320-325: unary minus is -1 * v */
+static v3 v3_neg(v3 a) { return v3_scale(a, -1.0); }
+/* vector.hpp:573-578: accumulate(tmp, T()) = ((0 + x) + y) + z */
+static double v3_dot(v3 a, v3 b)
+{
+    v3 t = v3_mul(a, b);
+    double s = 0.0;
+    s = s + t.v[0];
+    s = s + t.v[1];
+    s = s + t.v[2];
+    return s;
+}
+/* vector.hpp:580-590 */
+static double v3_norm(v3 a) { return sqrt(v3_dot(a, a)); }
+static v3 v3_normalize(v3 a) { return v3_div(a, v3_norm(a)); }
+/* vector.hpp:592-600 */
+static v3 v3_cross(v3 a, v3 b)
+{
+    return v3_make(a.v[1] * b.v[2] - a.v[2] * b.v[1],
+                   a.v[2] * b.v[0] - a.v[0] * b.v[2],
+                   a.v[0] * b.v[1] - a.v[1] * b.v[0]);
+}
+/* vector.hpp:602-606: -v + 2*dot(n, v)*n */
+static v3 v3_reflect(v3 v, v3 n)
+{
+    return v3_add(v3_neg(v), v3_scale(n, 2 * v3_dot(n, v)));
+}
+
+static const double k_pi = 3.14159265358979323846; /* constants.hpp:9 */
+
+/* ---- RNG, random.hpp:7-10 ---------------------------------------------------------------- */
+typedef struct {
+    int mode;
+    uint32_t path_key;
+    uint32_t draw;
+} rng_t;
+
+static double rng_uniform(rng_t* r)
+{
+    if (r->mode == DRT_ORACLE_RNG_LIBC)
+        return (double)rand() / RAND_MAX;
+    return (double)drt_rng_draw(r->path_key, r->draw++) / 2147483647.0;
+}
+
+uint32_t drt_oracle_rng_u31(uint32_t seed, uint64_t path, uint32_t n)
+{
+    return drt_rng_u31(seed, path, n);
+}
+
+/* ---- shapes, shape.hpp:49-59 (Plane), 78-106 (Sphere) ------------------------------------ */
+static int shape_intersect(const drt_shape_desc* s, v3 orig, v3 dir, double* t)
+{
+    if (s->type == DRT_SHAPE_PLANE) {
+        v3 n = v3_make(s->p[0], s->p[1], s->p[2]);
+        double h = v3_dot(orig, n) - s->p[3];
+        *t = h / v3_dot(dir, v3_neg(n));
+        return *t > 0;
+    } else {
+        v3 c = v3_make(s->p[0], s->p[1], s->p[2]);
+        double radius = s->p[3];
+        orig = v3_sub(orig, c);
+        double a = 1;
+        double b = 2 * v3_dot(orig, dir);
+        double cc = v3_dot(orig, orig) - radius * radius;
+        double d = b * b - 4 * a * cc;
+        if (d < 0)
+            return 0;
+        double t1 = (-b - sqrt(d)) / (2 * a);
+        double t2 = (-b + sqrt(d)) / (2 * a);
+        if (t1 > 0 && t2 > 0) {
+            *t = t2 < t1 ? t2 : t1; /* std::min(t1, t2) */
+            return 1;
+        } else if (t1 > 0) {
+            *t = t1;
+            return 1;
+        } else if (t2 > 0) {
+            *t = t2;
+            return 1;
+        }
+        return 0;
+    }
+}
+
+static v3 shape_normal(const drt_shape_desc* s, v3 point)
+{
+    if (s->type == DRT_SHAPE_PLANE)
+        return v3_make(s->p[0], s->p[1], s->p[2]);
+    return v3_normalize(v3_sub(point, v3_make(s->p[0], s->p[1], s->p[2])));
+}
+
+/* ---- Pathtracer::raycast, pathtracer.hpp:72-89 ------------------------------------------- */
+static int raycast(const drt_scene_desc* sc, v3 orig, v3 dir, v3* point, v3* normal, double* t_out)
+{
+    double tmin = INFINITY;
+    int hit = -1;
+    for (int i = 0; i < sc->n_shapes; ++i) {
+        double t;
+        if (!shape_intersect(&sc->shapes[i], orig, dir, &t) || t >= tmin)
+            continue;
+        tmin = t;
+        *point = v3_add(orig, v3_scale(dir, t));
+        *normal = shape_normal(&sc->shapes[i], *point);
+        hit = i;
+    }
+    *t_out = tmin;
+    return isinf(tmin) ? -1 : hit;
+}
+
+/* ---- make_frame / angle_to_dir, bxdf.hpp:29-52 ------------------------------------------- */
+static void make_frame(v3 normal, v3 frame[3])
+{
+    v3 e1 = v3_make(1., 0., 0.);
+    v3 e2 = v3_make(0., 1., 0.);
+    v3 tangent;
+    if (fabs(v3_dot(e1, normal)) < fabs(v3_dot(e2, normal)))
+        tangent = v3_normalize(v3_sub(e1, v3_scale(normal, v3_dot(e1, normal))));
+    else
+        tangent = v3_normalize(v3_sub(e2, v3_scale(normal, v3_dot(e2, normal))));
+    v3 bitangent = v3_normalize(v3_cross(normal, tangent));
+    frame[0] = tangent;
+    frame[1] = bitangent;
+    frame[2] = normal;
+}
+
+static v3 angle_to_dir(double theta, double phi, const v3 frame[3])
+{
+    double x = cos(phi) * sin(theta);
+    double y = sin(phi) * sin(theta);
+    double z = cos(theta);
+    return v3_add(v3_add(v3_scale(frame[0], x), v3_scale(frame[1], y)), v3_scale(frame[2], z));
+}
+
+/* ---- BxDF::sample, bxdf.hpp:69-79 (Diffuse), 106-120 (Specular); null: pathtracer.hpp:17-27 */
+static v3 bxdf_sample(const drt_material_desc* m, v3 normal, v3 dir_in, rng_t* rng, double* pdf)
+{
+    if (!m) {
+        *pdf = 1;
+        return v3_make(0, 0, 0);
+    }
+    v3 frame[3];
+    if (m->type == DRT_BXDF_DIFFUSE) {
+        double theta = asin(sqrt(rng_uniform(rng)));
+        double phi = 2 * k_pi * rng_uniform(rng);
+        make_frame(normal, frame);
+        v3 dir = angle_to_dir(theta, phi, frame);
+        *pdf = cos(theta) / k_pi;
+        return dir;
+    } else {
+        double e = m->exponent;
+        double theta = acos(sqrt(pow(rng_uniform(rng), 2 / (e + 2))));
+        double phi = 2 * k_pi * rng_uniform(rng);
+        make_frame(normal, frame);
+        v3 halfway = angle_to_dir(theta, phi, frame);
+        if (v3_dot(halfway, dir_in) < 0)
+            halfway = v3_reflect(halfway, normal);
+        v3 dir = v3_reflect(dir_in, halfway);
+        *pdf = (e + 2) / (2 * k_pi) * pow(cos(theta), e + 1) * sin(theta);
+        return dir;
+    }
+}
+
+/* BxDF::operator(): value = scale_kind(color): Diffuse color / pi (bxdf.hpp:63-67), Specular
+ * factor * color (bxdf.hpp:91-104).  Returns the scalar; *is_div says how it is applied. */
+static double bxdf_scalar(const drt_material_desc* m, v3 normal, v3 dir_in, v3 dir_out, int* is_div)
+{
+    if (m->type == DRT_BXDF_DIFFUSE) {
+        *is_div = 1;
+        return k_pi;
+    }
+    v3 halfway = v3_normalize(v3_add(dir_in, dir_out));
+    double cos_theta = v3_dot(normal, halfway);
+    double sin_theta = sqrt(1 - cos_theta * cos_theta);
+    double factor = (m->exponent + 2) / (2 * k_pi) * pow(cos_theta, m->exponent) * sin_theta;
+    *is_div = 0;
+    return factor;
+}
+
+/* ---- per-path vertex list ------------------------------------------------------------------ */
+typedef struct {
+    double p;        /* roulette survival probability of this depth, pathtracer.hpp:130 */
+    double q;        /* pdf of the sampled direction */
+    double c;        /* cos_theta = dot(normal, dir_out), pathtracer.hpp:103 */
+    double bscalar;  /* pi (Diffuse, divide) or factor (Specular, multiply) */
+    int bdiv;
+    int color_param; /* -1 = no BxDF */
+    int emis_param;  /* -1 = no emitter */
+    v3 f;            /* BxDF value */
+    v3 lnext;        /* radiance returned by the recursive trace, filled by the reverse sweep */
+} vertex_t;
+
+#define ORACLE_MAX_VERTICES 4096
+
+/* Camera::sample, camera.hpp:51-60 */
+static v3 camera_sample(const drt_camera_desc* cam, int x, int y, rng_t* rng)
+{
+    double width = (double)cam->width, height = (double)cam->height;
+    double s = (x + rng_uniform(rng)) / width;
+    double t = (y + rng_uniform(rng)) / height;
+    double aspect = width / height;
+    v3 fwd = v3_make(cam->forward[0], cam->forward[1], cam->forward[2]);
+    v3 right = v3_make(cam->right[0], cam->right[1], cam->right[2]);
+    v3 up = v3_make(cam->up[0], cam->up[1], cam->up[2]);
+    v3 dir = fwd;
+    dir = v3_add(dir, v3_scale(right, (2. * s - 1.) * aspect * tan(cam->vfov / 2.)));
+    dir = v3_add(dir, v3_scale(v3_neg(up), (2. * t - 1.) * tan(cam->vfov / 2.)));
+    return v3_normalize(dir);
+}
+
+int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
+                      const drt_render_params* rp, int rng_mode, uint32_t oracle_flags,
+                      const float* adjoint_rgb, double* out_rgb, double* out_param_grad,
+                      drt_oracle_stats* stats,
+                      drt_oracle_vertex* vertices, uint64_t max_vertices, uint64_t* n_vertices,
+                      uint64_t dump_paths)
+{
+    if (!scene || !cam || !rp || cam->width <= 0 || cam->height <= 0 || rp->spp <= 0)
+        return DRT_ERR_INVALID;
+    for (int i = 0; i < scene->n_shapes; ++i) {
+        const drt_shape_desc* s = &scene->shapes[i];
+        if ((s->type != DRT_SHAPE_PLANE && s->type != DRT_SHAPE_SPHERE) ||
+            s->material >= scene->n_materials || s->emitter >= scene->n_emitters)
+            return DRT_ERR_INVALID;
+    }
+    const int W = cam->width, H = cam->height, spp = rp->spp;
+    const int faithful = (oracle_flags & DRT_ORACLE_FAITHFUL_CONTINUATION) != 0;
+    const int max_depth = rp->max_depth > 0 ? rp->max_depth : 0; /* 0 = unlimited (reference) */
+    const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;
+    const int band = rp->band_rows > 0 ? rp->band_rows : 1;
+    const int want_grad = out_param_grad != NULL;
+    vertex_t* vtx = (vertex_t*)malloc(sizeof(vertex_t) * ORACLE_MAX_VERTICES);
+    if (!vtx)
+        return DRT_ERR_OOM;
+    drt_oracle_stats st;
+    memset(&st, 0, sizeof st);
+    uint64_t nvlog = 0;
+    if (want_grad)
+        memset(out_param_grad, 0, sizeof(double) * 3 * (size_t)scene->n_params);
+    if (rng_mode == DRT_ORACLE_RNG_LIBC)
+        srand(rp->seed);
+    rng_t rng;
+    rng.mode = rng_mode;
+    v3 eye = v3_make(cam->eye[0], cam->eye[1], cam->eye[2]);
+    int status = DRT_OK;
+
+    for (int y = 0; y < H && status == DRT_OK; ++y) {
+        if (n_shards > 1 && (y / band) % n_shards != rp->shard)
+            continue;
+        for (int x = 0; x < W && status == DRT_OK; ++x) {
+            size_t pix = (size_t)y * W + x;
+            v3 pixel = v3_make(0, 0, 0);
+            for (int i = 0; i < spp; ++i) {
+                uint64_t path = (uint64_t)pix * spp + i;
+                rng.path_key = drt_rng_path_key(rp->seed, path);
+                rng.draw = 0;
+                int logging = vertices && path < dump_paths;
+                v3 dir = camera_sample(cam, x, y, &rng);
+                v3 orig = eye;
+                int depth = 0, nv = 0;
+                /* forward walk: Pathtracer::trace / scatter, pathtracer.hpp:91-136 */
+                for (;;) {
+                    if (max_depth && depth >= max_depth)
+                        break; /* extension, not in the reference */
+                    if (depth >= rp->min_bounces && rng_uniform(&rng) < rp->absorb)
+                        break;
+                    double p = depth >= rp->min_bounces ? (1 - rp->absorb) : 1;
+                    v3 point = v3_make(0, 0, 0), normal = v3_make(0, 0, 0);
+                    double t;
+                    int zero_dir = dir.v[0] == 0 && dir.v[1] == 0 && dir.v[2] == 0;
+                    int shape = raycast(scene, orig, dir, &point, &normal, &t);
+                    if (zero_dir) st.zero_dir_segments++; else st.segments++;
+                    if (logging && nvlog < max_vertices) {
+                        drt_oracle_vertex* L = &vertices[nvlog++];
+                        memset(L, 0, sizeof *L);
+                        L->path = (double)path;
+                        L->depth = depth;
+                        for (int c = 0; c < 3; ++c) { L->o[c] = orig.v[c]; L->d[c] = dir.v[c]; }
+                        L->shape = shape;
+                        if (shape >= 0) {
+                            L->t = t;
+                            for (int c = 0; c < 3; ++c) { L->p[c] = point.v[c]; L->n[c] = normal.v[c]; }
+                        }
+                    }
+                    if (shape < 0)
+                        break;
+                    if (nv >= ORACLE_MAX_VERTICES) {
+                        status = DRT_ERR_INVALID;
+                        break;
+                    }
+                    const drt_shape_desc* sh = &scene->shapes[shape];
+                    const drt_material_desc* m = sh->material >= 0 ? &scene->materials[sh->material] : NULL;
+                    vertex_t* v = &vtx[nv++];
+                    v->p = p;
+                    v->emis_param = sh->emitter >= 0 ? scene->emitters[sh->emitter].param : -1;
+                    v->color_param = m ? m->param : -1;
+                    v3 dir_in = v3_neg(dir);
+                    v3 dir_out = bxdf_sample(m, normal, dir_in, &rng, &v->q);
+                    if (m) {
+                        v->bscalar = bxdf_scalar(m, normal, dir_in, dir_out, &v->bdiv);
+                        v3 color = v3_make(scene->params[m->param * 3], scene->params[m->param * 3 + 1],
+                                           scene->params[m->param * 3 + 2]);
+                        v->f = v->bdiv ? v3_div(color, v->bscalar) : v3_scale(color, v->bscalar);
+                    } else {
+                        v->bscalar = 0;
+                        v->bdiv = 0;
+                        v->f = v3_make(0, 0, 0); /* pathtracer.hpp:38-39 */
+                    }
+                    v->c = v3_dot(normal, dir_out);
+                    if (!m && !faithful)
+                        break; /* the continuation contributes exactly 0 */
+                    orig = v3_add(point, v3_scale(dir_out, 1e-3)); /* pathtracer.hpp:99 */
+                    dir = dir_out;
+                    ++depth;
+                }
+                if ((uint64_t)nv > st.max_vertices)
+                    st.max_vertices = (uint64_t)nv;
+                /* reverse sweep: L_k = (E + (0 + ((f*L_{k+1})*c)/q)) / p
+                 * pathtracer.hpp:104 (vector.hpp:515,532), integrate.hpp:31,34
+                 * (vector.hpp:553,493), pathtracer.hpp:114,133 */
+                v3 lnext = v3_make(0, 0, 0);
+                for (int k = nv - 1; k >= 0; --k) {
+                    vertex_t* v = &vtx[k];
+                    v->lnext = lnext;
+                    v3 contrib = v3_div(v3_scale(v3_mul(v->f, lnext), v->c), v->q);
+                    v3 diffuse = v3_add(v3_make(0, 0, 0), contrib);
+                    v3 emission = v3_make(0, 0, 0);
+                    if (v->emis_param >= 0)
+                        emission = v3_make(scene->params[v->emis_param * 3],
+                                           scene->params[v->emis_param * 3 + 1],
+                                           scene->params[v->emis_param * 3 + 2]);
+                    lnext = v3_div(v3_add(emission, diffuse), v->p);
+                }
+                pixel = v3_add(pixel, v3_div(lnext, 1.0)); /* render.cpp:78, pdf = 1 */
+                /* backward: vector.hpp:420-484 walked from the root, render.cpp:80 */
+                if (want_grad) {
+                    v3 g = v3_make(1, 1, 1);
+                    if (adjoint_rgb)
+                        g = v3_make(adjoint_rgb[pix * 3], adjoint_rgb[pix * 3 + 1], adjoint_rgb[pix * 3 + 2]);
+                    for (int k = 0; k < nv; ++k) {
+                        vertex_t* v = &vtx[k];
+                        v3 g1 = v3_div(g, v->p);                       /* ScalarDivBackward :479 */
+                        if (v->emis_param >= 0 &&
+                            (!scene->requires_grad || scene->requires_grad[v->emis_param])) {
+                            double* acc = &out_param_grad[v->emis_param * 3];
+                            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + g1.v[c]; /* :187 */
+                        }
+                        v3 g2 = v3_div(g1, v->q);                      /* ScalarDivBackward */
+                        v3 g3 = v3_scale(g2, v->c);                    /* ScalarMulBackward :457 */
+                        if (v->color_param >= 0 &&
+                            (!scene->requires_grad || scene->requires_grad[v->color_param])) {
+                            v3 df = v3_mul(v->lnext, g3);              /* MulBackward :446 */
+                            v3 dc = v->bdiv ? v3_div(df, v->bscalar) : v3_scale(df, v->bscalar);
+                            double* acc = &out_param_grad[v->color_param * 3];
+                            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + dc.v[c];
+                        }
+                        g = v3_mul(v->f, g3);                          /* MulBackward :447 */
+                    }
+                }
+                st.paths++;
+            }
+            if (out_rgb) {
+                v3 mean = v3_div(pixel, (double)spp); /* render.cpp:82 */
+                for (int c = 0; c < 3; ++c)
+                    out_rgb[pix * 3 + c] = mean.v[c];
+            }
+        }
+    }
+    free(vtx);
+    if (stats)
+        *stats = st;
+    if (n_vertices)
+        *n_vertices = nvlog;
+    return status;
+}

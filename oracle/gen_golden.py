@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the UNMODIFIED reference (oracle/_ref/ref_harness).
+
+Run in the build container only (needs /root/reference):  python oracle/gen_golden.py [--big]
+Each fixture is an .npz of inputs (render settings, scene name or arrays) and the reference's
+outputs (image, parameter gradients, raycast counters, optional per-raycast vertex dumps).
+--big also regenerates the full-size config-1 / config-3 fixtures (about 3 minutes of CPU).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle as O  # noqa: E402
+
+pkg = O.load_pkg()
+GOLDEN = os.path.join(O.REPO_ROOT, "tests", "golden")
+
+
+scene_by_name = pkg.scene_by_name
+
+
+def block_mean(img, b):
+    h, w, _ = img.shape
+    return img.reshape(h // b, b, w // b, b, 3).mean((1, 3))
+
+
+def run(case):
+    scene = scene_by_name(case["scene"])
+    if "requires_grad" in case:
+        scene.requires_grad = list(case["requires_grad"])
+    cam = pkg.Camera(case["width"], case["height"], case.get("vfov", 1.3963))
+    cam.look_at(case.get("eye", (0, 0, 0)), case.get("at", (0, 0, 1)))
+    rp = pkg.RenderParams(spp=case["spp"], min_bounces=case["min_bounces"], absorb=case["absorb"],
+                          seed=case["seed"])
+    adjoint = None
+    if case.get("adjoint_seed") is not None:
+        adjoint = np.random.RandomState(case["adjoint_seed"]).uniform(
+            -1, 2, (case["height"], case["width"], 3)).astype(np.float32)
+    r = O.render_reference(scene, cam, rp, backward=True, adjoint=adjoint,
+                           rng_mode=case.get("rng_mode", O.RNG_KEYED),
+                           dump_paths=case.get("dump_paths", 0))
+    out = {"case": json.dumps(case), "grads": r["grads"],
+           "segments": np.int64(r["stats"]["segments"]),
+           "zero_dir_segments": np.int64(r["stats"]["zero_dir_segments"]),
+           "mean_rgb": r["image"].mean((0, 1)),
+           "ref_seconds": np.float64(r["stats"]["seconds"])}
+    store = case.get("store", "f64")
+    if store == "f64":
+        out["image"] = r["image"]
+    elif store == "f32":
+        out["image"] = r["image"].astype(np.float32)
+    elif store.startswith("block"):
+        out["image_block_mean"] = block_mean(r["image"], int(store[5:]))
+        out["row_mean"] = r["image"].mean(1)
+    if r["vertices"] is not None:
+        out["vertices"] = r["vertices"]
+    path = os.path.join(GOLDEN, case["name"] + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{case['name']}: {r['stats']} mean={out['mean_rgb']} -> {os.path.getsize(path)} B")
+
+
+SMALL = [
+    dict(name="g2_cornell_32x32x4_d4", scene="cornell", width=32, height=32, spp=4, min_bounces=4,
+         absorb=1.0, seed=1, dump_paths=256),
+    dict(name="g3_cornell_64x64x8_d8", scene="cornell", width=64, height=64, spp=8, min_bounces=8,
+         absorb=1.0, seed=1),
+    dict(name="g3b_cornell_64x64x8_rr", scene="cornell", width=64, height=64, spp=8, min_bounces=1,
+         absorb=0.5, seed=7, dump_paths=128),
+    dict(name="g4_specular_64x64x8_d8", scene="cornell_specular", width=64, height=64, spp=8,
+         min_bounces=8, absorb=1.0, seed=3),
+    dict(name="g4b_emissive_wall_48x32x8_adj", scene="cornell_emissive_wall", width=48, height=32,
+         spp=8, min_bounces=3, absorb=0.3, seed=11, adjoint_seed=5,
+         requires_grad=[True, True, False, True, True]),
+    dict(name="g6_libc_64x64x8_d4", scene="cornell", width=64, height=64, spp=8, min_bounces=4,
+         absorb=1.0, seed=1, rng_mode=O.RNG_LIBC),
+    dict(name="g7_random3_40x30x6", scene="random3", width=40, height=30, spp=6, min_bounces=2,
+         absorb=0.25, seed=21, adjoint_seed=9, eye=(0.2, -0.3, 0.0), at=(0.0, 0.1, 1.0),
+         dump_paths=128),
+    dict(name="g8_random8_36x36x6_d5", scene="random8", width=36, height=36, spp=6, min_bounces=5,
+         absorb=1.0, seed=2),
+]
+BIG = [
+    dict(name="c1_cornell_256x256x8_d4", scene="cornell", width=256, height=256, spp=8,
+         min_bounces=4, absorb=1.0, seed=1, store="f32"),
+    dict(name="c3_cornell_512x512x64_d8", scene="cornell", width=512, height=512, spp=64,
+         min_bounces=8, absorb=1.0, seed=1, store="block8"),
+]
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    O.build()
+    os.makedirs(GOLDEN, exist_ok=True)
+    for case in SMALL + (BIG if a.big else []):
+        if a.only and a.only not in case["name"]:
+            continue
+        run(case)

@@ -1,0 +1,310 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE, compiled only in the build container.
+//
+// Drives the UNMODIFIED reference headers (found with -I/root/reference/include; nothing of the
+// reference is copied here) on a scene given as the same POD description the C ABI takes
+// (include/drt_hip.h), and interposes libc rand() so that the reference's
+// drt::random::uniform (random.hpp:7-10) consumes the per-path counter RNG drt_rng_u31.
+// Output: raw little-endian f64 arrays + a JSON side file, turned into tests/golden/* by
+// oracle/gen_golden.py.  The binary lives in oracle/_ref/ (git-ignored) and is used
+//   * to generate the committed golden vectors, and
+//   * as an extra cross-check of the C restatement (oracle/drt_oracle.c) in tests that run
+//     where /root/reference exists.
+//
+// The loop below restates what src/render.cpp:72-86 does (sample -> trace -> detach / backward).
+//
+// Scene file format (text, whitespace separated):
+//   params P            then P lines:  r g b requires_grad
+//   materials M         then M lines:  type param exponent
+//   emitters E          then E lines:  param
+//   shapes S            then S lines:  type material emitter p0 p1 p2 p3
+//   camera W H vfov ex ey ez fx fy fz rx ry rz ux uy uz
+//   render spp min_bounces absorb seed rng_mode(0 keyed,1 libc) backward dump_paths
+//   adjoint <file|none>   (raw f32 W*H*3)
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "drt/bxdf.hpp"
+#include "drt/camera.hpp"
+#include "drt/emitter.hpp"
+#include "drt/integrate.hpp"   // must precede pathtracer.hpp
+#include "drt/pathtracer.hpp"
+#include "drt/shape.hpp"
+#include "drt/vector.hpp"
+
+#include "../include/drt_hip.h"
+
+using T = double;
+using V3 = drt::Vector<T, 3>;
+using P3 = drt::Vector<T, 3, true>;
+
+// ---- rand() interposition ---------------------------------------------------------------
+static int g_rng_mode = 0;       // 0 keyed, 1 libc stream (glibc rand() == random())
+static uint32_t g_seed = 1;
+static uint32_t g_path_key = 0;
+static uint32_t g_draw = 0;
+
+extern "C" int rand(void)
+{
+    if (g_rng_mode == 1)
+        return (int)random();
+    return (int)drt_rng_draw(g_path_key, g_draw++);
+}
+
+// ---- instrumentation shapes (harness code, not reference code) --------------------------
+struct VertexLog {
+    double path, depth, o[3], d[3], shape, t, p[3], n[3];
+};
+static bool g_logging = false;
+static std::vector<VertexLog> g_log;
+static VertexLog g_cur;
+static bool g_cur_open = false;
+static uint64_t g_raycasts = 0, g_zero_raycasts = 0;
+static double g_cur_path = 0;
+static int g_cur_depth = 0;
+
+static void close_vertex()
+{
+    if (g_cur_open) {
+        g_log.push_back(g_cur);
+        g_cur_open = false;
+    }
+}
+
+// First entry of the scene: never hits, counts raycast() calls (pathtracer.hpp:72-89 calls
+// intersect on every shape, in order, once per raycast).
+class CountingShape : public drt::Shape<T> {
+public:
+    bool intersect(V3 orig, V3 dir, double& t) const override
+    {
+        ++g_raycasts;
+        bool zero = dir[0] == 0 && dir[1] == 0 && dir[2] == 0;
+        if (zero)
+            ++g_zero_raycasts;
+        if (g_logging) {
+            close_vertex();
+            g_cur = VertexLog{};
+            g_cur.path = g_cur_path;
+            g_cur.depth = g_cur_depth++;
+            for (int i = 0; i < 3; ++i) { g_cur.o[i] = orig[i]; g_cur.d[i] = dir[i]; }
+            g_cur.shape = -1;
+            g_cur.t = 0;
+            g_cur_open = true;
+        }
+        t = 0;
+        return false;
+    }
+    V3 normal(V3) const override { return V3(0.); }
+};
+
+// Forwards to a reference shape and records which one produced the accepted hit
+// (raycast calls normal() exactly when a shape becomes the closest so far,
+// pathtracer.hpp:82-86).
+class Probe : public drt::Shape<T> {
+public:
+    Probe(std::unique_ptr<drt::Shape<T>> inner, int index,
+          std::shared_ptr<drt::BxDF<T>> bxdf, std::shared_ptr<drt::Emitter<T>> emitter)
+      : drt::Shape<T>(bxdf, emitter), m_inner(std::move(inner)), m_index(index) { }
+    bool intersect(V3 orig, V3 dir, double& t) const override
+    {
+        bool hit = m_inner->intersect(orig, dir, t);
+        m_last_t = t;
+        return hit;
+    }
+    V3 normal(V3 point) const override
+    {
+        V3 n = m_inner->normal(point);
+        if (g_logging && g_cur_open) {
+            g_cur.shape = m_index;
+            g_cur.t = m_last_t;
+            for (int i = 0; i < 3; ++i) { g_cur.p[i] = point[i]; g_cur.n[i] = n[i]; }
+        }
+        return n;
+    }
+private:
+    std::unique_ptr<drt::Shape<T>> m_inner;
+    int m_index;
+    mutable double m_last_t = 0;
+};
+
+static void die(const char* msg)
+{
+    fprintf(stderr, "ref_harness: %s\n", msg);
+    exit(2);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3)
+        die("usage: ref_harness <scene.txt> <out_prefix>");
+    std::ifstream in(argv[1]);
+    if (!in)
+        die("cannot open scene file");
+    std::string out_prefix = argv[2];
+
+    std::string tok;
+    std::vector<P3> params;
+    std::vector<int> param_rg;
+    std::vector<std::shared_ptr<drt::BxDF<T>>> materials;
+    std::vector<std::shared_ptr<drt::Emitter<T>>> emitters;
+    std::vector<std::unique_ptr<drt::Shape<T>>> shapes;
+    int W = 0, H = 0, spp = 1, min_bounces = 1, backward = 0, dump_paths = 0;
+    double vfov = 1.3963, absorb = 0.5;
+    V3 eye(0.), fwd(0.), right(0.), up(0.);
+    std::string adjoint_file = "none";
+
+    while (in >> tok) {
+        if (tok == "params") {
+            int n; in >> n;
+            for (int i = 0; i < n; ++i) {
+                double r, g, b; int rg;
+                in >> r >> g >> b >> rg;
+                params.emplace_back(V3{r, g, b}, rg != 0);
+                param_rg.push_back(rg);
+            }
+        } else if (tok == "materials") {
+            int n; in >> n;
+            for (int i = 0; i < n; ++i) {
+                int type, param; double e;
+                in >> type >> param >> e;
+                if (type == DRT_BXDF_DIFFUSE)
+                    materials.push_back(std::make_shared<drt::DiffuseBxDF<T>>(params.at(param)));
+                else if (type == DRT_BXDF_SPECULAR)
+                    materials.push_back(std::make_shared<drt::SpecularBxDF<T>>(params.at(param), e));
+                else
+                    die("unsupported material type");
+            }
+        } else if (tok == "emitters") {
+            int n; in >> n;
+            for (int i = 0; i < n; ++i) {
+                int param; in >> param;
+                emitters.push_back(std::make_shared<drt::AreaEmitter<T>>(params.at(param)));
+            }
+        } else if (tok == "shapes") {
+            int n; in >> n;
+            for (int i = 0; i < n; ++i) {
+                int type, mat, emi; double p0, p1, p2, p3;
+                in >> type >> mat >> emi >> p0 >> p1 >> p2 >> p3;
+                std::shared_ptr<drt::BxDF<T>> bx = mat >= 0 ? materials.at(mat) : nullptr;
+                std::shared_ptr<drt::Emitter<T>> em = emi >= 0 ? emitters.at(emi) : nullptr;
+                std::unique_ptr<drt::Shape<T>> inner;
+                if (type == DRT_SHAPE_PLANE)
+                    inner.reset(new drt::Plane<T>(V3{p0, p1, p2}, p3, bx, em));
+                else if (type == DRT_SHAPE_SPHERE)
+                    inner.reset(new drt::Sphere<T>(V3{p0, p1, p2}, p3, bx, em));
+                else
+                    die("unsupported shape type");
+                shapes.emplace_back(new Probe(std::move(inner), i, bx, em));
+            }
+        } else if (tok == "camera") {
+            in >> W >> H >> vfov;
+            for (int i = 0; i < 3; ++i) in >> eye[i];
+            for (int i = 0; i < 3; ++i) in >> fwd[i];
+            for (int i = 0; i < 3; ++i) in >> right[i];
+            for (int i = 0; i < 3; ++i) in >> up[i];
+        } else if (tok == "render") {
+            in >> spp >> min_bounces >> absorb >> g_seed >> g_rng_mode >> backward >> dump_paths;
+        } else if (tok == "adjoint") {
+            in >> adjoint_file;
+        } else {
+            die("unknown token in scene file");
+        }
+    }
+    if (W <= 0 || H <= 0)
+        die("no camera");
+
+    std::vector<float> adjoint;
+    if (adjoint_file != "none") {
+        adjoint.resize((size_t)W * H * 3);
+        FILE* f = fopen(adjoint_file.c_str(), "rb");
+        if (!f || fread(adjoint.data(), sizeof(float), adjoint.size(), f) != adjoint.size())
+            die("cannot read adjoint file");
+        fclose(f);
+    }
+
+    CountingShape counter;
+    drt::Scene<T> scene;
+    scene.push_back(&counter);
+    for (auto& s : shapes)
+        scene.push_back(s.get());
+
+    // VariableNode::m_grad is default-initialised (vector.hpp:191), i.e. indeterminate: zero it.
+    for (size_t i = 0; i < params.size(); ++i)
+        if (param_rg[i])
+            params[i].grad() = V3(0.);
+
+    drt::Camera<T> cam(W, H, vfov, eye, fwd, right, up);
+    drt::Pathtracer<T> tracer(absorb, (size_t)min_bounces);
+    std::vector<double> img((size_t)W * H * 3, 0.0);
+
+    auto t0 = std::chrono::steady_clock::now();
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            V3 pixel(0.);
+            size_t pix = (size_t)y * W + x;
+            for (int i = 0; i < spp; ++i) {
+                uint64_t path = (uint64_t)pix * spp + i;
+                g_path_key = drt_rng_path_key(g_seed, path);
+                g_draw = 0;
+                g_logging = (int64_t)path < (int64_t)dump_paths;
+                g_cur_path = (double)path;
+                g_cur_depth = 0;
+                auto [dir, pdf] = cam.sample(x, y);
+                P3 radiance = tracer.trace(scene, cam.eye(), dir);
+                pixel += radiance.detach() / pdf;
+                if (backward) {
+                    V3 g(1.);
+                    if (!adjoint.empty())
+                        g = V3{adjoint[pix*3], adjoint[pix*3+1], adjoint[pix*3+2]};
+                    radiance.backward(g);
+                }
+                if (g_logging)
+                    close_vertex();
+                g_logging = false;
+            }
+            pixel = pixel / (double)spp;
+            for (int c = 0; c < 3; ++c)
+                img[pix*3 + c] = pixel[c];
+        }
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    std::vector<double> grads(params.size() * 3, 0.0);
+    for (size_t i = 0; i < params.size(); ++i)
+        if (param_rg[i])
+            for (int c = 0; c < 3; ++c)
+                grads[i*3 + c] = params[i].grad()[c];
+
+    auto dump = [&](const std::string& suffix, const void* p, size_t bytes) {
+        FILE* f = fopen((out_prefix + suffix).c_str(), "wb");
+        if (!f || fwrite(p, 1, bytes, f) != bytes)
+            die("cannot write output");
+        fclose(f);
+    };
+    dump(".img.f64", img.data(), img.size() * sizeof(double));
+    dump(".grad.f64", grads.data(), grads.size() * sizeof(double));
+    if (dump_paths > 0)
+        dump(".vtx.f64", g_log.data(), g_log.size() * sizeof(VertexLog));
+
+    FILE* f = fopen((out_prefix + ".json").c_str(), "w");
+    if (!f)
+        die("cannot write json");
+    fprintf(f, "{\"width\": %d, \"height\": %d, \"spp\": %d, \"min_bounces\": %d, \"absorb\": %.17g, "
+               "\"seed\": %u, \"rng_mode\": %d, \"backward\": %d, \"n_params\": %zu, "
+               "\"raycasts\": %llu, \"zero_dir_raycasts\": %llu, \"vertex_records\": %zu, "
+               "\"vertex_record_doubles\": %zu, \"seconds\": %.6f}\n",
+            W, H, spp, min_bounces, absorb, g_seed, g_rng_mode, backward, params.size(),
+            (unsigned long long)g_raycasts, (unsigned long long)g_zero_raycasts, g_log.size(),
+            sizeof(VertexLog) / sizeof(double), secs);
+    fclose(f);
+    fprintf(stderr, "ref_harness: %llu raycasts (%llu zero-dir) in %.3f s = %.3f Mray/s\n",
+            (unsigned long long)g_raycasts, (unsigned long long)g_zero_raycasts, secs,
+            g_raycasts / secs * 1e-6);
+    return 0;
+}

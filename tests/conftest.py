@@ -1,0 +1,64 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    o = entry.load_oracle()
+    o.lib()
+    return o
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    d["case"] = json.loads(str(d["case"]))
+    return d
+
+
+def case_inputs(pkg, case):
+    """Rebuild (scene, camera, render params, adjoint) from the inputs a golden fixture records."""
+    scene = pkg.scene_by_name(case["scene"])
+    if "requires_grad" in case:
+        scene.requires_grad = list(case["requires_grad"])
+    cam = pkg.Camera(case["width"], case["height"], case.get("vfov", 1.3963))
+    cam.look_at(case.get("eye", (0, 0, 0)), case.get("at", (0, 0, 1)))
+    rp = pkg.RenderParams(spp=case["spp"], min_bounces=case["min_bounces"], absorb=case["absorb"],
+                          seed=case["seed"])
+    adjoint = None
+    if case.get("adjoint_seed") is not None:
+        adjoint = np.random.RandomState(case["adjoint_seed"]).uniform(
+            -1, 2, (case["height"], case["width"], 3)).astype(np.float32)
+    return scene, cam, rp, adjoint
+
+
+SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_64x64x8_rr",
+                 "g4_specular_64x64x8_d8", "g4b_emissive_wall_48x32x8_adj", "g7_random3_40x30x6",
+                 "g8_random8_36x36x6_d5"]
+
+
+@pytest.fixture(scope="session")
+def hip(pkg):
+    """One context on device 0 for the gpu tests. No fallback: raises without the HIP library."""
+    r = pkg.HipRenderer(0)
+    yield r
+    r.close()
