@@ -139,20 +139,3 @@ __device__ inline void make_frame(V3<R> n, V3<R>& t, V3<R>& b)
         t = normalize(mk<R>(-n.x * n.y, R(1) - n.y * n.y, -n.z * n.y));
     b = normalize(cross(n, t));
 }
-
-// ---- wave64 queue append: ballot + mbcnt prefix, one atomic per wave (K4 fused into K1/K3) ---
-// Every lane of the wave must call this (convergent).
-__device__ inline uint32_t wave_append(uint32_t* counter, bool alive)
-{
-    const uint64_t mask = __ballot(alive);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    uint32_t base = 0;
-    if (mask != 0) {
-        const int leader = __ffsll((unsigned long long)mask) - 1;
-        if ((int)(threadIdx.x & (DRT_WAVE - 1)) == leader)
-            base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-    }
-    return base + rank;
-}

@@ -41,11 +41,11 @@ struct drt_hip_ctx {
     float* d_params_f = nullptr;
     double* d_params_d = nullptr;
 
-    DevBuf ray_a[2], ray_b[2], hit, lacc, rec, ids, nv, counts, film, gpart, grad, adjoint, out;
+    DevBuf ray_a[2], ray_b[2], hit, lacc, rec, ids, nv, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
-    std::vector<uint32_t> h_counts;
+    unsigned long long h_segments = 0;
 };
 
 namespace {
@@ -196,6 +196,17 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if (Sb < 1) Sb = 1;
     const size_t N = (size_t)Pb * Sb;   // batch capacity in paths
     const int D = depth_cap;
+    // queue regions: one wave each; enough of them to fill 256 CUs several times over
+    uint32_t region_size = 1024;
+    if (const char* e = getenv("DRT_HIP_REGION_SIZE")) {
+        long v = atol(e);
+        if (v >= 64)
+            region_size = (uint32_t)v;
+    }
+    while (region_size > 64 && N / region_size < (size_t)ctx->n_cu * 32)
+        region_size /= 2;
+    region_size = (region_size + DRT_WAVE - 1) / DRT_WAVE * DRT_WAVE;
+    const uint32_t max_regions = (uint32_t)((N + region_size - 1) / region_size);
 
     int rc;
     for (int i = 0; i < 2; ++i) {
@@ -212,10 +223,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const uint64_t n_pix_batches = (n_local_pixels + Pb - 1) / Pb;
     const uint64_t n_s_batches = ((uint64_t)spp + Sb - 1) / Sb;
     const uint64_t n_batches = n_pix_batches * n_s_batches;
-    const size_t cw = (size_t)(D + 2);
-    *n_count_words = (size_t)n_batches * cw;
-    if ((rc = ensure(ctx, ctx->counts, *n_count_words * sizeof(uint32_t))) != DRT_OK) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->counts.p, 0, *n_count_words * sizeof(uint32_t), ctx->stream));
+    const size_t cw = (size_t)(D + 1) * max_regions;   // counts[depth][region] of one batch
+    (void)n_batches;
+    *n_count_words = cw;
+    if ((rc = ensure(ctx, ctx->counts, cw * sizeof(uint32_t))) != DRT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->segtotal, sizeof(unsigned long long))) != DRT_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, sizeof(unsigned long long), ctx->stream));
     const int bwd_grid = grid_for(ctx, N);
     if (backward)
         if ((rc = ensure(ctx, ctx->gpart, (size_t)bwd_grid * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
@@ -233,6 +246,15 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     for (int i = 0; i < 3; ++i) {
         a.eye[i] = cam->eye[i]; a.fwd[i] = cam->forward[i];
         a.right[i] = cam->right[i]; a.up[i] = cam->up[i];
+    }
+    a.region_size = region_size;
+    {   // smallest r with !(double(r) / RAND_MAX < absorb): the roulette test as an integer compare
+        double guess = floor(rp->absorb * DRT_RAND_MAX_D);
+        int64_t r = (int64_t)guess - 2;
+        if (r < 0) r = 0;
+        while (r <= 2147483647LL && (double)r / DRT_RAND_MAX_D < rp->absorb)
+            ++r;
+        a.rr_threshold = (uint32_t)r;
     }
     a.tan_half = tan(cam->vfov / 2.);
     a.aspect = (double)cam->width / (double)cam->height;
@@ -255,8 +277,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             a.Pb = (n_local_pixels - p0) < Pb ? (n_local_pixels - p0) : Pb;
             a.Sb = ((uint32_t)spp - s0) < Sb ? ((uint32_t)spp - s0) : Sb;
             a.n_paths = a.Pb * a.Sb;
-            uint32_t* counts = (uint32_t*)ctx->counts.p + batch * cw;
-            const int g = grid_for(ctx, a.n_paths);
+            a.n_regions = (a.n_paths + region_size - 1) / region_size;
+            uint32_t* counts = (uint32_t*)ctx->counts.p;   // reused by every batch (stream order)
+            HIPCHK(ctx, hipMemsetAsync(counts, 0, cw * sizeof(uint32_t), ctx->stream));
+            const int g = (int)((a.n_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
+            const int gp = grid_for(ctx, a.n_paths);   // per-path kernels (K6): persistent grid
 
             if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
             hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
@@ -268,8 +293,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             for (int k = 0; k < D; ++k) {
                 const int cur = k & 1, nxt = cur ^ 1;
                 if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_intersect<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, d_scene,
-                                   ra[cur], rb[cur], hit, counts + k);
+                hipLaunchKernelGGL(k_intersect<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                   ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
 
@@ -280,15 +305,19 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if (backward)
                     hipLaunchKernelGGL((k_shade<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
                                        d_scene, d_params, ra[cur], rb[cur], hit, ra[nxt], rb[nxt], rec_in,
-                                       rec_out, ids_k, nv, lacc, counts);
+                                       rec_out, ids_k, nv, lacc, counts + (size_t)k * max_regions,
+                                       counts + (size_t)(k + 1) * max_regions);
                 else
                     hipLaunchKernelGGL((k_shade<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
                                        d_scene, d_params, ra[cur], rb[cur], hit, ra[nxt], rb[nxt], rec_in,
-                                       rec_out, ids_k, nv, lacc, counts);
+                                       rec_out, ids_k, nv, lacc, counts + (size_t)k * max_regions,
+                                       counts + (size_t)(k + 1) * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_SHADE]++;
             }
 
+            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, counts,
+                               (uint32_t)((size_t)D * max_regions), (unsigned long long*)ctx->segtotal.p);
             if (film) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;
                 hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
@@ -299,16 +328,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             }
             if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_backward<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                hipLaunchKernelGGL(k_backward<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                    d_params, rec, ids, nv, d_adjoint, gpart, grad);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_BACKWARD]++;
                 if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, g, n_fast,
+                hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast,
                                    grad);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_GRADREDUCE]++;
-                st->units[DRT_K_GRADREDUCE] += (uint64_t)g;
+                st->units[DRT_K_GRADREDUCE] += (uint64_t)gp;
             }
         }
     }
@@ -369,7 +398,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->hit, &ctx->lacc,
-                      &ctx->rec, &ctx->ids, &ctx->nv, &ctx->counts, &ctx->film, &ctx->gpart, &ctx->grad,
+                      &ctx->rec, &ctx->ids, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
     for (DevBuf* b : bufs)
         release(*b);
@@ -572,10 +601,9 @@ int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_rende
         if (backward)
             HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_params * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (stats && n_count_words) {
-        ctx->h_counts.resize(n_count_words);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts.data(), ctx->counts.p, n_count_words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    ctx->h_segments = 0;
+    if (stats && n_count_words)
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->h_segments, ctx->segtotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     if (sync)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (!dev_out && backward)
@@ -584,10 +612,7 @@ int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_rende
                 out_param_grad[p * 3] = out_param_grad[p * 3 + 1] = out_param_grad[p * 3 + 2] = 0.0;
 
     if (stats) {
-        const size_t cw = (size_t)depth_cap + 2;
-        for (size_t b = 0; b * cw < n_count_words; ++b)
-            for (int k = 0; k < depth_cap; ++k)
-                st.segments += ctx->h_counts[b * cw + (size_t)k];
+        st.segments = ctx->h_segments;
         st.units[DRT_K_INTERSECT] = st.segments;
         st.units[DRT_K_SHADE] = st.segments;
         st.units[DRT_K_BACKWARD] = backward ? st.segments : 0;

@@ -4,7 +4,7 @@
 //   K2 intersect   Pathtracer::raycast (pathtracer.hpp:72-89) over Plane/Sphere records
 //   K3 shade       Pathtracer::scatter (pathtracer.hpp:91-115): emission, BxDF sample + eval,
 //                  throughput update, next-depth roulette, tape write, and the queue append
-//                  (K4: wave ballot + prefix, one atomic per wave)
+//                  (K4: wave ballot + prefix into the wave's own queue region, no atomics)
 //   K5 film        the per-pixel mean of render.cpp:76-82
 //   K6 backward    reverse sweep of the per-bounce tape = the backward functors of
 //                  vector.hpp:418-484 in closed form
@@ -18,9 +18,18 @@
 //   ids[D][N]    colour param | emission param << 16      (backward only)
 //   nv[N]        vertices of the path                      (backward only)
 //   lacc[N]      (L.rgb, -) radiance accumulated along the path, by path index
-//   counts[D+1]  queue lengths per depth (device-resident: no host round trip per bounce)
+//   counts[D+1][n_regions]  queue lengths per depth and region (device-resident: no host round
+//                trip per bounce)
 // Path index i of a batch = (s - s0) * Pb + (pixel - p0): sample-major, so neighbouring lanes
 // are neighbouring pixels (coherent rays, coalesced film reads).
+//
+// Queue regions (K4): the queue of every depth is cut into n_regions regions of region_size
+// slots; wave w of the grid owns region w at EVERY depth.  It reads its live rays from the
+// front of its region and appends the survivors to the front of the same region of the other
+// ping-pong buffer: slot = region base + running count (SGPR) + prefix rank of the lane in the
+// wave ballot (v_mbcnt).  No atomics (a single queue-tail word saturates at ~88 returning
+// atomics/us on MI355X, which capped the first version of K1/K3 at ~3 ms per launch), the order
+// of paths is preserved, and the result is bitwise reproducible.
 #pragma once
 
 #include "drt_device.h"
@@ -30,6 +39,8 @@ struct BatchArgs {
     uint32_t n_paths;        // Pb * Sb
     uint32_t Pb, p0;         // pixels in the batch, first shard-local pixel
     uint32_t Sb, s0;         // samples in the batch, first sample
+    uint32_t n_regions, region_size;   // queue regions, one wave each (region_size % 64 == 0)
+    uint32_t rr_threshold;   // r31 < rr_threshold  <=>  double(r31) / RAND_MAX < absorb (exact)
     // image / sharding
     int32_t W, H, spp;
     int32_t shard, n_shards, band;
@@ -54,6 +65,26 @@ __device__ inline uint32_t global_pixel(const BatchArgs& a, uint32_t lp)
     return y * (uint32_t)a.W + x;
 }
 
+// wave index in the grid, as a scalar
+__device__ inline uint32_t grid_wave()
+{
+    return __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / DRT_WAVE);
+}
+
+// wave-local compaction step: rank of this lane among the alive lanes, and their number
+__device__ inline uint32_t wave_rank(bool alive, uint32_t& n_alive)
+{
+    const uint64_t mask = __ballot(alive);
+    n_alive = (uint32_t)__popcll(mask);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// uniform in [0,1] from a 31-bit draw, R = float: no fp64 (u and 1-u both from exact integers)
+__device__ inline float u01(float, uint32_t r) { return (float)r * (float)(1.0 / DRT_RAND_MAX_D); }
+__device__ inline double u01(double, uint32_t r) { return (double)r / DRT_RAND_MAX_D; }
+__device__ inline float one_minus_u01(float, uint32_t r) { return (float)(2147483647u - r) * (float)(1.0 / DRT_RAND_MAX_D); }
+__device__ inline double one_minus_u01(double, uint32_t r) { return 1.0 - (double)r / DRT_RAND_MAX_D; }
+
 // index of the first BxDF draw at depth k: 2 camera draws, 2 per earlier vertex, one roulette
 // draw per depth >= min_bounces up to and including k (draw order: SURVEY 3.1)
 __device__ inline uint32_t draw_index(int k, int min_bounces)
@@ -63,19 +94,26 @@ __device__ inline uint32_t draw_index(int k, int min_bounces)
 }
 
 // ---- K1 ---------------------------------------------------------------------------------------
+// One wave per queue region: generates the camera rays of its region's paths and compacts the
+// ones that survive the depth-0 roulette to the front of the region.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* __restrict__ ray_b,
          typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
 {
     typedef typename Q4<R>::T R4;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < a.n_paths; base += stride) {
-        const uint32_t i = base + threadIdx.x;
-        const bool valid = i < a.n_paths;
-        bool alive = valid;
+    const uint32_t w = grid_wave();
+    if (w >= a.n_regions)
+        return;
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t begin = w * a.region_size;
+    const uint32_t end = min(begin + a.region_size, a.n_paths);
+    uint32_t running = 0;
+    for (uint32_t off = begin; off < end; off += DRT_WAVE) {
+        const uint32_t i = off + lane;
+        bool alive = i < end;
         R4 ra, rb;
-        if (valid) {
+        if (alive) {
             const uint32_t sl = i / a.Pb, pl = i - sl * a.Pb;
             const uint32_t gpix = global_pixel(a, a.p0 + pl);
             const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
@@ -96,22 +134,25 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
             // pathtracer.hpp:128 at depth 0
             if (a.depth_cap <= 0)
                 alive = false;
-            else if (a.min_bounces <= 0 &&
-                     (double)drt_rng_draw(key, 2) / DRT_RAND_MAX_D < a.absorb)
+            else if (a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold)
                 alive = false;
             ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dx;
-            rb.x = (R)dy; rb.y = (R)dz; rb.z = pid_pack(R(0), i); rb.w = R(0);
+            rb.x = (R)dy; rb.y = (R)dz; rb.z = pid_pack(R(0), i); rb.w = pid_pack(R(0), key);
             R4 zero; zero.x = zero.y = zero.z = zero.w = R(0);
             lacc[i] = zero;
             if (nv && !alive)
                 nv[i] = 0;
         }
-        const uint32_t slot = wave_append(&counts[0], alive);
+        uint32_t n_alive;
+        const uint32_t slot = begin + running + wave_rank(alive, n_alive);
         if (alive) {
             ray_a[slot] = ra;
             ray_b[slot] = rb;
         }
+        running += n_alive;
     }
+    if (lane == 0)
+        counts[w] = running;
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
@@ -119,15 +160,19 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
 // wave-uniform so the records arrive through the scalar cache into SGPRs.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
-k_intersect(const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
+k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
             const typename Q4<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
-            const uint32_t* __restrict__ count)
+            const uint32_t* __restrict__ counts_k)
 {
     typedef typename Q4<R>::T R4;
-    const uint32_t n = *count;
+    const uint32_t w = grid_wave();
+    if (w >= a.n_regions)
+        return;
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t begin = w * a.region_size;
+    const uint32_t end = begin + __builtin_amdgcn_readfirstlane(counts_k[w]);
     const int n_shapes = sc->n_shapes;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += stride) {
+    for (uint32_t slot = begin + lane; slot < end; slot += DRT_WAVE) {
         const R4 ra = ray_a[slot];
         const R4 rb = ray_b[slot];
         const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
@@ -186,25 +231,31 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         const typename Q4<R>::T* rec_in,   // rec[k-1] (may alias rec_out when forward only)
         typename Q4<R>::T* rec_out,        // rec[k]
         uint32_t* __restrict__ ids_k, uint32_t* __restrict__ nv,
-        typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ counts)
+        typename Q4<R>::T* __restrict__ lacc, const uint32_t* __restrict__ counts_k,
+        uint32_t* __restrict__ counts_next)
 {
     typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
     stage_scene(lds, sc, params);
 
-    const uint32_t n = counts[k];
-    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t w = grid_wave();
+    if (w >= a.n_regions)
+        return;
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t begin = w * a.region_size;
+    const uint32_t end = begin + __builtin_amdgcn_readfirstlane(counts_k[w]);
     const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
     const R inv_pk = R(1) / pk;
     const uint32_t n_theta = draw_index(k, a.min_bounces);
     const bool next_rr = (k + 1) >= a.min_bounces;
     const bool next_cap = (k + 1) >= a.depth_cap;
+    uint32_t running = 0;
 
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
-        const uint32_t slot = base + threadIdx.x;
+    for (uint32_t off = begin; off < end; off += DRT_WAVE) {
+        const uint32_t slot = off + lane;
         bool alive = false;
         R4 na, nb;
-        if (slot < n) {
+        if (slot < end) {
             const R4 ra = ray_a[slot];
             const R4 rb = ray_b[slot];
             const HitRec<R> h = hit[slot];
@@ -242,11 +293,9 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                 } else {
                     const DevMaterial<R>& m = lds.sc.materials[sh.material];
                     cid = (uint32_t)m.param;
-                    const uint32_t key = drt_rng_path_key(
-                        a.seed, (uint64_t)global_pixel(a, a.p0 + pid % a.Pb) * (uint64_t)a.spp +
-                                    (uint64_t)(a.s0 + pid / a.Pb));
-                    const double u1 = (double)drt_rng_draw(key, n_theta) / DRT_RAND_MAX_D;
-                    const R u2 = (R)((double)drt_rng_draw(key, n_theta + 1) / DRT_RAND_MAX_D);
+                    const uint32_t key = pid_unpack(rb.w);
+                    const uint32_t r1 = drt_rng_draw(key, n_theta);
+                    const R u2 = u01(R(0), drt_rng_draw(key, n_theta + 1));
                     R sphi, cphi;
                     sincospi_r(R(2) * u2, &sphi, &cphi);       // phi = 2 pi u2
                     V3<R> tg, bt;
@@ -254,15 +303,16 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     V3<R> wo;
                     R q, bs;
                     if (m.type == DRT_BXDF_DIFFUSE) {
-                        // bxdf.hpp:69-79: theta = asin(sqrt(u1)) => sin = sqrt(u1), cos = sqrt(1-u1)
-                        // (1 - u1 formed in double so cos never rounds to 0: pdf > 0)
-                        const R st = sqrt_r((R)u1), ct = sqrt_r((R)(1.0 - u1));
+                        // bxdf.hpp:69-79: theta = asin(sqrt(u1)) => sin = sqrt(u1), cos = sqrt(1-u1);
+                        // 1 - u1 comes from the exact integer RAND_MAX - r so cos (and the pdf)
+                        // is never rounded to 0
+                        const R st = sqrt_r(u01(R(0), r1)), ct = sqrt_r(one_minus_u01(R(0), r1));
                         wo = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
                         q = ct * (R)(1.0 / DRT_PI);
                         bs = (R)(1.0 / DRT_PI);                // bxdf.hpp:63-67: color / pi
                     } else {
                         // bxdf.hpp:106-120: cos^2(theta) = u1^(2/(e+2)); sin^2 formed in double
-                        const double c2 = pow(u1, 2.0 / ((double)m.exponent + 2.0));
+                        const double c2 = pow((double)r1 / DRT_RAND_MAX_D, 2.0 / ((double)m.exponent + 2.0));
                         const R ct = sqrt_r((R)c2), st = sqrt_r((R)(1.0 - c2));
                         const V3<R> wi = -d;
                         V3<R> hv = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
@@ -284,7 +334,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     // roulette / cap of depth k+1, decided here so dead rays are never queued
                     alive = !next_cap;
                     if (alive && next_rr)
-                        alive = !((double)drt_rng_draw(key, n_theta + 2) / DRT_RAND_MAX_D < a.absorb);
+                        alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
                     if (BWD || alive) {
                         R4 r; r.x = Tn.x; r.y = Tn.y; r.z = Tn.z; r.w = mk_;
                         rec_out[pid] = r;
@@ -295,16 +345,39 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     }
                     const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
                     na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
-                    nb.x = wo.y; nb.y = wo.z; nb.z = rb.z; nb.w = R(0);
+                    nb.x = wo.y; nb.y = wo.z; nb.z = rb.z; nb.w = rb.w;
                 }
             }
         }
-        const uint32_t ns = wave_append(&counts[k + 1], alive);
+        uint32_t n_alive;
+        const uint32_t ns = begin + running + wave_rank(alive, n_alive);
         if (alive) {
             next_a[ns] = na;
             next_b[ns] = nb;
         }
+        running += n_alive;
     }
+    if (lane == 0)
+        counts_next[w] = running;
+}
+
+// segments of one batch = rays queued at depths 0..D-1, summed over regions -> 64-bit total
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long red[DRT_BLOCK];
+    unsigned long long v = 0;
+    for (uint32_t i = threadIdx.x; i < n_words; i += DRT_BLOCK)
+        v += counts[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *total += red[0];
 }
 
 // ---- K5 ---------------------------------------------------------------------------------------
