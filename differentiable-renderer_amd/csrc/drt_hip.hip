@@ -197,15 +197,14 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const size_t N = (size_t)Pb * Sb;   // batch capacity in paths
     const int D = depth_cap;
     // queue regions: one wave each; enough of them to fill 256 CUs several times over
-    uint32_t region_size = 1024;
+    uint32_t region_shift = 8;   // 256 slots: 4 chunks per wave (sweep in profiles/: 64..4096)
     if (const char* e = getenv("DRT_HIP_REGION_SIZE")) {
         long v = atol(e);
-        if (v >= 64)
-            region_size = (uint32_t)v;
+        for (region_shift = 6; region_shift < 20 && (1l << region_shift) < v; ++region_shift) { }
     }
-    while (region_size > 64 && N / region_size < (size_t)ctx->n_cu * 32)
-        region_size /= 2;
-    region_size = (region_size + DRT_WAVE - 1) / DRT_WAVE * DRT_WAVE;
+    while (region_shift > 6 && (N >> region_shift) < (size_t)ctx->n_cu * 32)
+        --region_shift;
+    const uint32_t region_size = 1u << region_shift;
     const uint32_t max_regions = (uint32_t)((N + region_size - 1) / region_size);
 
     int rc;
@@ -248,6 +247,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         a.right[i] = cam->right[i]; a.up[i] = cam->up[i];
     }
     a.region_size = region_size;
+    a.region_shift = region_shift;
     {   // smallest r with !(double(r) / RAND_MAX < absorb): the roulette test as an integer compare
         double guess = floor(rp->absorb * DRT_RAND_MAX_D);
         int64_t r = (int64_t)guess - 2;
@@ -293,7 +293,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             for (int k = 0; k < D; ++k) {
                 const int cur = k & 1, nxt = cur ^ 1;
                 if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_intersect<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                    ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
@@ -316,7 +316,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->launches[DRT_K_SHADE]++;
             }
 
-            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, counts,
+            hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts,
                                (uint32_t)((size_t)D * max_regions), (unsigned long long*)ctx->segtotal.p);
             if (film) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;

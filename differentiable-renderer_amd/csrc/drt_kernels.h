@@ -39,7 +39,7 @@ struct BatchArgs {
     uint32_t n_paths;        // Pb * Sb
     uint32_t Pb, p0;         // pixels in the batch, first shard-local pixel
     uint32_t Sb, s0;         // samples in the batch, first sample
-    uint32_t n_regions, region_size;   // queue regions, one wave each (region_size % 64 == 0)
+    uint32_t n_regions, region_size, region_shift;   // queue regions, one wave each; region_size = 1 << region_shift >= 64
     uint32_t rr_threshold;   // r31 < rr_threshold  <=>  double(r31) / RAND_MAX < absorb (exact)
     // image / sharding
     int32_t W, H, spp;
@@ -157,7 +157,10 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
 
 // ---- K2 ---------------------------------------------------------------------------------------
 // Streaming kernel: 2 x 16-byte loads, 1 x 8-byte store per ray; the shape loop index is
-// wave-uniform so the records arrive through the scalar cache into SGPRs.
+// wave-uniform so the records arrive through the scalar cache into SGPRs.  K2 appends nothing,
+// so it does not need the one-wave-per-region mapping: a persistent grid sweeps the 64-slot
+// chunks of all regions in address order (neighbouring waves stream neighbouring kilobytes, which
+// keeps DRAM pages open) and skips the chunks beyond a region's live count.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
@@ -165,14 +168,20 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
             const uint32_t* __restrict__ counts_k)
 {
     typedef typename Q4<R>::T R4;
-    const uint32_t w = grid_wave();
-    if (w >= a.n_regions)
-        return;
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
-    const uint32_t begin = w * a.region_size;
-    const uint32_t end = begin + __builtin_amdgcn_readfirstlane(counts_k[w]);
+    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
+    const uint32_t cpr_shift = a.region_shift - 6;                   // chunks per region (log2)
+    const uint32_t n_chunks = a.n_regions << cpr_shift;
     const int n_shapes = sc->n_shapes;
-    for (uint32_t slot = begin + lane; slot < end; slot += DRT_WAVE) {
+    for (uint32_t c = grid_wave(); c < n_chunks; c += n_waves) {
+        const uint32_t w = c >> cpr_shift;
+        const uint32_t off = (c - (w << cpr_shift)) * DRT_WAVE;
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(counts_k[w]);
+        if (off >= cnt)
+            continue;
+        if (off + lane >= cnt)
+            continue;
+        const uint32_t slot = (w << a.region_shift) + off + lane;
         const R4 ra = ray_a[slot];
         const R4 rb = ray_b[slot];
         const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
@@ -365,19 +374,22 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total)
 {
-    __shared__ unsigned long long red[DRT_BLOCK];
+    __shared__ unsigned long long red[DRT_BLOCK / DRT_WAVE];
     unsigned long long v = 0;
-    for (uint32_t i = threadIdx.x; i < n_words; i += DRT_BLOCK)
+    for (uint32_t i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n_words; i += gridDim.x * DRT_BLOCK)
         v += counts[i];
-    red[threadIdx.x] = v;
+    for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    if ((threadIdx.x & (DRT_WAVE - 1)) == 0)
+        red[threadIdx.x / DRT_WAVE] = v;
     __syncthreads();
-    for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
+            t += red[w];
+        if (t)
+            atomicAdd(total, t);   // integer: order-independent
     }
-    if (threadIdx.x == 0)
-        *total += red[0];
 }
 
 // ---- K5 ---------------------------------------------------------------------------------------

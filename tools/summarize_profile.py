@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (tools/profile.sh) into a small text/JSON summary:
+per-kernel launches, average duration, and PMC counters per launch.
+FETCH_SIZE is doubled for the bytes estimate as MI355X_MICROARCH.md (HBM section) prescribes
+for wide coalesced streams on gfx950; both raw and corrected values are printed."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pattern):
+    r = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    n = name.split("(")[0]
+    for k in ("k_raygen", "k_intersect", "k_shade", "k_film", "k_resolve", "k_backward", "k_gradreduce", "k_sum_counts"):
+        if k in n:
+            tag = k
+            if "<double" in name or "Id" in n.split(k)[-1][:3]:
+                tag += "<f64>"
+            if k == "k_shade":
+                tag += "<bwd>" if ("true" in name or "Lb1" in name) else "<fwd>"
+            return tag
+    return n[:40]
+
+
+summary = {}
+kt = find("trace", "*kernel_trace.csv")
+if kt:
+    d = defaultdict(list)
+    for row in csv.DictReader(open(kt)):
+        d[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    total = sum(sum(v) for v in d.values())
+    print("== kernel trace (rocprofv3 --kernel-trace --stats) ==")
+    print(f"{'kernel':28s} {'calls':>7s} {'avg_us':>10s} {'total_ms':>10s} {'%':>6s}")
+    for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k:28s} {len(v):7d} {sum(v)/len(v)/1e3:10.2f} {sum(v)/1e6:10.3f} {100*sum(v)/total:6.1f}")
+        summary.setdefault(k, {})["calls"] = len(v)
+        summary[k]["avg_us"] = sum(v) / len(v) / 1e3
+
+for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]),
+                      ("pmc_sq", ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                  "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU"])):
+    cc = find(sub, "*counter_collection.csv")
+    if not cc:
+        continue
+    d = defaultdict(lambda: defaultdict(list))
+    for row in csv.DictReader(open(cc)):
+        d[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    print(f"== PMC {sub} (per launch averages) ==")
+    for k, cs in d.items():
+        line = f"{k:28s}"
+        for c in counters:
+            if c in cs:
+                avg = sum(cs[c]) / len(cs[c])
+                summary.setdefault(k, {})[c] = avg
+                line += f" {c}={avg:.4g}"
+        print(line)
+
+# HBM bytes per launch: FETCH_SIZE/WRITE_SIZE are in KiB (rocprofv3 derived metric units)
+print("== HBM traffic per launch (KiB counters -> bytes; FETCH x2 gfx950 correction) ==")
+traffic = {}
+for k, v in summary.items():
+    if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+        f = v.get("FETCH_SIZE", 0.0) * 1024.0
+        w = v.get("WRITE_SIZE", 0.0) * 1024.0
+        traffic[k] = {"fetch_raw_B": f, "fetch_corrected_B": 2 * f, "write_B": w, "total_corrected_B": 2 * f + w}
+        print(f"{k:28s} fetch_raw={f/1e6:9.2f} MB  fetch_x2={2*f/1e6:9.2f} MB  write={w/1e6:9.2f} MB  total={(2*f+w)/1e6:9.2f} MB")
+json.dump({"kernels": summary, "traffic": traffic}, open(os.path.join(out, "summary.json"), "w"), indent=1)
