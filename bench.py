@@ -29,7 +29,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per ray segment, f32 queues
-BYTES_PER_UNIT = {"intersect": 40.0, "shade_fwd": 104.0, "shade_bwd": 108.0, "backward": 20.0}
+BYTES_PER_UNIT = {"intersect": 32.0, "shade_fwd": 104.0, "shade_bwd": 112.0, "backward": 8.0}
 
 
 def main():

@@ -43,9 +43,19 @@ template <typename R> struct Q4;
 template <> struct Q4<float> { typedef float4 T; };
 template <> struct Q4<double> { typedef double4 T; };
 
+// second and third queue lanes: (d.y, d.z) is all K2 still needs after ray_a, the ids ride apart
+template <typename R> struct Q2;
+template <> struct Q2<float> { typedef float2 T; };
+template <> struct Q2<double> { typedef double2 T; };
+
 template <typename R> struct HitRec;
 template <> struct __attribute__((aligned(8))) HitRec<float> { float t; int prim; };
 template <> struct __attribute__((aligned(16))) HitRec<double> { double t; int prim; int pad; };
+
+// one tape record per path vertex (backward only): T_{k+1} = T_k * color(ids & 0xFFFF) * m
+template <typename R> struct TapeRec;
+template <> struct __attribute__((aligned(8))) TapeRec<float> { float m; uint32_t ids; };
+template <> struct __attribute__((aligned(16))) TapeRec<double> { double m; uint32_t ids; uint32_t pad; };
 
 __device__ inline float pid_pack(float, uint32_t pid) { return __uint_as_float(pid); }
 __device__ inline double pid_pack(double, uint32_t pid) { return (double)pid; }
@@ -68,10 +78,15 @@ template <typename R> __device__ inline V3<R> cross(V3<R> a, V3<R> b)
 {
     return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ inline float rsqrt_r(float x) { return 1.0f / sqrtf(x); }
+// f32: the hardware's 1-ulp v_rsq / v_sqrt / v_rcp (no IEEE refinement sequences: they are
+// ~10 VALU instructions each and the path is already tolerance-, not bit-, comparable to the
+// fp64 reference).  f64 (verification mode): correctly rounded.
+__device__ inline float rsqrt_r(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double rsqrt_r(double x) { return 1.0 / sqrt(x); }
-__device__ inline float sqrt_r(float x) { return sqrtf(x); }
+__device__ inline float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ inline double sqrt_r(double x) { return sqrt(x); }
+__device__ inline float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ inline double div_r(double a, double b) { return a / b; }
 __device__ inline float abs_r(float x) { return fabsf(x); }
 __device__ inline double abs_r(double x) { return fabs(x); }
 __device__ inline float pow_r(float x, float y) { return powf(x, y); }
@@ -94,31 +109,21 @@ __device__ inline bool shape_intersect(const DevShape<R>& s, V3<R> o, V3<R> d, R
     if (s.type == DRT_SHAPE_PLANE) {
         V3<R> n = mk<R>(s.p[0], s.p[1], s.p[2]);
         R h = dot(o, n) - s.p[3];
-        t = h / -dot(d, n);
+        t = div_r(h, -dot(d, n));
         return t > R(0);
     }
+    // Sphere, shape.hpp:78-103 without divergent branches: with sqrt(disc) >= 0, t1 <= t2, so the
+    // reference's cascade (both > 0: min; else t1 > 0: t1; else t2 > 0: t2) is "t1 if t1 > 0
+    // else t2", accepted when disc >= 0 and that t > 0 (NaN fails every test, as it does there).
     V3<R> oc = o - mk<R>(s.p[0], s.p[1], s.p[2]);
     R b = R(2) * dot(oc, d);
     R c = dot(oc, oc) - s.p[3] * s.p[3];
     R disc = b * b - R(4) * c;
-    if (disc < R(0))
-        return false;
-    R sq = sqrt_r(disc);
+    R sq = sqrt_r(disc > R(0) ? disc : R(0));
     R t1 = (-b - sq) * R(0.5);
     R t2 = (-b + sq) * R(0.5);
-    if (t1 > R(0) && t2 > R(0)) {
-        t = t2 < t1 ? t2 : t1;
-        return true;
-    }
-    if (t1 > R(0)) {
-        t = t1;
-        return true;
-    }
-    if (t2 > R(0)) {
-        t = t2;
-        return true;
-    }
-    return false;
+    t = t1 > R(0) ? t1 : t2;
+    return disc >= R(0) && t > R(0);
 }
 
 template <typename R>

@@ -41,7 +41,7 @@ struct drt_hip_ctx {
     float* d_params_f = nullptr;
     double* d_params_d = nullptr;
 
-    DevBuf ray_a[2], ray_b[2], hit, lacc, rec, ids, nv, counts, segtotal, film, gpart, grad, adjoint, out;
+    DevBuf ray_a[2], ray_b[2], ray_id[2], ray_c[2], hit, lacc, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
@@ -210,13 +210,14 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     int rc;
     for (int i = 0; i < 2; ++i) {
         if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ray_b[i], N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ray_b[i], N * sizeof(typename Q2<R>::T))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ray_id[i], N * sizeof(uint2))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ray_c[i], N * sizeof(R4))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->rec, N * sizeof(R4) * (backward ? (size_t)(D > 0 ? D : 1) : 1))) != DRT_OK) return rc;
     if (backward) {
-        if ((rc = ensure(ctx, ctx->ids, N * sizeof(uint32_t) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
     }
     const uint64_t n_pix_batches = (n_local_pixels + Pb - 1) / Pb;
@@ -260,11 +261,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     a.aspect = (double)cam->width / (double)cam->height;
 
     R4* ra[2] = {(R4*)ctx->ray_a[0].p, (R4*)ctx->ray_a[1].p};
-    R4* rb[2] = {(R4*)ctx->ray_b[0].p, (R4*)ctx->ray_b[1].p};
+    typedef typename Q2<R>::T R2;
+    R2* rb[2] = {(R2*)ctx->ray_b[0].p, (R2*)ctx->ray_b[1].p};
+    uint2* rid[2] = {(uint2*)ctx->ray_id[0].p, (uint2*)ctx->ray_id[1].p};
     HitRec<R>* hit = (HitRec<R>*)ctx->hit.p;
     R4* lacc = (R4*)ctx->lacc.p;
-    R4* rec = (R4*)ctx->rec.p;
-    uint32_t* ids = (uint32_t*)ctx->ids.p;
+    R4* rcq[2] = {(R4*)ctx->ray_c[0].p, (R4*)ctx->ray_c[1].p};
+    TapeRec<R>* tape = (TapeRec<R>*)ctx->tape.p;
     uint32_t* nv = backward ? (uint32_t*)ctx->nv.p : nullptr;
     double* grad = (double*)ctx->grad.p;
     double* gpart = (double*)ctx->gpart.p;
@@ -285,7 +288,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 
             if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
             hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
-                               lacc, nv, counts);
+                               rid[0], lacc, nv, counts);
             if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
             st->launches[DRT_K_RAYGEN]++;
             st->units[DRT_K_RAYGEN] += a.n_paths;
@@ -298,19 +301,17 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
 
-                R4* rec_in = backward ? rec + (size_t)(k > 0 ? k - 1 : 0) * a.n_paths : rec;
-                R4* rec_out = backward ? rec + (size_t)k * a.n_paths : rec;
-                uint32_t* ids_k = backward ? ids + (size_t)k * a.n_paths : nullptr;
+                TapeRec<R>* tape_k = backward ? tape + (size_t)k * a.n_paths : nullptr;
                 if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
                 if (backward)
                     hipLaunchKernelGGL((k_shade<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
-                                       d_scene, d_params, ra[cur], rb[cur], hit, ra[nxt], rb[nxt], rec_in,
-                                       rec_out, ids_k, nv, lacc, counts + (size_t)k * max_regions,
+                                       d_scene, d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt],
+                                       rb[nxt], rid[nxt], rcq[nxt], tape_k, nv, lacc, counts + (size_t)k * max_regions,
                                        counts + (size_t)(k + 1) * max_regions);
                 else
                     hipLaunchKernelGGL((k_shade<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
-                                       d_scene, d_params, ra[cur], rb[cur], hit, ra[nxt], rb[nxt], rec_in,
-                                       rec_out, ids_k, nv, lacc, counts + (size_t)k * max_regions,
+                                       d_scene, d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt],
+                                       rb[nxt], rid[nxt], rcq[nxt], tape_k, nv, lacc, counts + (size_t)k * max_regions,
                                        counts + (size_t)(k + 1) * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_SHADE]++;
@@ -329,7 +330,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                 hipLaunchKernelGGL(k_backward<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                   d_params, rec, ids, nv, d_adjoint, gpart, grad);
+                                   d_params, tape, nv, d_adjoint, gpart, grad);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_BACKWARD]++;
                 if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
@@ -397,8 +398,8 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->hit, &ctx->lacc,
-                      &ctx->rec, &ctx->ids, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
+    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->ray_c[0],
+                      &ctx->ray_c[1], &ctx->hit, &ctx->lacc, &ctx->tape, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
     for (DevBuf* b : bufs)
         release(*b);

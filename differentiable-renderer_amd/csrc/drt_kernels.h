@@ -12,11 +12,13 @@
 //
 // Data layout in HBM (R = float, 16-byte lanes; R = double doubles every lane):
 //   ray_a[2][N]  (o.x, o.y, o.z, d.x)         dense by queue slot, ping-pong per bounce
-//   ray_b[2][N]  (d.y, d.z, path index, -)
+//   ray_b[2][N]  (d.y, d.z)                    8 bytes: K2 reads ray_a + ray_b = 24 B, all used
+//   ray_id[2][N] (path index, RNG path key)    8 bytes, K3 only
+//   ray_c[2][N]  (T.r, T.g, T.b, -) throughput of the path so far (not read at depth 0: T = 1)
 //   hit[N]       (t, shape index | -1)         dense by queue slot
-//   rec[D][N]    (T_{k+1}.rgb, m_k)            by path index; D = 1 (in place) when forward only
-//   ids[D][N]    colour param | emission param << 16      (backward only)
-//   nv[N]        vertices of the path                      (backward only)
+//   tape[D][N]   (m_k, colour param | emission param << 16)   by path index, backward only:
+//                T_{k+1} = T_k * colour * m_k, so K6 rebuilds every T_k from 8 bytes per vertex
+//   nv[N]        vertices of the path                          (backward only)
 //   lacc[N]      (L.rgb, -) radiance accumulated along the path, by path index
 //   counts[D+1][n_regions]  queue lengths per depth and region (device-resident: no host round
 //                trip per bounce)
@@ -98,8 +100,8 @@ __device__ inline uint32_t draw_index(int k, int min_bounces)
 // ones that survive the depth-0 roulette to the front of the region.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
-k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* __restrict__ ray_b,
-         typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
+k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* __restrict__ ray_b,
+         uint2* __restrict__ ray_id, typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
 {
     typedef typename Q4<R>::T R4;
     const uint32_t w = grid_wave();
@@ -112,7 +114,9 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
     for (uint32_t off = begin; off < end; off += DRT_WAVE) {
         const uint32_t i = off + lane;
         bool alive = i < end;
-        R4 ra, rb;
+        R4 ra;
+        typename Q2<R>::T rb;
+        uint2 rid;
         if (alive) {
             const uint32_t sl = i / a.Pb, pl = i - sl * a.Pb;
             const uint32_t gpix = global_pixel(a, a.p0 + pl);
@@ -137,7 +141,8 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
             else if (a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold)
                 alive = false;
             ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dx;
-            rb.x = (R)dy; rb.y = (R)dz; rb.z = pid_pack(R(0), i); rb.w = pid_pack(R(0), key);
+            rb.x = (R)dy; rb.y = (R)dz;
+            rid.x = i; rid.y = key;
             R4 zero; zero.x = zero.y = zero.z = zero.w = R(0);
             lacc[i] = zero;
             if (nv && !alive)
@@ -148,6 +153,7 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
         if (alive) {
             ray_a[slot] = ra;
             ray_b[slot] = rb;
+            ray_id[slot] = rid;
         }
         running += n_alive;
     }
@@ -156,49 +162,73 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q4<R>::T* 
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
-// Streaming kernel: 2 x 16-byte loads, 1 x 8-byte store per ray; the shape loop index is
+// Streaming kernel: a 16-byte and an 8-byte load, one 8-byte store per ray (32 B, all used); the shape loop index is
 // wave-uniform so the records arrive through the scalar cache into SGPRs.  K2 appends nothing,
 // so it does not need the one-wave-per-region mapping: a persistent grid sweeps the 64-slot
 // chunks of all regions in address order (neighbouring waves stream neighbouring kilobytes, which
-// keeps DRAM pages open) and skips the chunks beyond a region's live count.
+// keeps DRAM pages open) and skips the chunks beyond a region's live count.  Two chunks are in
+// flight per wave (their loads are issued before either is consumed).
+// Closest hit of TWO independent rays in one pass over the shapes: each shape record is fetched
+// once (scalar load) for both, and the two dependency chains interleave.
+template <typename R>
+__device__ inline void closest_hit2(const DevScene<R>* __restrict__ sc, int n_shapes,
+                                    typename Q4<R>::T ra0, typename Q2<R>::T rb0,
+                                    typename Q4<R>::T ra1, typename Q2<R>::T rb1,
+                                    HitRec<R>& h0, HitRec<R>& h1)
+{
+    const V3<R> o0 = mk<R>(ra0.x, ra0.y, ra0.z), d0 = mk<R>(ra0.w, rb0.x, rb0.y);
+    const V3<R> o1 = mk<R>(ra1.x, ra1.y, ra1.z), d1 = mk<R>(ra1.w, rb1.x, rb1.y);
+    R tmin0 = (R)INFINITY, tmin1 = (R)INFINITY;
+    int prim0 = -1, prim1 = -1;
+#pragma unroll 3
+    for (int s = 0; s < n_shapes; ++s) {
+        const DevShape<R> sh = sc->shapes[s];
+        R t0, t1;
+        const bool hit0 = shape_intersect(sh, o0, d0, t0);
+        const bool hit1 = shape_intersect(sh, o1, d1, t1);
+        if (hit0 && !(t0 >= tmin0)) { tmin0 = t0; prim0 = s; }          // pathtracer.hpp:80
+        if (hit1 && !(t1 >= tmin1)) { tmin1 = t1; prim1 = s; }
+    }
+    h0.t = tmin0; h0.prim = prim0;
+    h1.t = tmin1; h1.prim = prim1;
+}
+
+// slot of this lane in chunk c, or 0xFFFFFFFF when the lane has no live ray there
+__device__ inline uint32_t chunk_slot(const BatchArgs& a, const uint32_t* __restrict__ counts_k,
+                                      uint32_t c, uint32_t n_chunks, uint32_t lane)
+{
+    if (c >= n_chunks)
+        return 0xFFFFFFFFu;
+    const uint32_t cpr_shift = a.region_shift - 6;
+    const uint32_t w = c >> cpr_shift;
+    const uint32_t off = (c - (w << cpr_shift)) * DRT_WAVE + lane;
+    const uint32_t cnt = __builtin_amdgcn_readfirstlane(counts_k[w]);
+    return off < cnt ? (w << a.region_shift) + off : 0xFFFFFFFFu;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
-            const typename Q4<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
+            const typename Q2<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
             const uint32_t* __restrict__ counts_k)
 {
     typedef typename Q4<R>::T R4;
+    typedef typename Q2<R>::T R2;
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const uint32_t cpr_shift = a.region_shift - 6;                   // chunks per region (log2)
-    const uint32_t n_chunks = a.n_regions << cpr_shift;
+    const uint32_t n_chunks = a.n_regions << (a.region_shift - 6);
     const int n_shapes = sc->n_shapes;
-    for (uint32_t c = grid_wave(); c < n_chunks; c += n_waves) {
-        const uint32_t w = c >> cpr_shift;
-        const uint32_t off = (c - (w << cpr_shift)) * DRT_WAVE;
-        const uint32_t cnt = __builtin_amdgcn_readfirstlane(counts_k[w]);
-        if (off >= cnt)
-            continue;
-        if (off + lane >= cnt)
-            continue;
-        const uint32_t slot = (w << a.region_shift) + off + lane;
-        const R4 ra = ray_a[slot];
-        const R4 rb = ray_b[slot];
-        const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
-        const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
-        R tmin = (R)INFINITY;
-        int prim = -1;
-        for (int s = 0; s < n_shapes; ++s) {
-            R t;
-            if (shape_intersect(sc->shapes[s], o, d, t) && !(t >= tmin)) {
-                tmin = t;
-                prim = s;
-            }
-        }
-        HitRec<R> h;
-        h.t = tmin;
-        h.prim = prim;
-        hit[slot] = h;
+    for (uint32_t c = grid_wave(); c < n_chunks; c += 2 * n_waves) {
+        const uint32_t s0 = chunk_slot(a, counts_k, c, n_chunks, lane);
+        const uint32_t s1 = chunk_slot(a, counts_k, c + n_waves, n_chunks, lane);
+        R4 ra0 = {}, ra1 = {};
+        R2 rb0 = {}, rb1 = {};
+        if (s0 != 0xFFFFFFFFu) { ra0 = ray_a[s0]; rb0 = ray_b[s0]; }
+        if (s1 != 0xFFFFFFFFu) { ra1 = ray_a[s1]; rb1 = ray_b[s1]; }
+        HitRec<R> h0, h1;
+        closest_hit2<R>(sc, n_shapes, ra0, rb0, ra1, rb1, h0, h1);
+        if (s0 != 0xFFFFFFFFu) hit[s0] = h0;
+        if (s1 != 0xFFFFFFFFu) hit[s1] = h1;
     }
 }
 
@@ -231,15 +261,42 @@ __device__ inline V3<R> load_param(const SceneLds<R>& lds, const R* __restrict__
     return mk<R>(params[id * 3], params[id * 3 + 1], params[id * 3 + 2]);
 }
 
+// what K3 consumes per ray: its queue lanes and the hit record
+template <typename R>
+struct ShadeIn {
+    typename Q4<R>::T ra, rc;
+    typename Q2<R>::T rb;
+    uint2 rid;
+    HitRec<R> h;
+};
+
+template <typename R>
+__device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, int k,
+                                     const typename Q4<R>::T* __restrict__ ray_a,
+                                     const typename Q2<R>::T* __restrict__ ray_b,
+                                     const uint2* __restrict__ ray_id,
+                                     const typename Q4<R>::T* __restrict__ ray_c,
+                                     const HitRec<R>* __restrict__ hit)
+{
+    if (have) {
+        in.ra = ray_a[slot];
+        in.rb = ray_b[slot];
+        in.rid = ray_id[slot];
+        in.h = hit[slot];
+        if (k > 0)
+            in.rc = ray_c[slot];
+    }
+}
+
 template <typename R, bool BWD>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
-        const typename Q4<R>::T* __restrict__ ray_a, const typename Q4<R>::T* __restrict__ ray_b,
-        const HitRec<R>* __restrict__ hit,
-        typename Q4<R>::T* __restrict__ next_a, typename Q4<R>::T* __restrict__ next_b,
-        const typename Q4<R>::T* rec_in,   // rec[k-1] (may alias rec_out when forward only)
-        typename Q4<R>::T* rec_out,        // rec[k]
-        uint32_t* __restrict__ ids_k, uint32_t* __restrict__ nv,
+        const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
+        const uint2* __restrict__ ray_id,
+        const typename Q4<R>::T* __restrict__ ray_c, const HitRec<R>* __restrict__ hit,
+        typename Q4<R>::T* __restrict__ next_a, typename Q2<R>::T* __restrict__ next_b,
+        uint2* __restrict__ next_id, typename Q4<R>::T* __restrict__ next_c,
+        TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
         typename Q4<R>::T* __restrict__ lacc, const uint32_t* __restrict__ counts_k,
         uint32_t* __restrict__ counts_next)
 {
@@ -251,7 +308,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
     if (w >= a.n_regions)
         return;
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
-    const uint32_t begin = w * a.region_size;
+    const uint32_t begin = w << a.region_shift;
     const uint32_t end = begin + __builtin_amdgcn_readfirstlane(counts_k[w]);
     const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
     const R inv_pk = R(1) / pk;
@@ -260,15 +317,24 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
     const bool next_cap = (k + 1) >= a.depth_cap;
     uint32_t running = 0;
 
+    // software pipeline: the loads of chunk i+1 are issued before chunk i is shaded
+    ShadeIn<R> cur, nxt;
+    bool have = begin + lane < end;
+    load_shade_in(cur, begin + lane, have, k, ray_a, ray_b, ray_id, ray_c, hit);
+
     for (uint32_t off = begin; off < end; off += DRT_WAVE) {
-        const uint32_t slot = off + lane;
+        const uint32_t nslot = off + DRT_WAVE + lane;
+        const bool nhave = nslot < end;
+        load_shade_in(nxt, nslot, nhave, k, ray_a, ray_b, ray_id, ray_c, hit);
+
         bool alive = false;
-        R4 na, nb;
-        if (slot < end) {
-            const R4 ra = ray_a[slot];
-            const R4 rb = ray_b[slot];
-            const HitRec<R> h = hit[slot];
-            const uint32_t pid = pid_unpack(rb.z);
+        R4 na, nc;
+        typename Q2<R>::T nb;
+        if (have) {
+            const R4 ra = cur.ra;
+            const typename Q2<R>::T rb = cur.rb;
+            const HitRec<R> h = cur.h;
+            const uint32_t pid = cur.rid.x;
             if (h.prim < 0) {
                 if (BWD) nv[pid] = (uint32_t)k;               // miss: pathtracer.hpp:135
             } else {
@@ -278,10 +344,8 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                 const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
                 const V3<R> nrm = shape_normal(sh, P);
                 V3<R> T = mk<R>(R(1), R(1), R(1));
-                if (k > 0) {
-                    const R4 r = rec_in[pid];
-                    T = mk<R>(r.x, r.y, r.z);
-                }
+                if (k > 0)
+                    T = mk<R>(cur.rc.x, cur.rc.y, cur.rc.z);
                 uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
                 if (sh.emitter >= 0) {                         // pathtracer.hpp:113-114
                     eid = (uint32_t)lds.sc.emitter_param[sh.emitter];
@@ -296,13 +360,16 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
                     // continuation contributes exactly 0, the path ends here
                     if (BWD) {
-                        ids_k[pid] = DRT_ID_NONE | (eid << 16);
+                        TapeRec<R> tr;
+                        tr.m = R(0);
+                        tr.ids = DRT_ID_NONE | (eid << 16);
+                        tape_k[pid] = tr;
                         nv[pid] = (uint32_t)k + 1u;
                     }
                 } else {
                     const DevMaterial<R>& m = lds.sc.materials[sh.material];
                     cid = (uint32_t)m.param;
-                    const uint32_t key = pid_unpack(rb.w);
+                    const uint32_t key = cur.rid.y;
                     const uint32_t r1 = drt_rng_draw(key, n_theta);
                     const R u2 = u01(R(0), drt_rng_draw(key, n_theta + 1));
                     R sphi, cphi;
@@ -344,17 +411,17 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     alive = !next_cap;
                     if (alive && next_rr)
                         alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                    if (BWD || alive) {
-                        R4 r; r.x = Tn.x; r.y = Tn.y; r.z = Tn.z; r.w = mk_;
-                        rec_out[pid] = r;
-                    }
                     if (BWD) {
-                        ids_k[pid] = cid | (eid << 16);
+                        TapeRec<R> tr;
+                        tr.m = mk_;
+                        tr.ids = cid | (eid << 16);
+                        tape_k[pid] = tr;
                         if (!alive) nv[pid] = (uint32_t)k + 1u;
                     }
                     const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
                     na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
-                    nb.x = wo.y; nb.y = wo.z; nb.z = rb.z; nb.w = rb.w;
+                    nb.x = wo.y; nb.y = wo.z;
+                    nc.x = Tn.x; nc.y = Tn.y; nc.z = Tn.z; nc.w = R(0);
                 }
             }
         }
@@ -363,8 +430,12 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         if (alive) {
             next_a[ns] = na;
             next_b[ns] = nb;
+            next_id[ns] = cur.rid;
+            next_c[ns] = nc;
         }
         running += n_alive;
+        cur = nxt;
+        have = nhave;
     }
     if (lane == 0)
         counts_next[w] = running;
@@ -425,30 +496,53 @@ k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float
 }
 
 // ---- K6 ---------------------------------------------------------------------------------------
-// One thread per path, vertices walked deepest-first with the suffix radiance in registers:
-//   L_k = E_k / p_k + color_k * m_k * L_{k+1}
-//   d/dE_k     += g * T_k / p_k
-//   d/dcolor_k += g * T_k * m_k * L_{k+1}
+// One thread per path.  The tape holds 8 bytes per vertex (m_k, parameter ids); the prefix
+// throughputs T_k are rebuilt in registers with the very expression K3 used
+// (T_{k+1} = T_k * colour * m_k), DRT_TAPE_CHUNK vertices at a time, then the chunk is walked
+// deepest-first with the suffix radiance in registers:
+//   L_k = E_k / p_k + colour_k * m_k * L_{k+1}
+//   d/dE_k      += g * T_k / p_k
+//   d/dcolour_k += g * T_k * m_k * L_{k+1}
+// (closed form of the backward functors vector.hpp:418-484).  Paths longer than one
+// chunk rebuild the prefix product of the earlier chunks from the tape again.
 // Parameter ids < DRT_FAST_PARAMS accumulate in registers (compare-select, no atomics, fixed
 // order => bitwise reproducible); other ids use fp64 atomics on the gradient vector.
+#define DRT_TAPE_CHUNK 8
+
+// Per-thread accumulator columns in LDS: acc[row = param * 3 + channel][thread].  A thread only
+// ever touches its own column (bank = thread % 32: conflict-free), so the LDS add needs no
+// ordering: a plain ds_read / v_add / ds_write (LDS float ATOMICS were measured 4x slower than
+// the whole rest of the kernel: they serialise per lane).
+template <typename R>
+__device__ inline void grad_accumulate(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
+{
+    if (id < DRT_FAST_PARAMS) {
+        acc[id * 3 + 0][threadIdx.x] += v.x;
+        acc[id * 3 + 1][threadIdx.x] += v.y;
+        acc[id * 3 + 2][threadIdx.x] += v.z;
+    } else {
+        atomicAdd(&grad[id * 3 + 0], (double)v.x);
+        atomicAdd(&grad[id * 3 + 1], (double)v.y);
+        atomicAdd(&grad[id * 3 + 2], (double)v.z);
+    }
+}
+
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
-           const typename Q4<R>::T* __restrict__ rec, const uint32_t* __restrict__ ids,
-           const uint32_t* __restrict__ nv, const float* __restrict__ adjoint,
-           double* __restrict__ gpart, double* __restrict__ grad)
+           const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
+           const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad)
 {
-    typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
+    __shared__ R acc[DRT_FAST_PARAMS * 3][DRT_BLOCK];
     __shared__ double red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+#pragma unroll
+    for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r)
+        acc[r][threadIdx.x] = R(0);
     stage_scene(lds, sc, params);
 
-    R acc[DRT_FAST_PARAMS][3];
-#pragma unroll
-    for (int p = 0; p < DRT_FAST_PARAMS; ++p)
-        acc[p][0] = acc[p][1] = acc[p][2] = R(0);
-
     const size_t N = a.n_paths;
+    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
         const int K = (int)nv[i];
@@ -461,73 +555,64 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                       (R)adjoint[(size_t)gp * 3 + 2]);
         }
         V3<R> Ln = mk<R>(R(0), R(0), R(0));
-        R m_k = rec[(size_t)(K - 1) * N + i].w;
-        for (int k = K - 1; k >= 0; --k) {
-            const uint32_t id = ids[(size_t)k * N + i];
-            const uint32_t cid = id & 0xFFFFu, eid = id >> 16;
+        for (int c0 = ((K - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
+            // prefix throughput at the start of this chunk (only for paths longer than a chunk)
             V3<R> T = mk<R>(R(1), R(1), R(1));
-            R m_prev = R(0);
-            if (k > 0) {
-                const R4 r = rec[(size_t)(k - 1) * N + i];
-                T = mk<R>(r.x, r.y, r.z);
-                m_prev = r.w;
+            for (int j = 0; j < c0; ++j) {
+                const TapeRec<R> tr = tape[(size_t)j * N + i];
+                T = T * load_param(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
             }
-            const R inv_pk = k >= a.min_bounces ? (R)(1.0 / (1.0 - a.absorb)) : R(1);
-            const V3<R> adj = g * T;
-            V3<R> Lk = mk<R>(R(0), R(0), R(0));
-            if (eid != DRT_ID_NONE) {
-                const V3<R> gE = adj * inv_pk;
-                if (eid < DRT_FAST_PARAMS) {
+            R Tx[DRT_TAPE_CHUNK], Ty[DRT_TAPE_CHUNK], Tz[DRT_TAPE_CHUNK], M[DRT_TAPE_CHUNK];
+            uint32_t ID[DRT_TAPE_CHUNK];
+            TapeRec<R> trs[DRT_TAPE_CHUNK];
 #pragma unroll
-                    for (int p = 0; p < DRT_FAST_PARAMS; ++p) {
-                        const bool hitp = eid == (uint32_t)p;
-                        acc[p][0] += hitp ? gE.x : R(0);
-                        acc[p][1] += hitp ? gE.y : R(0);
-                        acc[p][2] += hitp ? gE.z : R(0);
-                    }
-                } else {
-                    atomicAdd(&grad[eid * 3 + 0], (double)gE.x);
-                    atomicAdd(&grad[eid * 3 + 1], (double)gE.y);
-                    atomicAdd(&grad[eid * 3 + 2], (double)gE.z);
-                }
-                Lk = load_param(lds, params, (int)eid) * inv_pk;
-            }
-            if (cid != DRT_ID_NONE) {
-                const V3<R> w = Ln * m_k;
-                const V3<R> gC = adj * w;
-                if (cid < DRT_FAST_PARAMS) {
+            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+                if (c0 + j < K)
+                    trs[j] = tape[(size_t)(c0 + j) * N + i];   // independent loads, all in flight
 #pragma unroll
-                    for (int p = 0; p < DRT_FAST_PARAMS; ++p) {
-                        const bool hitp = cid == (uint32_t)p;
-                        acc[p][0] += hitp ? gC.x : R(0);
-                        acc[p][1] += hitp ? gC.y : R(0);
-                        acc[p][2] += hitp ? gC.z : R(0);
-                    }
-                } else {
-                    atomicAdd(&grad[cid * 3 + 0], (double)gC.x);
-                    atomicAdd(&grad[cid * 3 + 1], (double)gC.y);
-                    atomicAdd(&grad[cid * 3 + 2], (double)gC.z);
+            for (int j = 0; j < DRT_TAPE_CHUNK; ++j) {
+                if (c0 + j < K) {
+                    ID[j] = trs[j].ids;
+                    M[j] = trs[j].m;
+                    Tx[j] = T.x; Ty[j] = T.y; Tz[j] = T.z;
+                    const uint32_t cid = ID[j] & 0xFFFFu;
+                    if (cid != DRT_ID_NONE)
+                        T = T * load_param(lds, params, (int)cid) * M[j];
                 }
-                Lk = Lk + load_param(lds, params, (int)cid) * w;
             }
-            Ln = Lk;
-            m_k = m_prev;
+#pragma unroll
+            for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
+                const int k = c0 + j;
+                if (k < K) {
+                    const uint32_t cid = ID[j] & 0xFFFFu, eid = ID[j] >> 16;
+                    const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
+                    const V3<R> adj = g * mk<R>(Tx[j], Ty[j], Tz[j]);
+                    V3<R> Lk = mk<R>(R(0), R(0), R(0));
+                    if (eid != DRT_ID_NONE) {
+                        grad_accumulate(acc, grad, eid, adj * inv_pk);
+                        Lk = load_param(lds, params, (int)eid) * inv_pk;
+                    }
+                    if (cid != DRT_ID_NONE) {
+                        const V3<R> wgt = Ln * M[j];
+                        grad_accumulate(acc, grad, cid, adj * wgt);
+                        Lk = Lk + load_param(lds, params, (int)cid) * wgt;
+                    }
+                    Ln = Lk;
+                }
+            }
         }
     }
 
-    // block reduction in fp64: lanes -> wave (shuffles) -> block (LDS), fixed order
+    // block reduction in fp64: thread columns -> wave (shuffles) -> block (LDS), fixed order
     const int lane = threadIdx.x & (DRT_WAVE - 1), wave = threadIdx.x / DRT_WAVE;
 #pragma unroll
-    for (int p = 0; p < DRT_FAST_PARAMS; ++p) {
+    for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r) {
+        double v = (double)acc[r][threadIdx.x];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double v = (double)acc[p][c];
-#pragma unroll
-            for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
-                v += __shfl_down(v, off);
-            if (lane == 0)
-                red[wave][p * 3 + c] = v;
-        }
+        for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
+            v += __shfl_down(v, off);
+        if (lane == 0)
+            red[wave][r] = v;
     }
     __syncthreads();
     if (threadIdx.x < DRT_FAST_PARAMS * 3) {

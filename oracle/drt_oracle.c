@@ -398,3 +398,25 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
         *n_vertices = nvlog;
     return status;
 }
+
+/* sizeof / offsetof of the ABI records as the C compiler lays them out (host-binding tests) */
+#include <stddef.h>
+int drt_oracle_abi_layout(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(drt_shape_desc);
+    case 1: return (int)sizeof(drt_material_desc);
+    case 2: return (int)sizeof(drt_emitter_desc);
+    case 3: return (int)sizeof(drt_scene_desc);
+    case 4: return (int)sizeof(drt_camera_desc);
+    case 5: return (int)sizeof(drt_render_params);
+    case 6: return (int)sizeof(drt_hip_stats);
+    case 10: return (int)offsetof(drt_shape_desc, p);
+    case 11: return (int)offsetof(drt_scene_desc, shapes);
+    case 12: return (int)offsetof(drt_camera_desc, eye);
+    case 13: return (int)offsetof(drt_render_params, absorb);
+    case 14: return (int)offsetof(drt_render_params, batch_paths);
+    case 15: return (int)offsetof(drt_hip_stats, ms_kernel);
+    default: return -1;
+    }
+}

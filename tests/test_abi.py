@@ -1,0 +1,80 @@
+"""The C-ABI library: loads on a CPU-only box, exports exactly what include/drt_hip.h declares,
+lays its records out as the ctypes mirror does, and FAILS LOUDLY without a device (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "drt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(drt_hip_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_the_entry_points():
+    syms = declared_symbols()
+    for s in ["drt_hip_device_count", "drt_hip_create", "drt_hip_destroy", "drt_hip_upload_scene",
+              "drt_hip_update_params", "drt_hip_render", "drt_hip_last_error", "drt_hip_abi_version",
+              "drt_hip_stream", "drt_hip_synchronize", "drt_hip_kernel_name"]:
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    pkg.build_native()
+    lib = C.CDLL(pkg.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"libdrt_hip.so does not export {s}"
+    assert pkg.load_library().drt_hip_abi_version() == 1
+    assert sorted(pkg._ABI_SYMBOLS) == declared_symbols()
+
+
+def test_ctypes_mirror_matches_the_c_layout(pkg, oracle):
+    L = oracle.lib().drt_oracle_abi_layout
+    L.restype = C.c_int
+    assert L(0) == C.sizeof(pkg.ShapeDesc)
+    assert L(1) == C.sizeof(pkg.MaterialDesc)
+    assert L(2) == C.sizeof(pkg.EmitterDesc)
+    assert L(3) == C.sizeof(pkg.SceneDesc)
+    assert L(4) == C.sizeof(pkg.CameraDesc)
+    assert L(5) == C.sizeof(pkg.RenderParamsDesc)
+    assert L(6) == C.sizeof(pkg.HipStats)
+    assert L(10) == pkg.ShapeDesc.p.offset
+    assert L(11) == pkg.SceneDesc.shapes.offset
+    assert L(12) == pkg.CameraDesc.eye.offset
+    assert L(13) == pkg.RenderParamsDesc.absorb.offset
+    assert L(14) == pkg.RenderParamsDesc.batch_paths.offset
+    assert L(15) == pkg.HipStats.ms_kernel.offset
+
+
+def test_no_device_means_an_error_not_a_fallback(pkg):
+    """On a box without a GPU the product path must refuse to run."""
+    lib = pkg.load_library()
+    if lib.drt_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert lib.drt_hip_create(0, C.byref(ctx)) == -2      # DRT_ERR_NO_DEVICE
+    assert not ctx.value
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_NO_DEVICE"):
+        pkg.HipRenderer(0)
+
+
+def test_missing_library_is_loud(pkg, tmp_path):
+    with pytest.raises(pkg.DrtHipError, match="not built"):
+        pkg.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_code_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg_dir = os.path.join(ROOT, "differentiable-renderer_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "drt_oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "drt_oracle" not in open(os.path.join(dirpath, f), errors="ignore").read()

@@ -32,7 +32,8 @@ def check_f32(img, grads, segments, g_img, g_grads, g_segments):
     m_got, m_want = img.astype(np.float64).mean((0, 1)), g_img.mean((0, 1))
     # flipped samples move the mean by at most (#flipped / #paths): allow that on tiny renders
     assert np.abs(m_got - m_want).max() <= MEAN_TOL * m_want.max() + 2.0 * bad.sum() / bad.size * scale
-    assert abs(int(segments) - int(g_segments)) <= max(2, int(2e-4 * g_segments))
+    # one path whose fp32 hit/miss decision flips can change the count by its whole length (<= 64)
+    assert abs(int(segments) - int(g_segments)) <= max(64, int(2e-4 * g_segments))
     if g_grads is not None:
         assert grad_rel_err(grads, g_grads) <= GRAD_TOL + 4.0 * bad.sum() / bad.size
 

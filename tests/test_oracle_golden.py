@@ -1,0 +1,84 @@
+"""The fp64 C restatement (oracle/) against the golden vectors captured from the UNMODIFIED
+reference headers (tests/golden/, generator: oracle/gen_golden.py).  Bit-exact: the restatement
+keeps the reference's operation order and shares its libm."""
+import numpy as np
+import pytest
+
+from conftest import SMALL_GOLDENS, case_inputs, load_golden
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDENS + ["g6_libc_64x64x8_d4"])
+def test_oracle_bit_exact_vs_reference_golden(pkg, oracle, name):
+    g = load_golden(name)
+    case = g["case"]
+    scene, cam, rp, adjoint = case_inputs(pkg, case)
+    libc = case.get("rng_mode", 0) == oracle.RNG_LIBC
+    dump = case.get("dump_paths", 0)
+    # the reference keeps tracing zero-direction rays after a light hit: needed for the libc
+    # stream and to reproduce its raycast counters / vertex dumps
+    r = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint,
+                      rng_mode=case.get("rng_mode", 0), faithful=True, dump_paths=dump)
+    np.testing.assert_array_equal(r["image"], g["image"])
+    np.testing.assert_array_equal(r["grads"], g["grads"])
+    assert r["stats"]["segments"] == int(g["segments"])
+    assert r["stats"]["zero_dir_segments"] == int(g["zero_dir_segments"])
+    if dump:
+        np.testing.assert_array_equal(r["vertices"], g["vertices"])
+    if not libc:
+        # skipping the continuation (what the device does) changes nothing but the counters
+        r2 = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint)
+        np.testing.assert_array_equal(r2["image"], g["image"])
+        np.testing.assert_array_equal(r2["grads"], g["grads"])
+        assert r2["stats"]["segments"] == int(g["segments"]) and r2["stats"]["zero_dir_segments"] == 0
+
+
+def test_libc_stream_known_answers(pkg, oracle):
+    """numbers probed independently from the reference with its own unseeded
+    rand() stream (64x64x8, -b 4 -p 1)."""
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(64, 64)
+    rp = pkg.RenderParams(spp=8, min_bounces=4, absorb=1.0, seed=1)
+    r = oracle.render(scene, cam, rp, backward=True, rng_mode=oracle.RNG_LIBC, faithful=True)
+    n = 64 * 64 * 8
+    np.testing.assert_allclose(r["image"].mean((0, 1)), [0.0486831665, 0.0464318928, 0.0438766479], rtol=2e-8)
+    np.testing.assert_allclose(r["grads"][0] / n, [0.00989532471, 0.0100936127, 0.00933074951], rtol=2e-8)
+    np.testing.assert_allclose(r["grads"][1] / n, [0.00573303223, 0.00527392731, 0.004947052], rtol=2e-8)
+    np.testing.assert_allclose(r["grads"][2] / n, [0.0358352661, 0.0335923927, 0.0291137695], rtol=2e-8)
+    np.testing.assert_allclose(r["grads"][3] / n, r["image"].mean((0, 1)), rtol=1e-12)
+
+
+def test_config1_full_image(pkg, oracle):
+    g = load_golden("c1_cornell_256x256x8_d4")
+    scene, cam, rp, _ = case_inputs(pkg, g["case"])
+    r = oracle.render(scene, cam, rp, backward=True)
+    np.testing.assert_array_equal(r["image"].astype(np.float32), g["image"])
+    np.testing.assert_array_equal(r["grads"], g["grads"])
+    assert r["stats"]["segments"] == int(g["segments"])
+
+
+def test_config3_rows_of_the_full_size_frame(pkg, oracle):
+    """Config 2/3 (512x512x64, depth 8) took the reference 116 s; the restatement re-renders one
+    16-row band of it (shard 5 of 32) and must reproduce the reference's row means exactly."""
+    g = load_golden("c3_cornell_512x512x64_d8")
+    scene, cam, rp, _ = case_inputs(pkg, g["case"])
+    import dataclasses
+    rps = dataclasses.replace(rp, shard=5, n_shards=32, band_rows=16)
+    r = oracle.render(scene, cam, rps, backward=False)
+    rows = pkg.shard_rows(512, 16, 32, 5)
+    np.testing.assert_array_equal(r["image"][rows].mean(1), g["row_mean"][rows])
+
+
+@pytest.mark.skipif("not __import__('os').path.exists('/root/reference/include/drt')")
+def test_oracle_vs_live_reference_on_fresh_random_scenes(pkg, oracle):
+    """Where the reference is present (build container), run it live on scenes that are in no
+    fixture: the restatement must still be bit-identical."""
+    oracle.build()
+    for seed in (101, 202):
+        scene = pkg.random_scene(seed)
+        cam = pkg.Camera(24, 18).look_at((0, 0.2, -0.1), (0.1, 0, 1))
+        rp = pkg.RenderParams(spp=3, min_bounces=1, absorb=0.3, seed=seed)
+        a = oracle.render(scene, cam, rp, backward=True, faithful=True)
+        b = oracle.render_reference(scene, cam, rp, backward=True)
+        np.testing.assert_array_equal(a["image"], b["image"])
+        np.testing.assert_array_equal(a["grads"], b["grads"])
+        assert a["stats"]["segments"] == b["stats"]["segments"]

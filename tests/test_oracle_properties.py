@@ -1,0 +1,101 @@
+"""Size-independent properties of the path, checked on the oracle: they are the
+same properties the gpu tests check on the device at full size."""
+import dataclasses
+
+import numpy as np
+
+
+def test_linearity_in_emission(pkg, oracle):
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(48, 48)
+    rp = pkg.RenderParams(spp=6, min_bounces=1, absorb=0.4, seed=3)
+    r = oracle.render(scene, cam, rp, backward=True)
+    total = r["image"].sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(r["grads"][3] * np.array(scene.params[3]), total, rtol=1e-12)
+
+
+def test_central_differences_match_reverse_mode(pkg, oracle):
+    """Sampling never depends on albedo/emission values, so with the keyed RNG a central
+    difference of the render is exact up to rounding and the cubic term."""
+    cam = pkg.cornell_camera(32, 32)
+    rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=2)
+    base = pkg.cornell_box()
+    g = oracle.render(base, cam, rp, backward=True)["grads"]
+    h = 1e-4
+    for p, c in [(0, 0), (1, 1), (2, 2), (3, 0)]:
+        vals = []
+        for sgn in (1, -1):
+            s = pkg.cornell_box()
+            q = list(s.params[p]); q[c] += sgn * h; s.params[p] = tuple(q)
+            vals.append(oracle.render(s, cam, rp)["image"].sum((0, 1))[c] * rp.spp)
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - g[p, c]) <= 1e-6 * abs(g[p, c])
+
+
+def test_adjoint_image_is_linear(pkg, oracle):
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(24, 16)
+    rp = pkg.RenderParams(spp=4, min_bounces=2, absorb=0.3, seed=5)
+    rs = np.random.RandomState(0)
+    a1 = rs.uniform(0, 1, (16, 24, 3)).astype(np.float32)
+    a2 = rs.uniform(0, 1, (16, 24, 3)).astype(np.float32)
+    g1 = oracle.render(scene, cam, rp, backward=True, adjoint=a1)["grads"]
+    g2 = oracle.render(scene, cam, rp, backward=True, adjoint=a2)["grads"]
+    g12 = oracle.render(scene, cam, rp, backward=True, adjoint=(a1 + a2))["grads"]
+    np.testing.assert_allclose(g1 + g2, g12, rtol=1e-6)
+    ones = oracle.render(scene, cam, rp, backward=True, adjoint=np.ones((16, 24, 3), np.float32))["grads"]
+    np.testing.assert_array_equal(ones, oracle.render(scene, cam, rp, backward=True)["grads"])
+
+
+def test_shards_tile_the_frame(pkg, oracle):
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(40, 37)
+    rp = pkg.RenderParams(spp=3, min_bounces=2, absorb=0.5, seed=8, band_rows=4)
+    full = oracle.render(scene, cam, rp, backward=True)
+    img = np.zeros_like(full["image"]); g = np.zeros_like(full["grads"]); seg = 0
+    for s in range(3):
+        r = oracle.render(scene, cam, dataclasses.replace(rp, shard=s, n_shards=3), backward=True)
+        rows = pkg.shard_rows(37, 4, 3, s)
+        img[rows] = r["image"][rows]; g += r["grads"]; seg += r["stats"]["segments"]
+    np.testing.assert_array_equal(img, full["image"])
+    np.testing.assert_allclose(g, full["grads"], rtol=1e-12)
+    assert seg == full["stats"]["segments"]
+
+
+def test_rng_is_uniform_and_decorrelated(oracle):
+    """drt_rng_u31 replaces libc rand(): 31-bit, uniform, no visible correlation between
+    neighbouring paths or consecutive draws."""
+    n = 20000
+    u = np.array([[oracle.rng_u31(1, p, d) for d in range(4)] for p in range(n)], dtype=np.float64) / 2147483647.0
+    assert u.min() >= 0 and u.max() <= 1
+    assert abs(u.mean() - 0.5) < 0.005 and abs(u.var() - 1 / 12) < 0.002
+    for d in range(4):
+        hist = np.histogram(u[:, d], bins=16, range=(0, 1))[0]
+        chi2 = ((hist - n / 16) ** 2 / (n / 16)).sum()
+        assert chi2 < 45            # 15 dof, p ~ 1e-4
+    assert abs(np.corrcoef(u[:-1, 0], u[1:, 0])[0, 1]) < 0.03      # path p vs p+1
+    assert abs(np.corrcoef(u[:, 0], u[:, 1])[0, 1]) < 0.03          # draw n vs n+1
+    assert abs(np.corrcoef(u[:, 1], u[:, 2])[0, 1]) < 0.03
+    # different seeds give different streams; 64-bit path ids are honoured
+    assert oracle.rng_u31(1, 5, 0) != oracle.rng_u31(2, 5, 0)
+    assert oracle.rng_u31(1, 5, 0) != oracle.rng_u31(1, 5 + (1 << 32), 0)
+
+
+def test_keyed_and_libc_streams_agree_statistically(pkg, oracle):
+    """Two sample sets of the same estimator: means agree within Monte-Carlo noise."""
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(64, 64)
+    rp = pkg.RenderParams(spp=8, min_bounces=4, absorb=1.0, seed=1)
+    a = oracle.render(scene, cam, rp)["image"].mean((0, 1))
+    b = oracle.render(scene, cam, rp, rng_mode=oracle.RNG_LIBC, faithful=True)["image"].mean((0, 1))
+    np.testing.assert_allclose(a, b, rtol=0.05)
+
+
+def test_max_depth_cap_equals_absorb_one(pkg, oracle):
+    """The depth cap (ABI extension) truncates exactly like `-b D -p 1` when roulette is off."""
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(20, 20)
+    a = oracle.render(scene, cam, pkg.RenderParams(spp=4, min_bounces=5, absorb=1.0, seed=4), backward=True)
+    b = oracle.render(scene, cam, pkg.RenderParams(spp=4, min_bounces=99, absorb=0.5, max_depth=5, seed=4), backward=True)
+    np.testing.assert_array_equal(a["image"], b["image"])
+    np.testing.assert_array_equal(a["grads"], b["grads"])
