@@ -1,0 +1,29 @@
+# Top-level build: the HIP library (gfx950), the checker, and the C++ host application.
+#   make            everything
+#   make lib        differentiable-renderer_amd/libdrt_hip.so   (hipcc --offload-arch=gfx950)
+#   make host       build/render   (src/render_hip.cpp against include/drt + libdrt_hip.so)
+#   make oracle     oracle/libdrt_oracle.so (+ oracle/_ref where /root/reference exists)
+PKG := differentiable-renderer_amd
+LIB := $(PKG)/libdrt_hip.so
+CXX ?= g++
+HIPCC ?= hipcc
+
+all: lib oracle host
+
+lib: $(LIB)
+$(LIB): $(PKG)/csrc/drt_hip.hip $(PKG)/csrc/drt_kernels.h $(PKG)/csrc/drt_device.h include/drt_hip.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -o $@ $(PKG)/csrc/drt_hip.hip
+
+oracle:
+	$(MAKE) -C oracle libdrt_oracle.so ref
+
+host: build/render
+build/render: src/render_hip.cpp src/args.hpp src/write.hpp $(wildcard include/drt/*.hpp) include/drt_hip.h $(LIB)
+	mkdir -p build
+	$(CXX) -O3 -std=c++17 -Iinclude -Isrc -o $@ src/render_hip.cpp -L$(PKG) -ldrt_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lpthread
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle host clean

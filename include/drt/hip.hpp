@@ -1,0 +1,262 @@
+// drt/hip.hpp -- host glue above the C ABI (include/drt_hip.h): the batched, device-side
+// replacement of the reference's pixel x sample loop (src/render.cpp:72-86).
+//
+//   drt::hip::render(scene, cam, tracer, spp, img [, options [, adjoint]])
+//
+// walks a drt::Scene<T> through the additive describe()/kind()/parameter() hooks, deduplicates the
+// scene parameters by tape-node identity (handles share nodes: `white` feeds two materials in
+// render.cpp:28,34-35), uploads the POD scene, renders on one or several MI355X devices and, when
+// options.backward is set, ADDS the returned gradients into param.grad() -- the accumulate
+// semantics of VariableNode::backward (vector.hpp:185-188).
+//
+// No CPU fallback: if libdrt_hip.so cannot create a context this throws std::runtime_error.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../drt_hip.h"
+#include "camera.hpp"
+#include "pathtracer.hpp"
+
+namespace drt { namespace hip {
+
+struct Options {
+    bool backward = false;          // also back-propagate (render.cpp:80, commented out there)
+    uint32_t seed = 1;
+    int max_depth = 0;              // 0 = library default (64)
+    std::vector<int> devices = {0}; // pixel-row bands are dealt round-robin to these devices
+    int band_rows = 16;
+    bool f64 = false;               // verification mode: compute in double on the device
+    long long batch_paths = 0;
+};
+
+struct Stats {
+    unsigned long long paths = 0, segments = 0;
+    double ms = 0;
+};
+
+template <typename T>
+struct FlatScene {
+    std::vector<drt_shape_desc> shapes;
+    std::vector<drt_material_desc> materials;
+    std::vector<drt_emitter_desc> emitters;
+    std::vector<double> params;
+    std::vector<uint8_t> requires_grad;
+    std::vector<Vector<T, 3, true>> handles;   // one per parameter, sharing the user's nodes
+
+    drt_scene_desc desc() const
+    {
+        drt_scene_desc d;
+        d.n_shapes = (int32_t)shapes.size();
+        d.n_materials = (int32_t)materials.size();
+        d.n_emitters = (int32_t)emitters.size();
+        d.n_params = (int32_t)requires_grad.size();
+        d.shapes = shapes.data();
+        d.materials = materials.data();
+        d.emitters = emitters.data();
+        d.params = params.data();
+        d.requires_grad = requires_grad.data();
+        return d;
+    }
+};
+
+template <typename T>
+inline FlatScene<T> flatten(const Scene<T>& scene)
+{
+    FlatScene<T> f;
+    std::map<const void*, int> param_of, material_of, emitter_of;
+    auto param_index = [&](const Vector<T, 3, true>& h) {
+        auto it = param_of.find(h.id());
+        if (it != param_of.end())
+            return it->second;
+        const int idx = (int)f.handles.size();
+        param_of[h.id()] = idx;
+        f.handles.push_back(h);
+        for (int c = 0; c < 3; ++c)
+            f.params.push_back(double(h[c]));
+        f.requires_grad.push_back(h.requires_grad() ? 1 : 0);
+        return idx;
+    };
+    for (Shape<T>* shape : scene) {
+        const ShapeRecord rec = shape->describe();
+        drt_shape_desc sd{};
+        if (rec.kind == ShapeKind::Plane)
+            sd.type = DRT_SHAPE_PLANE;
+        else if (rec.kind == ShapeKind::Sphere)
+            sd.type = DRT_SHAPE_SPHERE;
+        else
+            throw std::runtime_error("drt::hip: shape type has no device record (describe() not implemented)");
+        for (int i = 0; i < 4; ++i)
+            sd.p[i] = rec.p[i];
+        sd.material = -1;
+        sd.emitter = -1;
+        if (BxDF<T>* b = shape->bxdf()) {
+            auto it = material_of.find(b);
+            if (it == material_of.end()) {
+                drt_material_desc md{};
+                if (b->kind() == BxDFKind::Diffuse)
+                    md.type = DRT_BXDF_DIFFUSE;
+                else if (b->kind() == BxDFKind::Specular)
+                    md.type = DRT_BXDF_SPECULAR;
+                else
+                    throw std::runtime_error("drt::hip: BxDF type has no device record");
+                md.param = param_index(*b->parameter());
+                md.exponent = b->exponent();
+                it = material_of.emplace(b, (int)f.materials.size()).first;
+                f.materials.push_back(md);
+            }
+            sd.material = it->second;
+        }
+        if (Emitter<T>* e = shape->emitter()) {
+            auto it = emitter_of.find(e);
+            if (it == emitter_of.end()) {
+                auto* area = dynamic_cast<AreaEmitter<T>*>(e);
+                if (!area)
+                    throw std::runtime_error("drt::hip: emitter type has no device record");
+                drt_emitter_desc ed{};
+                ed.param = param_index(area->parameter());
+                it = emitter_of.emplace(e, (int)f.emitters.size()).first;
+                f.emitters.push_back(ed);
+            }
+            sd.emitter = it->second;
+        }
+        f.shapes.push_back(sd);
+    }
+    return f;
+}
+
+template <typename T>
+inline drt_camera_desc describe(const Camera<T>& cam)
+{
+    drt_camera_desc c{};
+    c.width = (int32_t)cam.width();
+    c.height = (int32_t)cam.height();
+    c.vfov = cam.vfov();
+    for (int i = 0; i < 3; ++i) {
+        c.eye[i] = double(cam.eye()[i]);
+        c.forward[i] = double(cam.forward()[i]);
+        c.right[i] = double(cam.right()[i]);
+        c.up[i] = double(cam.up()[i]);
+    }
+    return c;
+}
+
+class Context {
+public:
+    explicit Context(int device)
+    {
+        const int rc = drt_hip_create(device, &m_ctx);
+        if (rc != DRT_OK)
+            throw std::runtime_error("drt_hip_create(device " + std::to_string(device) + ") failed with status " +
+                                     std::to_string(rc) + " (no HIP device? there is no CPU fallback)");
+    }
+    ~Context() { drt_hip_destroy(m_ctx); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    drt_hip_ctx* get() const { return m_ctx; }
+    void check(int rc, const char* what) const
+    {
+        if (rc != DRT_OK)
+            throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + drt_hip_last_error(m_ctx));
+    }
+
+private:
+    drt_hip_ctx* m_ctx = nullptr;
+};
+
+// img: width*height row-major (render.cpp:66,82); adjoint: optional per-pixel seed, same layout.
+template <typename T>
+inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtracer<T>& tracer, std::size_t spp,
+                    Vector<T, 3>* img, const Options& opt = Options(), const Vector<T, 3>* adjoint = nullptr)
+{
+    FlatScene<T> flat = flatten(scene);
+    const drt_scene_desc sd = flat.desc();
+    const drt_camera_desc cd = describe(cam);
+    const std::size_t npix = cam.width() * cam.height();
+    const int n_dev = (int)opt.devices.size();
+    if (n_dev < 1)
+        throw std::runtime_error("drt::hip::render: no device given");
+
+    std::vector<float> adj;
+    if (adjoint) {
+        adj.resize(npix * 3);
+        for (std::size_t i = 0; i < npix; ++i)
+            for (int c = 0; c < 3; ++c)
+                adj[i * 3 + c] = float(adjoint[i][c]);
+    }
+    const std::size_t P = flat.requires_grad.size();
+    std::vector<std::vector<float>> frames(n_dev, std::vector<float>(npix * 3, 0.f));
+    std::vector<std::vector<double>> grads(n_dev, std::vector<double>(P * 3, 0.0));
+    std::vector<drt_hip_stats> stats(n_dev);
+    std::vector<std::string> errors(n_dev);
+
+    auto work = [&](int d) {
+        try {
+            Context ctx(opt.devices[d]);
+            ctx.check(drt_hip_upload_scene(ctx.get(), &sd), "drt_hip_upload_scene");
+            drt_render_params rp{};
+            rp.spp = (int32_t)spp;
+            rp.min_bounces = (int32_t)tracer.min_bounces();
+            rp.absorb = tracer.absorb();
+            rp.max_depth = opt.max_depth;
+            rp.seed = opt.seed;
+            rp.shard = d;
+            rp.n_shards = n_dev;
+            rp.band_rows = opt.band_rows;
+            rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u);
+            rp.batch_paths = opt.batch_paths;
+            ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, frames[d].data(),
+                                     opt.backward ? grads[d].data() : nullptr, &stats[d]),
+                      "drt_hip_render");
+        } catch (const std::exception& e) {
+            errors[d] = e.what();
+        }
+    };
+    if (n_dev == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int d = 0; d < n_dev; ++d)
+            pool.emplace_back(work, d);
+        for (auto& t : pool)
+            t.join();
+    }
+    for (const std::string& e : errors)
+        if (!e.empty())
+            throw std::runtime_error(e);
+
+    // disjoint rows: every device left the other shards' rows at zero
+    Stats total;
+    for (std::size_t i = 0; i < npix; ++i)
+        for (int c = 0; c < 3; ++c) {
+            float v = 0.f;
+            for (int d = 0; d < n_dev; ++d)
+                v += frames[d][i * 3 + c];
+            img[i][c] = T(v);
+        }
+    for (int d = 0; d < n_dev; ++d) {
+        total.paths += stats[d].paths;
+        total.segments += stats[d].segments;
+        if (stats[d].ms_total > total.ms)
+            total.ms = stats[d].ms_total;
+    }
+    if (opt.backward) {
+        for (std::size_t p = 0; p < P; ++p) {
+            if (!flat.requires_grad[p])
+                continue;
+            Vector<T, 3> g(T(0));
+            for (int d = 0; d < n_dev; ++d)
+                for (int c = 0; c < 3; ++c)
+                    g[c] += T(grads[d][p * 3 + c]);
+            flat.handles[p].grad() += g;          // accumulate, like m_grad += grad
+        }
+    }
+    return total;
+}
+
+} } // namespace drt::hip

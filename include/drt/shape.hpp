@@ -1,0 +1,117 @@
+// drt/shape.hpp -- Shape<T> plugin interface with the analytic Plane and Sphere of the reference
+// (include/drt/shape.hpp: interface :11-35, Plane :37-64, Sphere :66-111).  Same signatures and
+// the same predicates (hit iff t > 0; plane normal used un-normalised; sphere assumes a unit
+// direction and never flips its normal).
+// Additive: ShapeKind / describe() expose the private fields so a scene can be flattened.
+#pragma once
+
+#include <cmath>
+#include <memory>
+
+#include "bxdf.hpp"
+#include "constants.hpp"
+#include "emitter.hpp"
+#include "vector.hpp"
+
+namespace drt {
+
+enum class ShapeKind { Plane, Sphere, Other };
+
+struct ShapeRecord {
+    ShapeKind kind = ShapeKind::Other;
+    double p[4] = {0, 0, 0, 0};   // Plane: normal.xyz, offset   Sphere: center.xyz, radius
+};
+
+template <typename T>
+class Shape {
+public:
+    Shape(std::shared_ptr<BxDF<T>> bxdf = nullptr, std::shared_ptr<Emitter<T>> emitter = nullptr)
+      : m_material(std::move(bxdf)), m_light(std::move(emitter)) { }
+    virtual ~Shape() = default;
+
+    virtual bool intersect(Vector<T, 3> orig, Vector<T, 3> dir, double& t) const = 0;
+    virtual Vector<T, 3> normal(Vector<T, 3> point) const = 0;
+    virtual ShapeRecord describe() const { return ShapeRecord(); }   // additive
+
+    BxDF<T>* bxdf() { return m_material.get(); }
+    Emitter<T>* emitter() { return m_light.get(); }
+
+private:
+    std::shared_ptr<BxDF<T>> m_material;
+    std::shared_ptr<Emitter<T>> m_light;
+};
+
+template <typename T>
+class Plane : public Shape<T> {
+public:
+    Plane(Vector<T, 3> normal, double offset, std::shared_ptr<BxDF<T>> bxdf = nullptr,
+          std::shared_ptr<Emitter<T>> emitter = nullptr)
+      : Shape<T>(bxdf, emitter), m_n(normal), m_d(offset) { }
+
+    bool intersect(Vector<T, 3> orig, Vector<T, 3> dir, double& t) const override
+    {
+        const double height = dot(orig, m_n) - m_d;
+        t = height / dot(dir, -m_n);
+        return t > 0;
+    }
+
+    Vector<T, 3> normal(Vector<T, 3>) const override { return m_n; }
+
+    ShapeRecord describe() const override
+    {
+        ShapeRecord r;
+        r.kind = ShapeKind::Plane;
+        r.p[0] = double(m_n[0]); r.p[1] = double(m_n[1]); r.p[2] = double(m_n[2]); r.p[3] = m_d;
+        return r;
+    }
+
+private:
+    Vector<T, 3> m_n;
+    double m_d;
+};
+
+template <typename T>
+class Sphere : public Shape<T> {
+public:
+    Sphere(Vector<T, 3> center, double radius, std::shared_ptr<BxDF<T>> bxdf = nullptr,
+           std::shared_ptr<Emitter<T>> emitter = nullptr)
+      : Shape<T>(bxdf, emitter), m_c(center), m_r(radius) { }
+
+    bool intersect(Vector<T, 3> orig, Vector<T, 3> dir, double& t) const override
+    {
+        orig -= m_c;
+        const double a = 1;                       // unit direction assumed
+        const double b = 2 * dot(orig, dir);
+        const double c = dot(orig, orig) - m_r * m_r;
+        const double disc = b * b - 4 * a * c;
+        if (disc < 0)
+            return false;
+        const double near = (-b - std::sqrt(disc)) / (2 * a);
+        const double far = (-b + std::sqrt(disc)) / (2 * a);
+        if (near > 0 && far > 0)
+            t = std::min(near, far);
+        else if (near > 0)
+            t = near;
+        else if (far > 0)
+            t = far;
+        else
+            return false;
+        return true;
+    }
+
+    Vector<T, 3> normal(Vector<T, 3> point) const override { return normalize(point - m_c); }
+
+    ShapeRecord describe() const override
+    {
+        ShapeRecord r;
+        r.kind = ShapeKind::Sphere;
+        r.p[0] = double(m_c[0]); r.p[1] = double(m_c[1]); r.p[2] = double(m_c[2]); r.p[3] = m_r;
+        return r;
+    }
+
+private:
+    Vector<T, 3> m_c;
+    double m_r;
+};
+
+} // namespace drt

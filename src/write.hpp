@@ -1,0 +1,124 @@
+// write.hpp -- drt::write_exr(fname, data, width, height): same signature and pixel semantics as
+// the reference's src/write.hpp:9-26 (RGBA, 16-bit half, alpha 1, increasing-Y scan lines), but
+// self-contained: OpenEXR (branch RB-2.5 in the reference's .gitmodules) is not available here, so
+// this writes the OpenEXR 2 single-part scan-line container itself, uncompressed.  Pixel parity
+// with Imf::RgbaOutputFile, not byte parity (the reference's default is PIZ compression).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "drt/vector.hpp"
+
+namespace drt {
+
+// IEEE binary32 -> binary16, round to nearest even, overflow to infinity, NaN stays NaN
+inline uint16_t float_to_half(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t mag = x & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u)                                   // inf / nan
+        return (uint16_t)(sign | 0x7C00u | (mag > 0x7F800000u ? 0x0200u | ((mag >> 13) & 0x03FFu) : 0u));
+    if (mag >= 0x477FF000u)                                   // rounds to >= 65520 -> inf
+        return (uint16_t)(sign | 0x7C00u);
+    if (mag < 0x38800000u) {                                  // subnormal half or zero
+        if (mag < 0x33000000u)                                // < 2^-25 -> 0
+            return (uint16_t)sign;
+        const int shift = 126 - (int)(mag >> 23);             // 14..24
+        const uint32_t mant = (mag & 0x007FFFFFu) | 0x00800000u;
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1u)))
+            ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((mag - 0x38000000u) >> 13);                 // rebias exponent 127 -> 15
+    const uint32_t rem = mag & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u)))
+        ++h;                                                  // may carry into the exponent: correct
+    return (uint16_t)(sign | h);
+}
+
+namespace exr_detail {
+inline void put(std::vector<unsigned char>& b, const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; b.insert(b.end(), c, c + n); }
+inline void put_str(std::vector<unsigned char>& b, const char* s) { put(b, s, std::strlen(s) + 1); }
+inline void put_i32(std::vector<unsigned char>& b, int32_t v) { put(b, &v, 4); }
+inline void put_f32(std::vector<unsigned char>& b, float v) { put(b, &v, 4); }
+inline void attr(std::vector<unsigned char>& b, const char* name, const char* type, const std::vector<unsigned char>& value)
+{
+    put_str(b, name);
+    put_str(b, type);
+    put_i32(b, (int32_t)value.size());
+    put(b, value.data(), value.size());
+}
+} // namespace exr_detail
+
+template <typename T>
+inline void write_exr(const char* fname, const Vector<T, 3>* data, std::size_t width, std::size_t height)
+{
+    using namespace exr_detail;
+    std::vector<unsigned char> head;
+    const uint32_t magic = 20000630u, version = 2u;
+    put(head, &magic, 4);
+    put(head, &version, 4);
+    {   // channels, alphabetical: A B G R, HALF (pixel type 1), linear 0, sampling 1 1
+        std::vector<unsigned char> v;
+        for (const char* ch : {"A", "B", "G", "R"}) {
+            put_str(v, ch);
+            put_i32(v, 1);
+            const unsigned char plinear[4] = {0, 0, 0, 0};
+            put(v, plinear, 4);
+            put_i32(v, 1);
+            put_i32(v, 1);
+        }
+        v.push_back(0);
+        attr(head, "channels", "chlist", v);
+    }
+    { std::vector<unsigned char> v(1, 0); attr(head, "compression", "compression", v); }   // NO_COMPRESSION
+    {
+        std::vector<unsigned char> v;
+        put_i32(v, 0); put_i32(v, 0); put_i32(v, (int32_t)width - 1); put_i32(v, (int32_t)height - 1);
+        attr(head, "dataWindow", "box2i", v);
+        attr(head, "displayWindow", "box2i", v);
+    }
+    { std::vector<unsigned char> v(1, 0); attr(head, "lineOrder", "lineOrder", v); }        // INCREASING_Y
+    { std::vector<unsigned char> v; put_f32(v, 1.f); attr(head, "pixelAspectRatio", "float", v); }
+    { std::vector<unsigned char> v; put_f32(v, 0.f); put_f32(v, 0.f); attr(head, "screenWindowCenter", "v2f", v); }
+    { std::vector<unsigned char> v; put_f32(v, 1.f); attr(head, "screenWindowWidth", "float", v); }
+    head.push_back(0);
+
+    const size_t line_bytes = width * 4 * 2;
+    const uint64_t first = head.size() + 8ull * height;
+    std::FILE* f = std::fopen(fname, "wb");
+    if (!f)
+        throw std::runtime_error(std::string("write_exr: cannot open ") + fname);
+    std::fwrite(head.data(), 1, head.size(), f);
+    for (size_t y = 0; y < height; ++y) {
+        const uint64_t off = first + y * (8 + line_bytes);
+        std::fwrite(&off, 8, 1, f);
+    }
+    std::vector<uint16_t> line(width * 4);
+    const uint16_t one = float_to_half(1.f);
+    for (size_t y = 0; y < height; ++y) {
+        for (size_t x = 0; x < width; ++x) {
+            const Vector<T, 3>& rgb = data[y * width + x];
+            line[0 * width + x] = one;                                   // A
+            line[1 * width + x] = float_to_half((float)double(rgb[2]));  // B
+            line[2 * width + x] = float_to_half((float)double(rgb[1]));  // G
+            line[3 * width + x] = float_to_half((float)double(rgb[0]));  // R
+        }
+        const int32_t yy = (int32_t)y, size = (int32_t)line_bytes;
+        std::fwrite(&yy, 4, 1, f);
+        std::fwrite(&size, 4, 1, f);
+        std::fwrite(line.data(), 1, line_bytes, f);
+    }
+    std::fclose(f);
+}
+
+} // namespace drt
