@@ -146,13 +146,15 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dominant)
+            tj = json.load(open(tpath)).get(dominant)
+            traffic = tj.get("GBs") if tj else None
         except Exception:
             traffic = None
     dk = per_kernel.get(dominant, {"achieved_GBs": 0.0, "launches_per_step": 1, "ms_per_step": 0.0})
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": dk["achieved_GBs"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json) over the profiled launch time" if traffic else None,
                 "avg_launch_ms": round(dk["ms_per_step"] / max(1, dk["launches_per_step"]), 4),
                 "traversal_kernel": per_kernel.get("intersect"), "kernels": per_kernel}
 

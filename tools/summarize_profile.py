@@ -74,3 +74,15 @@ for k, v in summary.items():
         traffic[k] = {"fetch_raw_B": f, "fetch_corrected_B": 2 * f, "write_B": w, "total_corrected_B": 2 * f + w}
         print(f"{k:28s} fetch_raw={f/1e6:9.2f} MB  fetch_x2={2*f/1e6:9.2f} MB  write={w/1e6:9.2f} MB  total={(2*f+w)/1e6:9.2f} MB")
 json.dump({"kernels": summary, "traffic": traffic}, open(os.path.join(out, "summary.json"), "w"), indent=1)
+# bench.py's "traffic" field: PMC bytes per launch / traced average launch time, per kernel
+names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_shade<bwd>": "shade", "k_shade<fwd>": "shade_fwd",
+         "k_film": "film", "k_backward": "backward", "k_gradreduce": "gradreduce"}
+tj = {}
+for k, t in traffic.items():
+    if k in names and "avg_us" in summary.get(k, {}):
+        us = summary[k]["avg_us"]
+        tj[names[k]] = {"GBs": round(t["total_corrected_B"] / (us * 1e-6) * 1e-9, 1),
+                        "bytes_per_launch": round(t["total_corrected_B"]), "fetch_raw_bytes": round(t["fetch_raw_B"]),
+                        "write_bytes": round(t["write_B"]), "avg_launch_us": round(us, 2),
+                        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)"}
+json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
