@@ -33,6 +33,7 @@ struct drt_hip_ctx {
     std::string err;
 
     bool has_scene = false;
+    bool has_specular = false;
     int n_params = 0, n_shapes = 0;
     std::vector<uint8_t> requires_grad;
     std::vector<drt_material_desc> materials;
@@ -303,16 +304,23 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 
                 TapeRec<R>* tape_k = backward ? tape + (size_t)k * a.n_paths : nullptr;
                 if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
-                if (backward)
-                    hipLaunchKernelGGL((k_shade<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
-                                       d_scene, d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt],
-                                       rb[nxt], rid[nxt], rcq[nxt], tape_k, nv, lacc, counts + (size_t)k * max_regions,
-                                       counts + (size_t)(k + 1) * max_regions);
-                else
-                    hipLaunchKernelGGL((k_shade<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, k,
-                                       d_scene, d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt],
-                                       rb[nxt], rid[nxt], rcq[nxt], tape_k, nv, lacc, counts + (size_t)k * max_regions,
-                                       counts + (size_t)(k + 1) * max_regions);
+                {
+                    int gs = g;                                // one wave per region, or persistent
+                    static const int shade_bpc = getenv("DRT_HIP_SHADE_BLOCKS_PER_CU") ? atoi(getenv("DRT_HIP_SHADE_BLOCKS_PER_CU")) : 0;
+                    if (shade_bpc > 0 && ctx->n_cu * shade_bpc < g)
+                        gs = ctx->n_cu * shade_bpc;
+                    const uint32_t* ck = counts + (size_t)k * max_regions;
+                    uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
+#define DRT_LAUNCH_SHADE(BWD, SPEC)                                                                       \
+    hipLaunchKernelGGL((k_shade<R, BWD, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene, \
+                       d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt], rb[nxt], rid[nxt],   \
+                       rcq[nxt], tape_k, nv, lacc, ck, cn)
+                    if (backward && ctx->has_specular) DRT_LAUNCH_SHADE(true, true);
+                    else if (backward) DRT_LAUNCH_SHADE(true, false);
+                    else if (ctx->has_specular) DRT_LAUNCH_SHADE(false, true);
+                    else DRT_LAUNCH_SHADE(false, false);
+#undef DRT_LAUNCH_SHADE
+                }
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_SHADE]++;
             }
@@ -329,8 +337,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             }
             if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_backward<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                   d_params, tape, nv, d_adjoint, gpart, grad);
+#define DRT_LAUNCH_BWD(NP)                                                                              \
+    hipLaunchKernelGGL((k_backward<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params, \
+                       tape, nv, d_adjoint, gpart, grad)
+                if (ctx->n_params <= 4) DRT_LAUNCH_BWD(4);
+                else if (ctx->n_params <= 8) DRT_LAUNCH_BWD(8);
+                else DRT_LAUNCH_BWD(0);
+#undef DRT_LAUNCH_BWD
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_BACKWARD]++;
                 if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
@@ -479,6 +492,10 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     if (s->requires_grad)
         for (int i = 0; i < s->n_params; ++i)
             ctx->requires_grad[i] = s->requires_grad[i] ? 1 : 0;
+    ctx->has_specular = false;
+    for (int i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].type == DRT_BXDF_SPECULAR)
+            ctx->has_specular = true;
     ctx->has_scene = true;
     return DRT_OK;
 }

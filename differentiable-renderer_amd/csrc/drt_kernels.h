@@ -239,24 +239,39 @@ struct SceneLds {
     R params[DRT_LDS_PARAMS * 3];
 };
 
+// Copy the USED part of the scene (header, n_shapes shapes, n_materials materials, n_emitters
+// emitter ids, up to DRT_LDS_PARAMS parameters) into LDS: ~0.5 KB for the Cornell box.
 template <typename R>
 __device__ inline void stage_scene(SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
                                    const R* __restrict__ params)
 {
-    const int* src = reinterpret_cast<const int*>(sc);
-    int* dst = reinterpret_cast<int*>(&lds.sc);
-    for (int i = threadIdx.x; i < (int)(sizeof(DevScene<R>) / sizeof(int)); i += blockDim.x)
-        dst[i] = src[i];
+    const int ns = sc->n_shapes, nm = sc->n_materials, ne = sc->n_emitters;
+    if (threadIdx.x < 4)
+        reinterpret_cast<int*>(&lds.sc)[threadIdx.x] = reinterpret_cast<const int*>(sc)[threadIdx.x];
+    {
+        const int* src = reinterpret_cast<const int*>(sc->shapes);
+        int* dst = reinterpret_cast<int*>(lds.sc.shapes);
+        for (int i = threadIdx.x; i < ns * (int)(sizeof(DevShape<R>) / sizeof(int)); i += blockDim.x)
+            dst[i] = src[i];
+    }
+    {
+        const int* src = reinterpret_cast<const int*>(sc->materials);
+        int* dst = reinterpret_cast<int*>(lds.sc.materials);
+        for (int i = threadIdx.x; i < nm * (int)(sizeof(DevMaterial<R>) / sizeof(int)); i += blockDim.x)
+            dst[i] = src[i];
+    }
+    for (int i = threadIdx.x; i < ne; i += blockDim.x)
+        lds.sc.emitter_param[i] = sc->emitter_param[i];
     const int np = sc->n_params < DRT_LDS_PARAMS ? sc->n_params : DRT_LDS_PARAMS;
     for (int i = threadIdx.x; i < np * 3; i += blockDim.x)
         lds.params[i] = params[i];
     __syncthreads();
 }
 
-template <typename R>
+template <typename R, bool ALL_LDS = false>
 __device__ inline V3<R> load_param(const SceneLds<R>& lds, const R* __restrict__ params, int id)
 {
-    if (id < DRT_LDS_PARAMS)
+    if (ALL_LDS || id < DRT_LDS_PARAMS)
         return mk<R>(lds.params[id * 3], lds.params[id * 3 + 1], lds.params[id * 3 + 2]);
     return mk<R>(params[id * 3], params[id * 3 + 1], params[id * 3 + 2]);
 }
@@ -288,8 +303,26 @@ __device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, i
     }
 }
 
-template <typename R, bool BWD>
-__global__ void __launch_bounds__(DRT_BLOCK)
+// first region >= w (stepping by n_waves) that has live rays; its count in cnt
+__device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_k, uint32_t w, uint32_t n_waves,
+                                            uint32_t n_regions, uint32_t& cnt)
+{
+    cnt = 0;
+    while (w < n_regions) {
+        cnt = __builtin_amdgcn_readfirstlane(counts_k[w]);
+        if (cnt)
+            break;
+        w += n_waves;
+    }
+    return w;
+}
+
+// Persistent blocks; every wave walks the regions w, w + n_waves, ... it owns in this launch and
+// shades them chunk by chunk.  The loads of the NEXT chunk (same region or the next live one) are
+// issued before the current chunk is shaded, so a wave always has one chunk of loads in flight.
+// SPEC = false instantiations carry no specular code (and fewer registers) for all-diffuse scenes.
+template <typename R, bool BWD, bool SPEC>
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
         const uint2* __restrict__ ray_id,
@@ -304,28 +337,33 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
     __shared__ SceneLds<R> lds;
     stage_scene(lds, sc, params);
 
-    const uint32_t w = grid_wave();
-    if (w >= a.n_regions)
-        return;
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
-    const uint32_t begin = w << a.region_shift;
-    const uint32_t end = begin + __builtin_amdgcn_readfirstlane(counts_k[w]);
+    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
     const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
     const R inv_pk = R(1) / pk;
     const uint32_t n_theta = draw_index(k, a.min_bounces);
     const bool next_rr = (k + 1) >= a.min_bounces;
     const bool next_cap = (k + 1) >= a.depth_cap;
-    uint32_t running = 0;
 
-    // software pipeline: the loads of chunk i+1 are issued before chunk i is shaded
+    uint32_t cnt;
+    uint32_t w = next_live_region(counts_k, grid_wave(), n_waves, a.n_regions, cnt);
+    if (w >= a.n_regions)
+        return;
+    uint32_t off = 0, running = 0;
     ShadeIn<R> cur, nxt;
-    bool have = begin + lane < end;
-    load_shade_in(cur, begin + lane, have, k, ray_a, ray_b, ray_id, ray_c, hit);
+    bool have = lane < cnt;
+    load_shade_in(cur, (w << a.region_shift) + lane, have, k, ray_a, ray_b, ray_id, ray_c, hit);
 
-    for (uint32_t off = begin; off < end; off += DRT_WAVE) {
-        const uint32_t nslot = off + DRT_WAVE + lane;
-        const bool nhave = nslot < end;
-        load_shade_in(nxt, nslot, nhave, k, ray_a, ray_b, ray_id, ray_c, hit);
+    for (;;) {
+        // where the next chunk is, and its loads
+        uint32_t nw = w, noff = off + DRT_WAVE, ncnt = cnt;
+        if (noff >= cnt) {
+            noff = 0;
+            nw = next_live_region(counts_k, w + n_waves, n_waves, a.n_regions, ncnt);
+        }
+        const bool more = nw < a.n_regions;
+        const bool nhave = more && noff + lane < ncnt;
+        load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, k, ray_a, ray_b, ray_id, ray_c, hit);
 
         bool alive = false;
         R4 na, nc;
@@ -378,7 +416,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     make_frame(nrm, tg, bt);
                     V3<R> wo;
                     R q, bs;
-                    if (m.type == DRT_BXDF_DIFFUSE) {
+                    if (!SPEC || m.type == DRT_BXDF_DIFFUSE) {
                         // bxdf.hpp:69-79: theta = asin(sqrt(u1)) => sin = sqrt(u1), cos = sqrt(1-u1);
                         // 1 - u1 comes from the exact integer RAND_MAX - r so cos (and the pdf)
                         // is never rounded to 0
@@ -426,7 +464,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
             }
         }
         uint32_t n_alive;
-        const uint32_t ns = begin + running + wave_rank(alive, n_alive);
+        const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
         if (alive) {
             next_a[ns] = na;
             next_b[ns] = nb;
@@ -434,11 +472,19 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
             next_c[ns] = nc;
         }
         running += n_alive;
+        if (nw != w) {                                         // region finished
+            if (lane == 0)
+                counts_next[w] = running;
+            running = 0;
+        }
+        if (!more)
+            break;
         cur = nxt;
         have = nhave;
+        w = nw;
+        off = noff;
+        cnt = ncnt;
     }
-    if (lane == 0)
-        counts_next[w] = running;
 }
 
 // segments of one batch = rays queued at depths 0..D-1, summed over regions -> 64-bit total
@@ -509,36 +555,80 @@ k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float
 // order => bitwise reproducible); other ids use fp64 atomics on the gradient vector.
 #define DRT_TAPE_CHUNK 8
 
-// Per-thread accumulator columns in LDS: acc[row = param * 3 + channel][thread].  A thread only
-// ever touches its own column (bank = thread % 32: conflict-free), so the LDS add needs no
-// ordering: a plain ds_read / v_add / ds_write (LDS float ATOMICS were measured 4x slower than
-// the whole rest of the kernel: they serialise per lane).
-template <typename R>
-__device__ inline void grad_accumulate(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
-{
-    if (id < DRT_FAST_PARAMS) {
-        acc[id * 3 + 0][threadIdx.x] += v.x;
-        acc[id * 3 + 1][threadIdx.x] += v.y;
-        acc[id * 3 + 2][threadIdx.x] += v.z;
-    } else {
-        atomicAdd(&grad[id * 3 + 0], (double)v.x);
-        atomicAdd(&grad[id * 3 + 1], (double)v.y);
-        atomicAdd(&grad[id * 3 + 2], (double)v.z);
+// Gradient accumulators of one thread.
+//   NP = 4 or 8 (the scene has at most NP parameters): NP x 3 registers, conditional adds with a
+//        compile-time parameter index -- no memory traffic, no waits, fixed order.
+//   NP = 0 (general): a column per thread in LDS, acc[row = param * 3 + channel][thread], for ids
+//        < DRT_FAST_PARAMS (bank = thread % 32: conflict-free; plain read/add/write -- LDS float
+//        ATOMICS were measured 4x slower than the rest of the kernel) and fp64 global atomics for
+//        the others.  The read-add-write chains serialise on lgkmcnt, so NP > 0 is ~2x faster.
+template <typename R, int NP>
+struct GradAcc {
+    R r[NP][3];
+    __device__ inline void init(R (*)[DRT_BLOCK])
+    {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            r[p][0] = r[p][1] = r[p][2] = R(0);
     }
-}
+    __device__ inline void add(R (*)[DRT_BLOCK], double* __restrict__, uint32_t id, V3<R> v)
+    {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool sel = id == (uint32_t)p;
+            r[p][0] += sel ? v.x : R(0);
+            r[p][1] += sel ? v.y : R(0);
+            r[p][2] += sel ? v.z : R(0);
+        }
+    }
+    __device__ inline double get(R (*)[DRT_BLOCK], int row) const
+    {
+        double v = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (row == p * 3 + c)
+                    v = (double)r[p][c];
+        return v;
+    }
+};
 
 template <typename R>
+struct GradAcc<R, 0> {
+    __device__ inline void init(R (*acc)[DRT_BLOCK])
+    {
+#pragma unroll
+        for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r)
+            acc[r][threadIdx.x] = R(0);
+    }
+    __device__ inline void add(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
+    {
+        if (id < DRT_FAST_PARAMS) {
+            acc[id * 3 + 0][threadIdx.x] += v.x;
+            acc[id * 3 + 1][threadIdx.x] += v.y;
+            acc[id * 3 + 2][threadIdx.x] += v.z;
+        } else {
+            atomicAdd(&grad[id * 3 + 0], (double)v.x);
+            atomicAdd(&grad[id * 3 + 1], (double)v.y);
+            atomicAdd(&grad[id * 3 + 2], (double)v.z);
+        }
+    }
+    __device__ inline double get(R (*acc)[DRT_BLOCK], int row) const { return (double)acc[row][threadIdx.x]; }
+};
+
+template <typename R, int NP>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
            const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad)
 {
+    constexpr bool SMALL = NP > 0;
     __shared__ SceneLds<R> lds;
-    __shared__ R acc[DRT_FAST_PARAMS * 3][DRT_BLOCK];
+    __shared__ R acc[NP > 0 ? 1 : DRT_FAST_PARAMS * 3][DRT_BLOCK];
     __shared__ double red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
-#pragma unroll
-    for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r)
-        acc[r][threadIdx.x] = R(0);
+    GradAcc<R, NP> ga;
+    ga.init(acc);
     stage_scene(lds, sc, params);
 
     const size_t N = a.n_paths;
@@ -560,7 +650,7 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
             V3<R> T = mk<R>(R(1), R(1), R(1));
             for (int j = 0; j < c0; ++j) {
                 const TapeRec<R> tr = tape[(size_t)j * N + i];
-                T = T * load_param(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
+                T = T * load_param<R, SMALL>(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
             }
             R Tx[DRT_TAPE_CHUNK], Ty[DRT_TAPE_CHUNK], Tz[DRT_TAPE_CHUNK], M[DRT_TAPE_CHUNK];
             uint32_t ID[DRT_TAPE_CHUNK];
@@ -577,7 +667,7 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                     Tx[j] = T.x; Ty[j] = T.y; Tz[j] = T.z;
                     const uint32_t cid = ID[j] & 0xFFFFu;
                     if (cid != DRT_ID_NONE)
-                        T = T * load_param(lds, params, (int)cid) * M[j];
+                        T = T * load_param<R, SMALL>(lds, params, (int)cid) * M[j];
                 }
             }
 #pragma unroll
@@ -589,13 +679,13 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                     const V3<R> adj = g * mk<R>(Tx[j], Ty[j], Tz[j]);
                     V3<R> Lk = mk<R>(R(0), R(0), R(0));
                     if (eid != DRT_ID_NONE) {
-                        grad_accumulate(acc, grad, eid, adj * inv_pk);
-                        Lk = load_param(lds, params, (int)eid) * inv_pk;
+                        ga.add(acc, grad, eid, adj * inv_pk);
+                        Lk = load_param<R, SMALL>(lds, params, (int)eid) * inv_pk;
                     }
                     if (cid != DRT_ID_NONE) {
                         const V3<R> wgt = Ln * M[j];
-                        grad_accumulate(acc, grad, cid, adj * wgt);
-                        Lk = Lk + load_param(lds, params, (int)cid) * wgt;
+                        ga.add(acc, grad, cid, adj * wgt);
+                        Lk = Lk + load_param<R, SMALL>(lds, params, (int)cid) * wgt;
                     }
                     Ln = Lk;
                 }
@@ -606,8 +696,8 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     // block reduction in fp64: thread columns -> wave (shuffles) -> block (LDS), fixed order
     const int lane = threadIdx.x & (DRT_WAVE - 1), wave = threadIdx.x / DRT_WAVE;
 #pragma unroll
-    for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r) {
-        double v = (double)acc[r][threadIdx.x];
+    for (int r = 0; r < (NP > 0 ? NP * 3 : DRT_FAST_PARAMS * 3); ++r) {
+        double v = ga.get(acc, r);
 #pragma unroll
         for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
             v += __shfl_down(v, off);
@@ -617,8 +707,9 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     __syncthreads();
     if (threadIdx.x < DRT_FAST_PARAMS * 3) {
         double v = 0;
-        for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
-            v += red[w][threadIdx.x];
+        if ((int)threadIdx.x < (NP > 0 ? NP * 3 : DRT_FAST_PARAMS * 3))
+            for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
+                v += red[w][threadIdx.x];
         gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
     }
 }
