@@ -25,7 +25,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libdrt_hip.so")
 
 # ---- enums / flags (include/drt_hip.h) ------------------------------------------------------
-SHAPE_PLANE, SHAPE_SPHERE = 0, 1
+SHAPE_PLANE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2
 BXDF_DIFFUSE, BXDF_SPECULAR = 0, 1
 RENDER_BACKWARD = 0x1
 RENDER_DEVICE_OUT = 0x2
@@ -41,7 +41,13 @@ STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3:
 
 class ShapeDesc(C.Structure):
     _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("emitter", C.c_int32),
-                ("reserved", C.c_int32), ("p", C.c_double * 4)]
+                ("mesh", C.c_int32), ("p", C.c_double * 4)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_triangles", C.c_int32),
+                ("vertices", C.POINTER(C.c_double)), ("indices", C.POINTER(C.c_uint32)),
+                ("face_material", C.POINTER(C.c_int32))]
 
 
 class MaterialDesc(C.Structure):
@@ -57,7 +63,8 @@ class SceneDesc(C.Structure):
                 ("n_params", C.c_int32),
                 ("shapes", C.POINTER(ShapeDesc)), ("materials", C.POINTER(MaterialDesc)),
                 ("emitters", C.POINTER(EmitterDesc)), ("params", C.POINTER(C.c_double)),
-                ("requires_grad", C.POINTER(C.c_uint8))]
+                ("requires_grad", C.POINTER(C.c_uint8)),
+                ("n_meshes", C.c_int32), ("reserved", C.c_int32), ("meshes", C.POINTER(MeshDesc))]
 
 
 class CameraDesc(C.Structure):
@@ -97,6 +104,7 @@ class Scene:
     materials: List[Tuple[int, int, float]] = field(default_factory=list)   # type, param, exponent
     emitters: List[int] = field(default_factory=list)                       # param
     shapes: List[Tuple[int, int, int, Tuple[float, float, float, float]]] = field(default_factory=list)
+    meshes: list = field(default_factory=list)   # (vertices f64 [nv,3], indices u32 [nt,3], face_material i32 [nt] | None)
 
     # Vector<T,3,true>(value, requires_grad), vector.hpp:228-234
     def parameter(self, rgb: Sequence[float], requires_grad: bool = True, name: str = "") -> int:
@@ -132,6 +140,16 @@ class Scene:
                             (float(center[0]), float(center[1]), float(center[2]), float(radius))))
         return len(self.shapes) - 1
 
+    # extension: a triangle mesh standing for its triangles at this position of the scene
+    def mesh(self, vertices, indices, material: int = -1, emitter: int = -1, face_material=None) -> int:
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        fm = None if face_material is None else np.ascontiguousarray(face_material, dtype=np.int32).reshape(-1)
+        assert i.max() < len(v) and (fm is None or len(fm) == len(i))
+        self.meshes.append((v, i, fm))
+        self.shapes.append((SHAPE_MESH, material, emitter, (float(len(self.meshes) - 1), 0.0, 0.0, 0.0)))
+        return len(self.shapes) - 1
+
     @property
     def n_params(self) -> int:
         return len(self.params)
@@ -141,8 +159,9 @@ class Scene:
         shapes = (ShapeDesc * max(1, len(self.shapes)))()
         for i, (t, m, e, p) in enumerate(self.shapes):
             shapes[i].type, shapes[i].material, shapes[i].emitter = t, m, e
+            shapes[i].mesh = int(p[0]) if t == SHAPE_MESH else 0
             for j in range(4):
-                shapes[i].p[j] = p[j]
+                shapes[i].p[j] = 0.0 if t == SHAPE_MESH else p[j]
         mats = (MaterialDesc * max(1, len(self.materials)))()
         for i, (t, p, ex) in enumerate(self.materials):
             mats[i].type, mats[i].param, mats[i].exponent = t, p, ex
@@ -156,9 +175,15 @@ class Scene:
         rg = (C.c_uint8 * max(1, len(self.params)))()
         for i, r in enumerate(self.requires_grad):
             rg[i] = 1 if r else 0
+        meshes = (MeshDesc * max(1, len(self.meshes)))()
+        for i, (v, idx, fm) in enumerate(self.meshes):
+            meshes[i].n_vertices, meshes[i].n_triangles = len(v), len(idx)
+            meshes[i].vertices = v.ctypes.data_as(C.POINTER(C.c_double))
+            meshes[i].indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+            meshes[i].face_material = fm.ctypes.data_as(C.POINTER(C.c_int32)) if fm is not None else None
         d = SceneDesc(len(self.shapes), len(self.materials), len(self.emitters), len(self.params),
-                      shapes, mats, emis, params, rg)
-        return d, [shapes, mats, emis, params, rg]
+                      shapes, mats, emis, params, rg, len(self.meshes), 0, meshes)
+        return d, [shapes, mats, emis, params, rg, meshes, self.meshes]
 
 
 def cornell_box(front_specular: bool = False, emissive_wall: bool = False) -> Scene:
@@ -227,6 +252,54 @@ def random_scene(seed: int, n_spheres: int = 5, specular: bool = True, n_lights:
     return s
 
 
+def displaced_sphere_mesh(n_lat: int, n_lon: int, center=(0., -1.2, 3.6), radius: float = 1.3,
+                          amplitude: float = 0.12, seed: int = 1234):
+    """Procedural test mesh (no assets, no network): a latitude/longitude sphere whose vertices are
+    pushed along the radius by a smooth pseudo-random field; 2*n_lon*(n_lat-1) triangles
+    (n_lat = n_lon = 160 -> 50,880: the "~50k-triangle mesh" of BASELINE config 4)."""
+    rs = np.random.RandomState(seed)
+    k = rs.randint(1, 6, (6, 2)).astype(np.float64)
+    ph = rs.uniform(0, 2 * np.pi, (6, 2))
+    amp = rs.uniform(0.3, 1.0, 6)
+    verts = [(0.0, 0.0)]                                  # (theta, phi) of the north pole
+    for i in range(1, n_lat):
+        for j in range(n_lon):
+            verts.append((np.pi * i / n_lat, 2 * np.pi * j / n_lon))
+    verts.append((np.pi, 0.0))
+    tp = np.array(verts)
+    th, phi = tp[:, 0], tp[:, 1]
+    disp = sum(a * np.sin(kk[0] * th + p[0]) * np.cos(kk[1] * phi + p[1]) for a, kk, p in zip(amp, k, ph))
+    r = radius * (1.0 + amplitude * disp / amp.sum())
+    xyz = np.stack([r * np.sin(th) * np.cos(phi), r * np.cos(th), r * np.sin(th) * np.sin(phi)], 1) + np.array(center)
+    ring = lambda i, j: 1 + (i - 1) * n_lon + (j % n_lon)
+    tris = []
+    for j in range(n_lon):
+        tris.append((0, ring(1, j + 1), ring(1, j)))
+        for i in range(1, n_lat - 1):
+            a, b, c, d = ring(i, j), ring(i, j + 1), ring(i + 1, j), ring(i + 1, j + 1)
+            tris.append((a, b, d))
+            tris.append((a, d, c))
+        tris.append((len(verts) - 1, ring(n_lat - 1, j), ring(n_lat - 1, j + 1)))
+    return xyz.astype(np.float64), np.array(tris, dtype=np.uint32)
+
+
+def cornell_with_mesh(n_lat: int = 160, n_lon: int = 160, per_face_params: int = 0, seed: int = 1234) -> Scene:
+    """BASELINE config 4 shape: the Cornell box of render.cpp with a displaced-sphere mesh in it
+    (in place of sphere_front).  per_face_params > 0 gives the mesh that many albedo parameters,
+    assigned to faces round-robin (per-face materials)."""
+    s = cornell_box()
+    v, idx = displaced_sphere_mesh(n_lat, n_lon, seed=seed)
+    white_mat = 2
+    fm = None
+    if per_face_params > 0:
+        rs = np.random.RandomState(seed + 1)
+        mats = [s.diffuse(s.parameter(rs.uniform(0.2, 0.9, 3), True, f"face{i}")) for i in range(per_face_params)]
+        fm = np.array([mats[t % per_face_params] for t in range(len(idx))], dtype=np.int32)
+    s.meshes.append((v, idx, fm))
+    s.shapes[0] = (SHAPE_MESH, white_mat, -1, (float(len(s.meshes) - 1), 0.0, 0.0, 0.0))
+    return s
+
+
 def scene_by_name(name: str) -> Scene:
     """Named test/bench scenes (the names the golden fixtures record)."""
     if name == "cornell":
@@ -237,6 +310,10 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box(emissive_wall=True)
     if name.startswith("random"):
         return random_scene(int(name[len("random"):]))
+    if name.startswith("mesh"):          # mesh<n_lat>x<n_lon>[f<per-face params>]
+        body, _, pf = name[4:].partition("f")
+        a, b = body.split("x")
+        return cornell_with_mesh(int(a), int(b), int(pf) if pf else 0)
     raise KeyError(name)
 
 

@@ -33,6 +33,8 @@ struct DevMaterial {
 template <typename R>
 struct DevScene {
     int n_shapes, n_materials, n_emitters, n_params;
+    int flat[DRT_MAX_SHAPES];   // position of shape s in the flattened scene (a mesh counts once per
+                                // triangle): the order that breaks exact ties, pathtracer.hpp:80
     DevShape<R> shapes[DRT_MAX_SHAPES];
     DevMaterial<R> materials[DRT_MAX_MATERIALS];
     int emitter_param[DRT_MAX_EMITTERS];
@@ -62,6 +64,24 @@ __device__ inline double pid_pack(double, uint32_t pid) { return (double)pid; }
 __device__ inline uint32_t pid_unpack(float v) { return __float_as_uint(v); }
 __device__ inline uint32_t pid_unpack(double v) { return (uint32_t)v; }
 
+// ---- triangle meshes (extension): one threaded BVH over all triangles of the scene -----------
+//   node_lo[i] = (box.lo.xyz, hit link)   hit link: first child, or 0x80000000 | first << 3 | count
+//   node_hi[i] = (box.hi.xyz, miss link)  miss link: next node when missed / done, 0xFFFFFFFF = end
+//   tri_a/b/c[j] (leaf order) = (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, global index, flat index, -)
+//   tri_shade[g] (global triangle order) = (normal.xyz, material | emitter << 16)
+template <typename R>
+struct DevBvh {
+    const typename Q4<R>::T* node_lo;
+    const typename Q4<R>::T* node_hi;
+    const typename Q4<R>::T* tri_a;
+    const typename Q4<R>::T* tri_b;
+    const typename Q4<R>::T* tri_c;
+    const typename Q4<R>::T* tri_shade;
+    uint32_t n_nodes, n_top, n_tris, pad;
+};
+#define DRT_BVH_END 0xFFFFFFFFu
+#define DRT_BVH_LDS_NODES_F32 1024   // 32 KB of LDS per block (f32); f64 stages half as many
+
 // ---- small vector math -----------------------------------------------------------------------
 template <typename R>
 struct V3 {
@@ -87,6 +107,10 @@ __device__ inline float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ inline double sqrt_r(double x) { return sqrt(x); }
 __device__ inline float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ inline double div_r(double a, double b) { return a / b; }
+__device__ inline float min_r(float a, float b) { return fminf(a, b); }   // NaN-ignoring (v_min_f32)
+__device__ inline double min_r(double a, double b) { return fmin(a, b); }
+__device__ inline float max_r(float a, float b) { return fmaxf(a, b); }
+__device__ inline double max_r(double a, double b) { return fmax(a, b); }
 __device__ inline float abs_r(float x) { return fabsf(x); }
 __device__ inline double abs_r(double x) { return fabs(x); }
 __device__ inline float pow_r(float x, float y) { return powf(x, y); }
@@ -143,4 +167,37 @@ __device__ inline void make_frame(V3<R> n, V3<R>& t, V3<R>& b)
     else
         t = normalize(mk<R>(-n.x * n.y, R(1) - n.y * n.y, -n.z * n.y));
     b = normalize(cross(n, t));
+}
+
+// ---- triangle: two-sided Moller-Trumbore, hit iff t > 0 (oracle/ref_harness.cpp `Triangle`) ---
+template <typename R>
+__device__ inline bool tri_intersect(V3<R> v0, V3<R> e1, V3<R> e2, V3<R> o, V3<R> d, R& t)
+{
+    const V3<R> pvec = cross(d, e2);
+    const R det = dot(e1, pvec);
+    if (det == R(0))
+        return false;
+    const R inv = R(1) / det;
+    const V3<R> tvec = o - v0;
+    const R u = dot(tvec, pvec) * inv;
+    if (u < R(0) || u > R(1))
+        return false;
+    const V3<R> qvec = cross(tvec, e1);
+    const R v = dot(d, qvec) * inv;
+    if (v < R(0) || u + v > R(1))
+        return false;
+    t = dot(e2, qvec) * inv;
+    return t > R(0);
+}
+
+// conservative slab test against a (padded) box, limited to (0, tmax]
+template <typename R>
+__device__ inline bool box_hit(V3<R> lo, V3<R> hi, V3<R> o, V3<R> inv_d, R tmax)
+{
+    const R ax = (lo.x - o.x) * inv_d.x, bx = (hi.x - o.x) * inv_d.x;
+    const R ay = (lo.y - o.y) * inv_d.y, by = (hi.y - o.y) * inv_d.y;
+    const R az = (lo.z - o.z) * inv_d.z, bz = (hi.z - o.z) * inv_d.z;
+    const R tn = max_r(max_r(min_r(ax, bx), min_r(ay, by)), max_r(min_r(az, bz), R(0)));
+    const R tf = min_r(min_r(max_r(ax, bx), max_r(ay, by)), min_r(max_r(az, bz), tmax));
+    return tn <= tf;
 }

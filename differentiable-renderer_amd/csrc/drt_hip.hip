@@ -3,6 +3,7 @@
 // bounce is two launches (K2, K3) on persistent grids that read their queue length from device
 // memory, so a whole render is enqueued without a single host round trip.
 #include "drt_kernels.h"
+#include "drt_bvh.h"
 
 #include <chrono>
 #include <cmath>
@@ -41,6 +42,11 @@ struct drt_hip_ctx {
     DevScene<double>* d_scene_d = nullptr;
     float* d_params_f = nullptr;
     double* d_params_d = nullptr;
+    // triangle meshes (extension): one BVH over all triangles, in both compute types
+    bool has_mesh = false;
+    DevBvh<float> bvh_f{};
+    DevBvh<double> bvh_d{};
+    std::vector<void*> mesh_allocs;
 
     DevBuf ray_a[2], ray_b[2], ray_id[2], ray_c[2], hit, lacc, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
@@ -99,6 +105,82 @@ void release(DevBuf& b)
     b.cap = 0;
 }
 
+void release_mesh(drt_hip_ctx* ctx)
+{
+    for (void* p : ctx->mesh_allocs)
+        (void)hipFree(p);
+    ctx->mesh_allocs.clear();
+    ctx->has_mesh = false;
+    memset(&ctx->bvh_f, 0, sizeof ctx->bvh_f);
+    memset(&ctx->bvh_d, 0, sizeof ctx->bvh_d);
+}
+
+template <typename R4>
+int upload_array(drt_hip_ctx* ctx, const std::vector<R4>& host, const R4** dev)
+{
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, host.empty() ? 16 : host.size() * sizeof(R4));
+    if (e == hipSuccess && !host.empty())
+        e = hipMemcpy(p, host.data(), host.size() * sizeof(R4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ctx->err = std::string("mesh upload: ") + hipGetErrorString(e);
+        if (p) (void)hipFree(p);
+        return DRT_ERR_HIP;
+    }
+    ctx->mesh_allocs.push_back(p);
+    *dev = (const R4*)p;
+    return DRT_OK;
+}
+
+inline float link_bits(float, uint32_t v) { float f; memcpy(&f, &v, 4); return f; }
+inline double link_bits(double, uint32_t v) { return (double)v; }
+
+// device image of the BVH in compute type R
+template <typename R>
+int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_bvh::Tri>& tris, DevBvh<R>* out)
+{
+    typedef typename Q4<R>::T R4;
+    std::vector<R4> lo(b.nodes.size()), hi(b.nodes.size());
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+        const drt_bvh::Node& n = b.nodes[i];
+        // boxes must stay conservative after rounding to R: round outwards
+        lo[i].x = (R)n.lo[0]; lo[i].y = (R)n.lo[1]; lo[i].z = (R)n.lo[2];
+        hi[i].x = (R)n.hi[0]; hi[i].y = (R)n.hi[1]; hi[i].z = (R)n.hi[2];
+        if (sizeof(R) == 4) {
+            R* l = &lo[i].x; R* h = &hi[i].x;
+            for (int a = 0; a < 3; ++a) {
+                if ((double)l[a] > n.lo[a]) l[a] = (R)nextafterf((float)l[a], -INFINITY);
+                if ((double)h[a] < n.hi[a]) h[a] = (R)nextafterf((float)h[a], INFINITY);
+            }
+        }
+        lo[i].w = link_bits(R(0), n.hit);
+        hi[i].w = link_bits(R(0), n.miss);
+    }
+    std::vector<R4> ta(b.order.size()), tb(b.order.size()), tc(b.order.size()), ts(tris.size());
+    for (size_t j = 0; j < b.order.size(); ++j) {
+        const drt_bvh::Tri& t = tris[b.order[j]];
+        ta[j].x = (R)t.v0[0]; ta[j].y = (R)t.v0[1]; ta[j].z = (R)t.v0[2]; ta[j].w = (R)t.e1[0];
+        tb[j].x = (R)t.e1[1]; tb[j].y = (R)t.e1[2]; tb[j].z = (R)t.e2[0]; tb[j].w = (R)t.e2[1];
+        tc[j].x = (R)t.e2[2]; tc[j].y = link_bits(R(0), t.global); tc[j].z = link_bits(R(0), t.flat); tc[j].w = R(0);
+    }
+    for (size_t g = 0; g < tris.size(); ++g) {
+        const drt_bvh::Tri& t = tris[g];
+        ts[t.global].x = (R)t.n[0]; ts[t.global].y = (R)t.n[1]; ts[t.global].z = (R)t.n[2];
+        ts[t.global].w = link_bits(R(0), t.ids);
+    }
+    int rc;
+    if ((rc = upload_array(ctx, lo, &out->node_lo)) != DRT_OK) return rc;
+    if ((rc = upload_array(ctx, hi, &out->node_hi)) != DRT_OK) return rc;
+    if ((rc = upload_array(ctx, ta, &out->tri_a)) != DRT_OK) return rc;
+    if ((rc = upload_array(ctx, tb, &out->tri_b)) != DRT_OK) return rc;
+    if ((rc = upload_array(ctx, tc, &out->tri_c)) != DRT_OK) return rc;
+    if ((rc = upload_array(ctx, ts, &out->tri_shade)) != DRT_OK) return rc;
+    out->n_nodes = (uint32_t)b.nodes.size();
+    out->n_top = b.top;
+    out->n_tris = (uint32_t)tris.size();
+    return DRT_OK;
+}
+
 template <typename R>
 void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s)
 {
@@ -107,7 +189,10 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     ds.n_materials = s->n_materials;
     ds.n_emitters = s->n_emitters;
     ds.n_params = s->n_params;
+    int flat = 0;
     for (int i = 0; i < s->n_shapes; ++i) {
+        ds.flat[i] = flat;
+        flat += s->shapes[i].type == DRT_SHAPE_MESH ? s->meshes[s->shapes[i].mesh].n_triangles : 1;
         for (int j = 0; j < 4; ++j)
             ds.shapes[i].p[j] = (R)s->shapes[i].p[j];
         ds.shapes[i].type = s->shapes[i].type;
@@ -175,6 +260,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const DevScene<R>* d_scene = sizeof(R) == 4 ? (const DevScene<R>*)ctx->d_scene_f
                                                 : (const DevScene<R>*)ctx->d_scene_d;
     const R* d_params = sizeof(R) == 4 ? (const R*)ctx->d_params_f : (const R*)ctx->d_params_d;
+    DevBvh<R> bvh;
+    memcpy(&bvh, sizeof(R) == 4 ? (const void*)&ctx->bvh_f : (const void*)&ctx->bvh_d, sizeof bvh);
     const int spp = rp->spp;
     const uint64_t total_paths = (uint64_t)n_local_pixels * (uint64_t)spp;
     uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
@@ -297,8 +384,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             for (int k = 0; k < D; ++k) {
                 const int cur = k & 1, nxt = cur ^ 1;
                 if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                   ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                if (ctx->has_mesh)
+                    hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                       bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                else
+                    hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                       ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
 
@@ -314,7 +405,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #define DRT_LAUNCH_SHADE(BWD, SPEC)                                                                       \
     hipLaunchKernelGGL((k_shade<R, BWD, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene, \
                        d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt], rb[nxt], rid[nxt],   \
-                       rcq[nxt], tape_k, nv, lacc, ck, cn)
+                       rcq[nxt], tape_k, nv, lacc, ck, cn, bvh.tri_shade)
                     if (backward && ctx->has_specular) DRT_LAUNCH_SHADE(true, true);
                     else if (backward) DRT_LAUNCH_SHADE(true, false);
                     else if (ctx->has_specular) DRT_LAUNCH_SHADE(false, true);
@@ -416,6 +507,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
                       &ctx->adjoint, &ctx->out};
     for (DevBuf* b : bufs)
         release(*b);
+    release_mesh(ctx);
     if (ctx->d_scene_f) (void)hipFree(ctx->d_scene_f);
     if (ctx->d_scene_d) (void)hipFree(ctx->d_scene_d);
     if (ctx->d_params_f) (void)hipFree(ctx->d_params_f);
@@ -439,9 +531,20 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
         return fail(ctx, DRT_ERR_INVALID, "scene: bad counts or null arrays");
     for (int i = 0; i < s->n_shapes; ++i) {
         const drt_shape_desc& sh = s->shapes[i];
-        if (sh.type == DRT_SHAPE_MESH)
-            return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: DRT_SHAPE_MESH is reserved, not built yet");
-        if (sh.type != DRT_SHAPE_PLANE && sh.type != DRT_SHAPE_SPHERE)
+        if (sh.type == DRT_SHAPE_MESH) {
+            if (sh.mesh < 0 || sh.mesh >= s->n_meshes || !s->meshes)
+                return fail(ctx, DRT_ERR_INVALID, "scene: mesh index out of range");
+            const drt_mesh_desc& m = s->meshes[sh.mesh];
+            if (m.n_triangles < 0 || m.n_vertices < 0 || (m.n_triangles && (!m.vertices || !m.indices)))
+                return fail(ctx, DRT_ERR_INVALID, "scene: malformed mesh");
+            for (int t = 0; t < m.n_triangles * 3; ++t)
+                if (m.indices[t] >= (uint32_t)m.n_vertices)
+                    return fail(ctx, DRT_ERR_INVALID, "scene: mesh vertex index out of range");
+            if (m.face_material)
+                for (int t = 0; t < m.n_triangles; ++t)
+                    if (m.face_material[t] < -1 || m.face_material[t] >= s->n_materials)
+                        return fail(ctx, DRT_ERR_INVALID, "scene: face material index out of range");
+        } else if (sh.type != DRT_SHAPE_PLANE && sh.type != DRT_SHAPE_SPHERE)
             return fail(ctx, DRT_ERR_INVALID, "scene: unknown shape type");
         if (sh.material < -1 || sh.material >= s->n_materials || sh.emitter < -1 || sh.emitter >= s->n_emitters)
             return fail(ctx, DRT_ERR_INVALID, "scene: shape material/emitter index out of range");
@@ -486,6 +589,49 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     delete hd;
     if (rc != DRT_OK)
         return rc;
+    release_mesh(ctx);
+    {
+        std::vector<drt_bvh::Tri> tris;
+        uint32_t flat = 0;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < s->n_shapes; ++i) {
+            const drt_shape_desc& sh = s->shapes[i];
+            if (sh.type != DRT_SHAPE_MESH) { ++flat; continue; }
+            const drt_mesh_desc& m = s->meshes[sh.mesh];
+            for (int k = 0; k < m.n_triangles; ++k, ++flat) {
+                drt_bvh::Tri t;
+                const double* a = &m.vertices[(size_t)m.indices[k * 3] * 3];
+                const double* b = &m.vertices[(size_t)m.indices[k * 3 + 1] * 3];
+                const double* c = &m.vertices[(size_t)m.indices[k * 3 + 2] * 3];
+                for (int x = 0; x < 3; ++x) {
+                    t.v0[x] = a[x]; t.e1[x] = b[x] - a[x]; t.e2[x] = c[x] - a[x];
+                    lo[x] = std::min(lo[x], std::min(a[x], std::min(b[x], c[x])));
+                    hi[x] = std::max(hi[x], std::max(a[x], std::max(b[x], c[x])));
+                }
+                // normalize(cross(e1, e2)) in the operation order of the oracle / harness
+                const double nx = t.e1[1] * t.e2[2] - t.e1[2] * t.e2[1];
+                const double ny = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2];
+                const double nz = t.e1[0] * t.e2[1] - t.e1[1] * t.e2[0];
+                const double len = sqrt(((0.0 + nx * nx) + ny * ny) + nz * nz);
+                t.n[0] = nx / len; t.n[1] = ny / len; t.n[2] = nz / len;
+                t.global = (uint32_t)tris.size();
+                t.flat = flat;
+                const int mat = m.face_material ? m.face_material[k] : sh.material;
+                t.ids = (uint32_t)(mat < 0 ? 0xFFFF : mat) | ((uint32_t)(sh.emitter < 0 ? 0xFFFF : sh.emitter) << 16);
+                tris.push_back(t);
+            }
+        }
+        if (!tris.empty()) {
+            if (tris.size() >= (1u << 28))
+                return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: more than 2^28 triangles");
+            const double diag = sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
+                                     (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES_F32, 1e-5 * (diag > 0 ? diag : 1.0));
+            if ((rc = upload_bvh<float>(ctx, built, tris, &ctx->bvh_f)) != DRT_OK) return rc;
+            if ((rc = upload_bvh<double>(ctx, built, tris, &ctx->bvh_d)) != DRT_OK) return rc;
+            ctx->has_mesh = true;
+        }
+    }
     ctx->n_params = s->n_params;
     ctx->n_shapes = s->n_shapes;
     ctx->requires_grad.assign((size_t)s->n_params, 1);

@@ -232,6 +232,92 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     }
 }
 
+// ---- K2 (scenes with triangle meshes) -----------------------------------------------------------
+// Same chunk sweep as k_intersect; per ray: the analytic shapes, then a stackless walk of the
+// threaded BVH.  The top of the tree (breadth-first prefix) is staged in LDS once per block, the
+// rest of the nodes and the triangles come from L2.  Exact ties keep the primitive that comes
+// first in the flattened scene, like the reference's linear scan (pathtracer.hpp:80).
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
+                 const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
+                 HitRec<R>* __restrict__ hit, const uint32_t* __restrict__ counts_k)
+{
+    typedef typename Q4<R>::T R4;
+    typedef typename Q2<R>::T R2;
+    constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES_F32 * sizeof(float) / sizeof(R);
+    __shared__ R4 s_lo[LDS_NODES], s_hi[LDS_NODES];
+    const uint32_t n_lds = bvh.n_top < LDS_NODES ? bvh.n_top : LDS_NODES;
+    for (uint32_t i = threadIdx.x; i < n_lds; i += blockDim.x) {
+        s_lo[i] = bvh.node_lo[i];
+        s_hi[i] = bvh.node_hi[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
+    const uint32_t n_chunks = a.n_regions << (a.region_shift - 6);
+    const int n_shapes = sc->n_shapes;
+    for (uint32_t c = grid_wave(); c < n_chunks; c += n_waves) {
+        const uint32_t slot = chunk_slot(a, counts_k, c, n_chunks, lane);
+        if (slot == 0xFFFFFFFFu)
+            continue;
+        const R4 ra = ray_a[slot];
+        const R2 rb = ray_b[slot];
+        const V3<R> o = mk<R>(ra.x, ra.y, ra.z), d = mk<R>(ra.w, rb.x, rb.y);
+        R tmin = (R)INFINITY;
+        int prim = -1;
+        uint32_t best_flat = 0xFFFFFFFFu;
+        for (int s = 0; s < n_shapes; ++s) {
+            const DevShape<R> sh = sc->shapes[s];
+            if (sh.type == DRT_SHAPE_MESH)
+                continue;
+            R t;
+            const uint32_t flat = (uint32_t)sc->flat[s];
+            if (shape_intersect(sh, o, d, t) && (t < tmin || (t == tmin && flat < best_flat))) {
+                tmin = t;
+                prim = s;
+                best_flat = flat;
+            }
+        }
+        const V3<R> inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+        uint32_t node = bvh.n_nodes ? 0u : DRT_BVH_END;
+        while (node != DRT_BVH_END) {
+            R4 nlo, nhi;
+            if (node < n_lds) { nlo = s_lo[node]; nhi = s_hi[node]; }
+            else { nlo = bvh.node_lo[node]; nhi = bvh.node_hi[node]; }
+            const uint32_t miss = pid_unpack(nhi.w);
+            if (!box_hit(mk<R>(nlo.x, nlo.y, nlo.z), mk<R>(nhi.x, nhi.y, nhi.z), o, inv_d, tmin)) {
+                node = miss;
+                continue;
+            }
+            const uint32_t link = pid_unpack(nlo.w);
+            if (!(link & 0x80000000u)) {
+                node = link;
+                continue;
+            }
+            const uint32_t first = (link & 0x7FFFFFFFu) >> 3, count = link & 7u;
+            for (uint32_t j = first; j < first + count; ++j) {
+                const R4 ta = bvh.tri_a[j], tb = bvh.tri_b[j], tc = bvh.tri_c[j];
+                R t;
+                if (tri_intersect(mk<R>(ta.x, ta.y, ta.z), mk<R>(ta.w, tb.x, tb.y), mk<R>(tb.z, tb.w, tc.x), o, d, t)) {
+                    const uint32_t flat = pid_unpack(tc.z);
+                    if (t < tmin || (t == tmin && flat < best_flat)) {
+                        tmin = t;
+                        prim = n_shapes + (int)pid_unpack(tc.y);
+                        best_flat = flat;
+                    }
+                }
+            }
+            node = miss;
+        }
+        HitRec<R> h;
+        h.t = tmin;
+        h.prim = prim;
+        hit[slot] = h;
+    }
+}
+
 // ---- K3 ---------------------------------------------------------------------------------------
 template <typename R>
 struct SceneLds {
@@ -331,7 +417,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         uint2* __restrict__ next_id, typename Q4<R>::T* __restrict__ next_c,
         TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
         typename Q4<R>::T* __restrict__ lacc, const uint32_t* __restrict__ counts_k,
-        uint32_t* __restrict__ counts_next)
+        uint32_t* __restrict__ counts_next, const typename Q4<R>::T* __restrict__ tri_shade)
 {
     typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
@@ -339,6 +425,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
+    const int n_shapes = lds.sc.n_shapes;
     const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
     const R inv_pk = R(1) / pk;
     const uint32_t n_theta = draw_index(k, a.min_bounces);
@@ -378,15 +465,27 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
             } else {
                 const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
                 const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
-                const DevShape<R>& sh = lds.sc.shapes[h.prim];
                 const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
-                const V3<R> nrm = shape_normal(sh, P);
+                V3<R> nrm;
+                int material, emitter;
+                if (h.prim < n_shapes) {
+                    const DevShape<R>& sh = lds.sc.shapes[h.prim];
+                    nrm = shape_normal(sh, P);
+                    material = sh.material;
+                    emitter = sh.emitter;
+                } else {                                       // triangle: per-triangle record
+                    const R4 ts = tri_shade[h.prim - n_shapes];
+                    const uint32_t ids = pid_unpack(ts.w);
+                    nrm = mk<R>(ts.x, ts.y, ts.z);
+                    material = (ids & 0xFFFFu) == 0xFFFFu ? -1 : (int)(ids & 0xFFFFu);
+                    emitter = (ids >> 16) == 0xFFFFu ? -1 : (int)(ids >> 16);
+                }
                 V3<R> T = mk<R>(R(1), R(1), R(1));
                 if (k > 0)
                     T = mk<R>(cur.rc.x, cur.rc.y, cur.rc.z);
                 uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
-                if (sh.emitter >= 0) {                         // pathtracer.hpp:113-114
-                    eid = (uint32_t)lds.sc.emitter_param[sh.emitter];
+                if (emitter >= 0) {                            // pathtracer.hpp:113-114
+                    eid = (uint32_t)lds.sc.emitter_param[emitter];
                     const V3<R> E = load_param(lds, params, (int)eid);
                     R4 L = lacc[pid];
                     L.x += T.x * E.x * inv_pk;
@@ -394,7 +493,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     L.z += T.z * E.z * inv_pk;
                     lacc[pid] = L;
                 }
-                if (sh.material < 0) {
+                if (material < 0) {
                     // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
                     // continuation contributes exactly 0, the path ends here
                     if (BWD) {
@@ -405,7 +504,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                         nv[pid] = (uint32_t)k + 1u;
                     }
                 } else {
-                    const DevMaterial<R>& m = lds.sc.materials[sh.material];
+                    const DevMaterial<R>& m = lds.sc.materials[material];
                     cid = (uint32_t)m.param;
                     const uint32_t key = cur.rid.y;
                     const uint32_t r1 = drt_rng_draw(key, n_theta);

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 1
+#define DRT_HIP_ABI_VERSION 2
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -53,17 +53,31 @@ typedef enum drt_status {
 /* ---- scene description (host-side POD, doubles: the reference computes in double,
  *      src/render.cpp:22; the device converts to its compute type) ------------------------ */
 
-enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2 /* reserved */ };
+enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2 };
 enum { DRT_BXDF_DIFFUSE = 0, DRT_BXDF_SPECULAR = 1, DRT_BXDF_MIRROR = 2 /* reserved */ };
 
 typedef struct drt_shape_desc {
     int32_t type;      /* DRT_SHAPE_* */
     int32_t material;  /* index into materials, -1 = no BxDF (shape.hpp:26-27 returns nullptr) */
     int32_t emitter;   /* index into emitters,  -1 = no emitter (shape.hpp:29-30) */
-    int32_t reserved;
+    int32_t mesh;      /* MESH: index into meshes; otherwise ignored */
     double p[4];       /* PLANE: normal.xyz (NOT normalised, shape.hpp:58-59), offset
-                          SPHERE: center.xyz, radius */
+                          SPHERE: center.xyz, radius   MESH: unused */
 } drt_shape_desc;
+
+/* Triangle mesh: an EXTENSION behind the Shape<T> plugin surface (the reference has no
+ * triangles).  A MESH shape stands for its triangles listed in index order at
+ * the shape's position in the scene, each one a Shape<T> with these semantics (pinned by the
+ * brute-force `Triangle : drt::Shape<double>` of oracle/ref_harness.cpp, compiled against the
+ * reference headers): two-sided Moller-Trumbore with e1 = v1 - v0, e2 = v2 - v0, hit iff t > 0
+ * (the predicate of shape.hpp:55), normal = normalize(cross(e1, e2)), never flipped (like
+ * Sphere, shape.hpp:105-106); on exact ties the earlier triangle wins (pathtracer.hpp:80). */
+typedef struct drt_mesh_desc {
+    int32_t n_vertices, n_triangles;
+    const double* vertices;        /* n_vertices x 3 */
+    const uint32_t* indices;       /* n_triangles x 3 */
+    const int32_t* face_material;  /* n_triangles material indices, or NULL: the shape's material */
+} drt_mesh_desc;
 
 typedef struct drt_material_desc {
     int32_t type;      /* DRT_BXDF_* */
@@ -84,6 +98,8 @@ typedef struct drt_scene_desc {
     const drt_emitter_desc* emitters;
     const double* params;                /* n_params x 3 (RGB) */
     const uint8_t* requires_grad;        /* n_params, NULL = all true */
+    int32_t n_meshes, reserved;
+    const drt_mesh_desc* meshes;
 } drt_scene_desc;
 
 typedef struct drt_camera_desc {

@@ -115,22 +115,86 @@ static v3 shape_normal(const drt_shape_desc* s, v3 point)
     return v3_normalize(v3_sub(point, v3_make(s->p[0], s->p[1], s->p[2])));
 }
 
+/* ---- triangles: EXTENSION (the reference has none).  Restates the brute-force
+ * `Triangle : drt::Shape<double>` of oracle/ref_harness.cpp operation for operation: two-sided
+ * Moller-Trumbore on (v0, e1 = v1 - v0, e2 = v2 - v0), hit iff t > 0, normal =
+ * normalize(cross(e1, e2)). */
+static void tri_load(const drt_mesh_desc* m, int tri, v3* v0, v3* e1, v3* e2)
+{
+    const uint32_t* ix = &m->indices[(size_t)tri * 3];
+    const double* a = &m->vertices[(size_t)ix[0] * 3];
+    const double* b = &m->vertices[(size_t)ix[1] * 3];
+    const double* c = &m->vertices[(size_t)ix[2] * 3];
+    *v0 = v3_make(a[0], a[1], a[2]);
+    *e1 = v3_sub(v3_make(b[0], b[1], b[2]), *v0);
+    *e2 = v3_sub(v3_make(c[0], c[1], c[2]), *v0);
+}
+
+static int tri_intersect(v3 v0, v3 e1, v3 e2, v3 orig, v3 dir, double* t)
+{
+    v3 pvec = v3_cross(dir, e2);
+    double det = v3_dot(e1, pvec);
+    if (det == 0)
+        return 0;
+    double inv = 1 / det;
+    v3 tvec = v3_sub(orig, v0);
+    double u = v3_dot(tvec, pvec) * inv;
+    if (u < 0 || u > 1)
+        return 0;
+    v3 qvec = v3_cross(tvec, e1);
+    double v = v3_dot(dir, qvec) * inv;
+    if (v < 0 || u + v > 1)
+        return 0;
+    *t = v3_dot(e2, qvec) * inv;
+    return *t > 0;
+}
+
 /* ---- Pathtracer::raycast, pathtracer.hpp:72-89 ------------------------------------------- */
-static int raycast(const drt_scene_desc* sc, v3 orig, v3 dir, v3* point, v3* normal, double* t_out)
+typedef struct {
+    int shape;      /* index into scene->shapes, -1 = miss */
+    int tri;        /* triangle within the mesh, -1 for analytic shapes */
+    int flat;       /* position in the flattened scene (every triangle counts as a shape) */
+    int material;   /* resolved material index (per-face or the shape's), -1 = none */
+} hit_t;
+
+static hit_t raycast(const drt_scene_desc* sc, v3 orig, v3 dir, v3* point, v3* normal, double* t_out)
 {
     double tmin = INFINITY;
-    int hit = -1;
+    hit_t hit = {-1, -1, -1, -1};
+    int flat = 0;
     for (int i = 0; i < sc->n_shapes; ++i) {
-        double t;
-        if (!shape_intersect(&sc->shapes[i], orig, dir, &t) || t >= tmin)
+        const drt_shape_desc* sh = &sc->shapes[i];
+        if (sh->type == DRT_SHAPE_MESH) {
+            const drt_mesh_desc* m = &sc->meshes[sh->mesh];
+            for (int k = 0; k < m->n_triangles; ++k, ++flat) {
+                v3 v0, e1, e2;
+                double t;
+                tri_load(m, k, &v0, &e1, &e2);
+                if (!tri_intersect(v0, e1, e2, orig, dir, &t) || t >= tmin)
+                    continue;
+                tmin = t;
+                *point = v3_add(orig, v3_scale(dir, t));
+                *normal = v3_normalize(v3_cross(e1, e2));
+                hit.shape = i; hit.tri = k; hit.flat = flat;
+                hit.material = m->face_material ? m->face_material[k] : sh->material;
+            }
             continue;
+        }
+        double t;
+        if (!shape_intersect(sh, orig, dir, &t) || t >= tmin) {
+            ++flat;
+            continue;
+        }
         tmin = t;
         *point = v3_add(orig, v3_scale(dir, t));
-        *normal = shape_normal(&sc->shapes[i], *point);
-        hit = i;
+        *normal = shape_normal(sh, *point);
+        hit.shape = i; hit.tri = -1; hit.flat = flat; hit.material = sh->material;
+        ++flat;
     }
     *t_out = tmin;
-    return isinf(tmin) ? -1 : hit;
+    if (isinf(tmin))
+        hit.shape = -1;
+    return hit;
 }
 
 /* ---- make_frame / angle_to_dir, bxdf.hpp:29-52 ------------------------------------------- */
@@ -244,8 +308,9 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
         return DRT_ERR_INVALID;
     for (int i = 0; i < scene->n_shapes; ++i) {
         const drt_shape_desc* s = &scene->shapes[i];
-        if ((s->type != DRT_SHAPE_PLANE && s->type != DRT_SHAPE_SPHERE) ||
-            s->material >= scene->n_materials || s->emitter >= scene->n_emitters)
+        if ((s->type != DRT_SHAPE_PLANE && s->type != DRT_SHAPE_SPHERE && s->type != DRT_SHAPE_MESH) ||
+            s->material >= scene->n_materials || s->emitter >= scene->n_emitters ||
+            (s->type == DRT_SHAPE_MESH && (s->mesh < 0 || s->mesh >= scene->n_meshes)))
             return DRT_ERR_INVALID;
     }
     const int W = cam->width, H = cam->height, spp = rp->spp;
@@ -293,7 +358,8 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                     v3 point = v3_make(0, 0, 0), normal = v3_make(0, 0, 0);
                     double t;
                     int zero_dir = dir.v[0] == 0 && dir.v[1] == 0 && dir.v[2] == 0;
-                    int shape = raycast(scene, orig, dir, &point, &normal, &t);
+                    const hit_t hit = raycast(scene, orig, dir, &point, &normal, &t);
+                    const int shape = hit.shape;
                     if (zero_dir) st.zero_dir_segments++; else st.segments++;
                     if (logging && nvlog < max_vertices) {
                         drt_oracle_vertex* L = &vertices[nvlog++];
@@ -301,7 +367,7 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                         L->path = (double)path;
                         L->depth = depth;
                         for (int c = 0; c < 3; ++c) { L->o[c] = orig.v[c]; L->d[c] = dir.v[c]; }
-                        L->shape = shape;
+                        L->shape = shape >= 0 ? hit.flat : -1;
                         if (shape >= 0) {
                             L->t = t;
                             for (int c = 0; c < 3; ++c) { L->p[c] = point.v[c]; L->n[c] = normal.v[c]; }
@@ -314,7 +380,7 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                         break;
                     }
                     const drt_shape_desc* sh = &scene->shapes[shape];
-                    const drt_material_desc* m = sh->material >= 0 ? &scene->materials[sh->material] : NULL;
+                    const drt_material_desc* m = hit.material >= 0 ? &scene->materials[hit.material] : NULL;
                     vertex_t* v = &vtx[nv++];
                     v->p = p;
                     v->emis_param = sh->emitter >= 0 ? scene->emitters[sh->emitter].param : -1;

@@ -82,6 +82,14 @@ SMALL = [
          dump_paths=128),
     dict(name="g8_random8_36x36x6_d5", scene="random8", width=36, height=36, spp=6, min_bounces=5,
          absorb=1.0, seed=2),
+    # triangle meshes: the reference has none; these run the brute-force Triangle plugin of
+    # oracle/ref_harness.cpp inside the unmodified reference path tracer
+    dict(name="g9_mesh6x8_40x30x4", scene="mesh6x8", width=40, height=30, spp=4, min_bounces=3,
+         absorb=0.3, seed=3, dump_paths=128),
+    dict(name="g10_mesh10x12f5_32x32x4_d4", scene="mesh10x12f5", width=32, height=32, spp=4,
+         min_bounces=4, absorb=1.0, seed=5, adjoint_seed=2),
+    dict(name="g11_mesh40x40_48x48x4_d5", scene="mesh40x40", width=48, height=48, spp=4, min_bounces=5,
+         absorb=1.0, seed=9),
 ]
 BIG = [
     dict(name="c1_cornell_256x256x8_d4", scene="cornell", width=256, height=256, spp=8,

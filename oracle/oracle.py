@@ -127,6 +127,14 @@ def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, d
         f.write(f"emitters {len(scene.emitters)}\n")
         for p in scene.emitters:
             f.write(f"{p}\n")
+        if scene.meshes:
+            f.write(f"meshes {len(scene.meshes)}\n")
+            for v, idx, fm in scene.meshes:
+                f.write(f"{len(v)} {len(idx)} {int(fm is not None)}\n")
+                for x in v:
+                    f.write(f"{float(x[0])!r} {float(x[1])!r} {float(x[2])!r}\n")
+                for t in range(len(idx)):
+                    f.write(f"{int(idx[t][0])} {int(idx[t][1])} {int(idx[t][2])}" + (f" {int(fm[t])}" if fm is not None else "") + "\n")
         f.write(f"shapes {len(scene.shapes)}\n")
         for t, m, e, p in scene.shapes:
             f.write(f"{t} {m} {e} {p[0]!r} {p[1]!r} {p[2]!r} {p[3]!r}\n")

@@ -16,7 +16,9 @@
 //   params P            then P lines:  r g b requires_grad
 //   materials M         then M lines:  type param exponent
 //   emitters E          then E lines:  param
-//   shapes S            then S lines:  type material emitter p0 p1 p2 p3
+//   meshes M            then per mesh: "nv nt has_face_material", nv lines "x y z", nt lines
+//                       "i j k [material]"           (must precede shapes)
+//   shapes S            then S lines:  type material emitter p0 p1 p2 p3   (type 2: p0 = mesh)
 //   camera W H vfov ex ey ez fx fy fz rx ry rz ux uy uz
 //   render spp min_bounces absorb seed rng_mode(0 keyed,1 libc) backward dump_paths
 //   adjoint <file|none>   (raw f32 W*H*3)
@@ -24,6 +26,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <array>
 #include <chrono>
 #include <fstream>
 #include <memory>
@@ -133,6 +136,45 @@ private:
     mutable double m_last_t = 0;
 };
 
+// EXTENSION: the reference has no triangles.  This brute-force triangle is a plain plugin of the
+// reference's Shape<T> interface (shape.hpp:11-35) and defines the semantics every other
+// implementation here must reproduce: two-sided Moller-Trumbore, hit iff t > 0 (like
+// shape.hpp:55), geometric normal never flipped (like shape.hpp:105-106).
+class Triangle : public drt::Shape<T> {
+public:
+    Triangle(V3 a, V3 b, V3 c, std::shared_ptr<drt::BxDF<T>> bxdf, std::shared_ptr<drt::Emitter<T>> emitter)
+      : drt::Shape<T>(bxdf, emitter), m_v0(a), m_e1(b - a), m_e2(c - a)
+    {
+        m_n = drt::normalize(drt::cross(m_e1, m_e2));
+    }
+    bool intersect(V3 orig, V3 dir, double& t) const override
+    {
+        V3 pvec = drt::cross(dir, m_e2);
+        double det = drt::dot(m_e1, pvec);
+        if (det == 0)
+            return false;
+        double inv = 1 / det;
+        V3 tvec = orig - m_v0;
+        double u = drt::dot(tvec, pvec) * inv;
+        if (u < 0 || u > 1)
+            return false;
+        V3 qvec = drt::cross(tvec, m_e1);
+        double v = drt::dot(dir, qvec) * inv;
+        if (v < 0 || u + v > 1)
+            return false;
+        t = drt::dot(m_e2, qvec) * inv;
+        return t > 0;
+    }
+    V3 normal(V3) const override { return m_n; }
+private:
+    V3 m_v0, m_e1, m_e2, m_n;
+};
+
+struct MeshData {
+    std::vector<V3> verts;
+    std::vector<std::array<int, 4>> tris;   // i, j, k, material (-1 = the shape's)
+};
+
 static void die(const char* msg)
 {
     fprintf(stderr, "ref_harness: %s\n", msg);
@@ -154,6 +196,7 @@ int main(int argc, char** argv)
     std::vector<std::shared_ptr<drt::BxDF<T>>> materials;
     std::vector<std::shared_ptr<drt::Emitter<T>>> emitters;
     std::vector<std::unique_ptr<drt::Shape<T>>> shapes;
+    std::vector<MeshData> meshes;
     int W = 0, H = 0, spp = 1, min_bounces = 1, backward = 0, dump_paths = 0;
     double vfov = 1.3963, absorb = 0.5;
     V3 eye(0.), fwd(0.), right(0.), up(0.);
@@ -186,13 +229,38 @@ int main(int argc, char** argv)
                 int param; in >> param;
                 emitters.push_back(std::make_shared<drt::AreaEmitter<T>>(params.at(param)));
             }
+        } else if (tok == "meshes") {
+            int n; in >> n;
+            for (int m = 0; m < n; ++m) {
+                int nv, nt, has_fm; in >> nv >> nt >> has_fm;
+                MeshData md;
+                for (int i = 0; i < nv; ++i) { double x, y, z; in >> x >> y >> z; md.verts.push_back(V3{x, y, z}); }
+                for (int i = 0; i < nt; ++i) {
+                    std::array<int, 4> t{0, 0, 0, -1};
+                    in >> t[0] >> t[1] >> t[2];
+                    if (has_fm) in >> t[3];
+                    md.tris.push_back(t);
+                }
+                meshes.push_back(std::move(md));
+            }
         } else if (tok == "shapes") {
             int n; in >> n;
+            int flat = 0;
             for (int i = 0; i < n; ++i) {
                 int type, mat, emi; double p0, p1, p2, p3;
                 in >> type >> mat >> emi >> p0 >> p1 >> p2 >> p3;
                 std::shared_ptr<drt::BxDF<T>> bx = mat >= 0 ? materials.at(mat) : nullptr;
                 std::shared_ptr<drt::Emitter<T>> em = emi >= 0 ? emitters.at(emi) : nullptr;
+                if (type == DRT_SHAPE_MESH) {
+                    // a mesh stands for its triangles, in index order, at this scene position
+                    const MeshData& md = meshes.at((size_t)p0);
+                    for (const auto& t : md.tris) {
+                        std::shared_ptr<drt::BxDF<T>> tb = t[3] >= 0 ? materials.at(t[3]) : bx;
+                        std::unique_ptr<drt::Shape<T>> tri(new Triangle(md.verts.at(t[0]), md.verts.at(t[1]), md.verts.at(t[2]), tb, em));
+                        shapes.emplace_back(new Probe(std::move(tri), flat++, tb, em));
+                    }
+                    continue;
+                }
                 std::unique_ptr<drt::Shape<T>> inner;
                 if (type == DRT_SHAPE_PLANE)
                     inner.reset(new drt::Plane<T>(V3{p0, p1, p2}, p3, bx, em));
@@ -200,7 +268,7 @@ int main(int argc, char** argv)
                     inner.reset(new drt::Sphere<T>(V3{p0, p1, p2}, p3, bx, em));
                 else
                     die("unsupported shape type");
-                shapes.emplace_back(new Probe(std::move(inner), i, bx, em));
+                shapes.emplace_back(new Probe(std::move(inner), flat++, bx, em));
             }
         } else if (tok == "camera") {
             in >> W >> H >> vfov;

@@ -53,7 +53,8 @@ def case_inputs(pkg, case):
 
 SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_64x64x8_rr",
                  "g4_specular_64x64x8_d8", "g4b_emissive_wall_48x32x8_adj", "g7_random3_40x30x6",
-                 "g8_random8_36x36x6_d5"]
+                 "g8_random8_36x36x6_d5", "g9_mesh6x8_40x30x4", "g10_mesh10x12f5_32x32x4_d4",
+                 "g11_mesh40x40_48x48x4_d5"]
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,88 @@
+"""Triangle meshes on the device (extension behind the Shape plugin surface; BASELINE config 4
+shape): the BVH traversal of K2 against the brute-force oracle, whose triangle semantics are
+pinned by a Triangle plugin running inside the unmodified reference (tests/golden/g9..g11)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def grad_rel_err(got, want):
+    return float(np.abs(got - want).max() / np.abs(want).max())
+
+
+def test_50k_triangle_bvh_matches_brute_force(pkg, hip, oracle):
+    """160 x 160 displaced sphere = 50,880 triangles: every closest hit found through the BVH must
+    be the one the oracle's linear scan finds (f64 mode: identical paths, gradients to 1e-9)."""
+    scene = pkg.cornell_with_mesh(160, 160)
+    assert len(scene.meshes[0][1]) == 50880
+    cam = pkg.cornell_camera(40, 32)
+    rp = pkg.RenderParams(spp=2, min_bounces=4, absorb=1.0, seed=6)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True, f64=True)
+    assert st["segments"] == ref["stats"]["segments"]
+    assert grad_rel_err(grads, ref["grads"]) < 1e-9
+    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    assert abs(st["segments"] - ref["stats"]["segments"]) <= 64
+    scale = np.abs(ref["image"]).max()
+    bad = np.abs(img.astype(np.float64) - ref["image"]).max(-1) > 2e-4 * scale
+    assert bad.mean() <= 5e-3
+    assert grad_rel_err(grads, ref["grads"]) <= 1e-4 + 4.0 * bad.sum() / bad.size
+
+
+def test_per_face_parameters_use_the_general_gradient_path(pkg, hip, oracle):
+    """12 per-face albedos + the 4 Cornell parameters = 16 > 8: K6's LDS columns + fp64 atomics."""
+    scene = pkg.cornell_with_mesh(24, 24, per_face_params=12)
+    assert scene.n_params == 16
+    cam = pkg.cornell_camera(48, 48)
+    rp = pkg.RenderParams(spp=4, min_bounces=2, absorb=0.3, seed=8)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    _, g64, st = hip.render(cam, rp, backward=True, f64=True)
+    assert st["segments"] == ref["stats"]["segments"]
+    np.testing.assert_allclose(g64, ref["grads"], rtol=1e-9, atol=1e-12)
+    _, g32, _ = hip.render(cam, rp, backward=True)
+    assert grad_rel_err(g32, ref["grads"]) <= 1e-4
+    assert np.abs(ref["grads"][4:]).min() > 0        # every face parameter is reached
+
+
+def test_mesh_scene_properties_at_scale(pkg, hip):
+    """Config-4-shaped render (50k triangles, 256 x 256 x 16): linearity in emission, determinism,
+    sharding."""
+    scene = pkg.cornell_with_mesh(160, 160)
+    cam = pkg.cornell_camera(256, 256)
+    rp = pkg.RenderParams(spp=16, min_bounces=6, absorb=1.0, seed=2)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    total = img.astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[3] * np.array(scene.params[3]), total, rtol=2e-6)
+    img2, grads2, st2 = hip.render(cam, rp, backward=True)
+    np.testing.assert_array_equal(img, img2)
+    np.testing.assert_array_equal(grads, grads2)
+    acc = np.zeros_like(img)
+    gsum = np.zeros_like(grads)
+    for s in range(2):
+        im_s, g_s, _ = hip.render(cam, dataclasses.replace(rp, shard=s, n_shards=2), backward=True)
+        rows = pkg.shard_rows(256, rp.band_rows, 2, s)
+        acc[rows] = im_s[rows]
+        gsum += g_s
+    np.testing.assert_array_equal(acc, img)
+    np.testing.assert_allclose(gsum, grads, rtol=1e-9)
+
+
+def test_mesh_errors(pkg, hip):
+    scene = pkg.cornell_with_mesh(6, 8)
+    v, idx, fm = scene.meshes[0]
+    bad = idx.copy()
+    bad[3, 1] = len(v) + 5
+    scene.meshes[0] = (v, bad, fm)
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
+        hip.upload_scene(scene)
+    scene.meshes[0] = (v, idx, np.full(len(idx), 99, np.int32))
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
+        hip.upload_scene(scene)
+    hip.upload_scene(pkg.cornell_box())          # the context is still usable
