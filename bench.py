@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scene", default="cornell", help="cornell (headline) | cornell_specular | mesh<lat>x<lon>[f<n>] | random<seed>")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,13 +57,15 @@ def main():
     if world != max(1, a.gpus):
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if world > 1:
+    # launched by torch.distributed.run (also with one rank: exercises the RCCL path on one GPU)
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
-    scene = pkg.cornell_box()
+    scene = pkg.scene_by_name(a.scene)
     cam = pkg.cornell_camera(a.width, a.height)
     backward = not a.forward_only
     rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
@@ -78,15 +81,15 @@ def main():
     def step(timing=False):
         st = r.render_device(cam, rp, out_rgb.data_ptr(), grad.data_ptr() if backward else 0,
                              backward=backward, timing=timing, sync=False)
-        if world > 1 and backward:
+        if use_dist and backward:
             with torch.cuda.stream(ext):
-                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)   # the ONE collective of the path
         return st
 
     def fence():
         r.synchronize()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -97,7 +100,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -116,7 +119,7 @@ def main():
     fence()
     segments = stats["segments"]
     paths = stats["paths"]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([segments, paths], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_segments, total_paths = float(t[0].item()), float(t[1].item())
@@ -184,7 +187,7 @@ def main():
             "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell box (render.cpp:26-59) {a.width}x{a.height}, "
+            "config": {"workload": ("" if a.scene == "cornell" else f"[scene {a.scene}] ") + f"cornell box (render.cpp:26-59) {a.width}x{a.height}, "
                                    f"{a.spp} spp per GPU, depth {a.depth} (-b {a.depth} -p 1), "
                                    f"{'fwd + radiative-backprop grads of 4 params' if backward else 'fwd only'}",
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
@@ -193,7 +196,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     r.close()

@@ -1,9 +1,9 @@
 // drt_bvh.h -- host-side BVH construction for the triangle-mesh extension (all meshes of a scene
-// share ONE tree).  Binned-SAH top-down build, then a THREADED layout: every node carries a
-// hit link (first child, or the leaf's triangle range) and a miss link (where to continue when
-// the box is missed or the leaf is done), so the device traverses without a stack.  Links are
-// explicit, so the physical order is free: the first `top` nodes are the top of the tree in
-// breadth-first order (K2 stages them in LDS), the rest follow depth-first (subtrees contiguous).
+// share ONE tree).  Binned-SAH top-down build with a bounded depth, emitted as interior nodes
+// that carry the boxes of BOTH children (one fetch on the device yields two box tests and the
+// near/far order); leaves are not nodes, a child link is either an interior node index or a
+// triangle range.  The first `top` nodes are the top of the tree in breadth-first order (K2 stages
+// them in LDS), the rest follow depth-first (subtrees contiguous).
 #pragma once
 
 #include <algorithm>
@@ -23,19 +23,22 @@ struct Tri {
     uint32_t ids;         // material | emitter << 16 (0xFFFF = none)
 };
 
+// child link: bit 31 clear = interior node index; bit 31 set = leaf, (first << 3) | count in the
+// low bits (count 0 = empty child, its box is inverted so it is never entered)
 struct Node {
-    double lo[3], hi[3];
-    uint32_t hit;         // interior: index of the first child; leaf: 0x80000000 | first << 3 | count
-    uint32_t miss;        // next node when this one is missed / finished; 0xFFFFFFFF = done
+    double lo[2][3], hi[2][3];   // [0] = left child, [1] = right child
+    uint32_t child[2];
 };
 
-constexpr uint32_t kEnd = 0xFFFFFFFFu;
+constexpr uint32_t kLeaf = 0x80000000u;
 constexpr int kMaxLeaf = 4;
+constexpr int kMaxDepth = 30;     // the device keeps a 32-entry traversal stack per lane
 
 struct Built {
-    std::vector<Node> nodes;      // threaded, final order
+    std::vector<Node> nodes;      // final order, root = 0
     std::vector<uint32_t> order;  // triangle indices (into the input) in leaf order
     uint32_t top = 0;             // nodes [0, top) are the breadth-first top of the tree
+    int depth = 0;
 };
 
 namespace detail {
@@ -82,8 +85,11 @@ struct Builder {
         }
     }
 
-    int build(uint32_t first, uint32_t count)
+    int max_depth_seen = 0;
+
+    int build(uint32_t first, uint32_t count, int depth = 0)
     {
+        max_depth_seen = std::max(max_depth_seen, depth);
         const int me = (int)tmp.size();
         tmp.emplace_back();
         for (int a = 0; a < 3; ++a) { tmp[me].lo[a] = INFINITY; tmp[me].hi[a] = -INFINITY; }
@@ -97,11 +103,15 @@ struct Builder {
         tmp[me].count = count;
         if (count <= 2)
             return me;
+        // depth bound: once the remaining levels are only enough for a balanced tree, split by median
+        int need = 0;
+        while ((1u << need) * (uint32_t)kMaxLeaf < count) ++need;
+        const bool force_median = depth + need + 1 >= kMaxDepth;
         // binned SAH over the widest centroid axis first, then the others
         constexpr int B = 16;
         double best = INFINITY;
         int best_axis = -1, best_bin = -1;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3 && !force_median; ++a) {
             const double ext = chi[a] - clo[a];
             if (!(ext > 0))
                 continue;
@@ -138,9 +148,8 @@ struct Builder {
             }
         }
         const double leaf_cost = count * area(tmp[me].lo, tmp[me].hi);
-        if (best_axis < 0 || (count <= (uint32_t)kMaxLeaf && best >= leaf_cost))
-            if (count <= (uint32_t)kMaxLeaf)
-                return me;
+        if (count <= (uint32_t)kMaxLeaf && (best_axis < 0 || best >= leaf_cost))
+            return me;
         uint32_t mid;
         if (best_axis >= 0) {
             const double ext = chi[best_axis] - clo[best_axis];
@@ -151,12 +160,18 @@ struct Builder {
             });
             mid = (uint32_t)(it - idx.begin());
         } else {
-            mid = first + count / 2;      // coincident centroids: split the list
+            // median split along the widest centroid axis (balanced: bounds the depth)
+            int ax = 0;
+            for (int a2 = 1; a2 < 3; ++a2)
+                if (chi[a2] - clo[a2] > chi[ax] - clo[ax]) ax = a2;
+            mid = first + count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
+                             [&](uint32_t x, uint32_t y) { return cen[x * 3 + ax] < cen[y * 3 + ax]; });
         }
         if (mid == first || mid == first + count)
             mid = first + count / 2;
-        const int l = build(first, mid - first);
-        const int r = build(mid, first + count - mid);
+        const int l = build(first, mid - first, depth + 1);
+        const int r = build(mid, first + count - mid, depth + 1);
         tmp[me].left = l;
         tmp[me].right = r;
         tmp[me].count = 0;
@@ -176,12 +191,26 @@ inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
     detail::Builder b(tris);
     b.tmp.reserve(tris.size() * 2);
     b.build(0, (uint32_t)tris.size());
+    out.depth = b.max_depth_seen;
     const std::vector<detail::Tmp>& t = b.tmp;
+    out.order = b.idx;
+    auto leaf_link = [&](int u) { return kLeaf | (t[u].first << 3) | t[u].count; };
+    auto set_child = [&](Node& nd, int side, int u, uint32_t link) {
+        for (int a = 0; a < 3; ++a) { nd.lo[side][a] = t[u].lo[a] - pad; nd.hi[side][a] = t[u].hi[a] + pad; }
+        nd.child[side] = link;
+    };
+    if (t[0].left < 0) {          // the whole scene is one leaf: a root with one real child
+        Node nd;
+        set_child(nd, 0, 0, leaf_link(0));
+        for (int a = 0; a < 3; ++a) { nd.lo[1][a] = INFINITY; nd.hi[1][a] = -INFINITY; }
+        nd.child[1] = kLeaf;
+        out.nodes.push_back(nd);
+        out.top = 1;
+        return out;
+    }
+    // interior nodes only; physical order: breadth-first prefix of at most max_top, then depth-first
     const uint32_t n = (uint32_t)t.size();
-
-    // physical order: breadth-first prefix of at most max_top nodes, then depth-first
-    std::vector<uint32_t> pos(n, kEnd), at;
-    at.reserve(n);
+    std::vector<uint32_t> pos(n, 0xFFFFFFFFu), at;
     std::vector<int> frontier;
     {
         std::queue<int> q;
@@ -191,44 +220,27 @@ inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
             q.pop();
             pos[u] = (uint32_t)at.size();
             at.push_back((uint32_t)u);
-            if (t[u].left >= 0) { q.push(t[u].left); q.push(t[u].right); }
+            if (t[t[u].left].left >= 0) q.push(t[u].left);
+            if (t[t[u].right].left >= 0) q.push(t[u].right);
         }
         while (!q.empty()) { frontier.push_back(q.front()); q.pop(); }
     }
     out.top = (uint32_t)at.size();
-    std::vector<int> stack;
-    for (auto it = frontier.rbegin(); it != frontier.rend(); ++it)
-        stack.push_back(*it);
+    std::vector<int> stack(frontier.rbegin(), frontier.rend());
     while (!stack.empty()) {
         const int u = stack.back();
         stack.pop_back();
         pos[u] = (uint32_t)at.size();
         at.push_back((uint32_t)u);
-        if (t[u].left >= 0) { stack.push_back(t[u].right); stack.push_back(t[u].left); }
+        if (t[t[u].right].left >= 0) stack.push_back(t[u].right);
+        if (t[t[u].left].left >= 0) stack.push_back(t[u].left);
     }
-
-    // links: miss(root) = end; left child's miss = right child; right child's miss = parent's miss
-    std::vector<uint32_t> miss(n, kEnd);
-    {
-        std::vector<int> st{0};
-        while (!st.empty()) {
-            const int u = st.back();
-            st.pop_back();
-            if (t[u].left >= 0) {
-                miss[t[u].left] = pos[t[u].right];
-                miss[t[u].right] = miss[u];
-                st.push_back(t[u].left);
-                st.push_back(t[u].right);
-            }
-        }
-    }
-    out.order = b.idx;
-    out.nodes.resize(n);
-    for (uint32_t u = 0; u < n; ++u) {
-        Node& nd = out.nodes[pos[u]];
-        for (int a = 0; a < 3; ++a) { nd.lo[a] = t[u].lo[a] - pad; nd.hi[a] = t[u].hi[a] + pad; }
-        nd.miss = miss[u];
-        nd.hit = t[u].left >= 0 ? pos[t[u].left] : (0x80000000u | (t[u].first << 3) | t[u].count);
+    out.nodes.resize(at.size());
+    for (size_t i = 0; i < at.size(); ++i) {
+        const int u = (int)at[i];
+        const int l = t[u].left, r = t[u].right;
+        set_child(out.nodes[i], 0, l, t[l].left >= 0 ? pos[l] : leaf_link(l));
+        set_child(out.nodes[i], 1, r, t[r].left >= 0 ? pos[r] : leaf_link(r));
     }
     return out;
 }

@@ -64,23 +64,28 @@ __device__ inline double pid_pack(double, uint32_t pid) { return (double)pid; }
 __device__ inline uint32_t pid_unpack(float v) { return __float_as_uint(v); }
 __device__ inline uint32_t pid_unpack(double v) { return (uint32_t)v; }
 
-// ---- triangle meshes (extension): one threaded BVH over all triangles of the scene -----------
-//   node_lo[i] = (box.lo.xyz, hit link)   hit link: first child, or 0x80000000 | first << 3 | count
-//   node_hi[i] = (box.hi.xyz, miss link)  miss link: next node when missed / done, 0xFFFFFFFF = end
+// ---- triangle meshes (extension): one BVH over all triangles of the scene ---------------------
+// Interior node i = four 16-byte lanes (64 B in f32), the boxes of BOTH children live in the parent:
+//   node[i][0] = (left.lo.xyz,  left link)     link: bit 31 clear = interior node index,
+//   node[i][1] = (left.hi.xyz,  right link)          bit 31 set   = leaf: first << 3 | count
+//   node[i][2] = (right.lo.xyz, -)
+//   node[i][3] = (right.hi.xyz, -)
 //   tri_a/b/c[j] (leaf order) = (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, global index, flat index, -)
 //   tri_shade[g] (global triangle order) = (normal.xyz, material | emitter << 16)
 template <typename R>
 struct DevBvh {
-    const typename Q4<R>::T* node_lo;
-    const typename Q4<R>::T* node_hi;
+    const typename Q4<R>::T* node;      // [n_nodes][4]
     const typename Q4<R>::T* tri_a;
     const typename Q4<R>::T* tri_b;
     const typename Q4<R>::T* tri_c;
     const typename Q4<R>::T* tri_shade;
     uint32_t n_nodes, n_top, n_tris, pad;
 };
-#define DRT_BVH_END 0xFFFFFFFFu
-#define DRT_BVH_LDS_NODES_F32 1024   // 32 KB of LDS per block (f32); f64 stages half as many
+#define DRT_BVH_NONE 0xFFFFFFFFu
+#define DRT_BVH_LEAF 0x80000000u
+#define DRT_BVH_LDS_NODES_F32 128    // 8 KB of LDS per block (f32); f64 stages half as many
+#define DRT_BVH_STACK 32             // per-lane traversal stack in LDS (the builder bounds the depth at 30)
+#define DRT_BVH_REFILL 16            // idle lanes needed before the wave pulls new rays from its stream
 
 // ---- small vector math -----------------------------------------------------------------------
 template <typename R>
@@ -190,14 +195,14 @@ __device__ inline bool tri_intersect(V3<R> v0, V3<R> e1, V3<R> e2, V3<R> o, V3<R
     return t > R(0);
 }
 
-// conservative slab test against a (padded) box, limited to (0, tmax]
+// conservative slab test against a (padded) box, limited to (0, tmax]; tn = entry distance
 template <typename R>
-__device__ inline bool box_hit(V3<R> lo, V3<R> hi, V3<R> o, V3<R> inv_d, R tmax)
+__device__ inline bool box_hit(V3<R> lo, V3<R> hi, V3<R> o, V3<R> inv_d, R tmax, R& tn)
 {
     const R ax = (lo.x - o.x) * inv_d.x, bx = (hi.x - o.x) * inv_d.x;
     const R ay = (lo.y - o.y) * inv_d.y, by = (hi.y - o.y) * inv_d.y;
     const R az = (lo.z - o.z) * inv_d.z, bz = (hi.z - o.z) * inv_d.z;
-    const R tn = max_r(max_r(min_r(ax, bx), min_r(ay, by)), max_r(min_r(az, bz), R(0)));
+    tn = max_r(max_r(min_r(ax, bx), min_r(ay, by)), max_r(min_r(az, bz), R(0)));
     const R tf = min_r(min_r(max_r(ax, bx), max_r(ay, by)), min_r(max_r(az, bz), tmax));
     return tn <= tf;
 }

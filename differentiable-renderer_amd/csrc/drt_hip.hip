@@ -140,21 +140,27 @@ template <typename R>
 int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_bvh::Tri>& tris, DevBvh<R>* out)
 {
     typedef typename Q4<R>::T R4;
-    std::vector<R4> lo(b.nodes.size()), hi(b.nodes.size());
+    std::vector<R4> nodes(b.nodes.size() * 4);
     for (size_t i = 0; i < b.nodes.size(); ++i) {
         const drt_bvh::Node& n = b.nodes[i];
-        // boxes must stay conservative after rounding to R: round outwards
-        lo[i].x = (R)n.lo[0]; lo[i].y = (R)n.lo[1]; lo[i].z = (R)n.lo[2];
-        hi[i].x = (R)n.hi[0]; hi[i].y = (R)n.hi[1]; hi[i].z = (R)n.hi[2];
-        if (sizeof(R) == 4) {
-            R* l = &lo[i].x; R* h = &hi[i].x;
+        for (int side = 0; side < 2; ++side) {
+            R4& lo = nodes[i * 4 + side * 2];
+            R4& hi = nodes[i * 4 + side * 2 + 1];
+            R* l = &lo.x;
+            R* h = &hi.x;
             for (int a = 0; a < 3; ++a) {
-                if ((double)l[a] > n.lo[a]) l[a] = (R)nextafterf((float)l[a], -INFINITY);
-                if ((double)h[a] < n.hi[a]) h[a] = (R)nextafterf((float)h[a], INFINITY);
+                l[a] = (R)n.lo[side][a];
+                h[a] = (R)n.hi[side][a];
+                if (sizeof(R) == 4) {   // boxes must stay conservative after rounding: round outwards
+                    if ((double)l[a] > n.lo[side][a]) l[a] = (R)nextafterf((float)l[a], -INFINITY);
+                    if ((double)h[a] < n.hi[side][a]) h[a] = (R)nextafterf((float)h[a], INFINITY);
+                }
             }
+            lo.w = R(0);
+            hi.w = R(0);
         }
-        lo[i].w = link_bits(R(0), n.hit);
-        hi[i].w = link_bits(R(0), n.miss);
+        nodes[i * 4 + 0].w = link_bits(R(0), n.child[0]);
+        nodes[i * 4 + 1].w = link_bits(R(0), n.child[1]);
     }
     std::vector<R4> ta(b.order.size()), tb(b.order.size()), tc(b.order.size()), ts(tris.size());
     for (size_t j = 0; j < b.order.size(); ++j) {
@@ -169,8 +175,7 @@ int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_
         ts[t.global].w = link_bits(R(0), t.ids);
     }
     int rc;
-    if ((rc = upload_array(ctx, lo, &out->node_lo)) != DRT_OK) return rc;
-    if ((rc = upload_array(ctx, hi, &out->node_hi)) != DRT_OK) return rc;
+    if ((rc = upload_array(ctx, nodes, &out->node)) != DRT_OK) return rc;
     if ((rc = upload_array(ctx, ta, &out->tri_a)) != DRT_OK) return rc;
     if ((rc = upload_array(ctx, tb, &out->tri_b)) != DRT_OK) return rc;
     if ((rc = upload_array(ctx, tc, &out->tri_c)) != DRT_OK) return rc;

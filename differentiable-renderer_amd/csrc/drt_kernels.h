@@ -233,10 +233,17 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
 }
 
 // ---- K2 (scenes with triangle meshes) -----------------------------------------------------------
-// Same chunk sweep as k_intersect; per ray: the analytic shapes, then a stackless walk of the
-// threaded BVH.  The top of the tree (breadth-first prefix) is staged in LDS once per block, the
-// rest of the nodes and the triangles come from L2.  Exact ties keep the primitive that comes
-// first in the flattened scene, like the reference's linear scan (pathtracer.hpp:80).
+// One closest-hit query = the analytic shapes, then an ORDERED walk of the BVH (near child first,
+// far child on a 32-entry per-lane stack in LDS).  The top of the tree is staged in LDS once per
+// block; deeper nodes and the triangles come from L2.  Incoherent rays make traversal lengths
+// wildly different from lane to lane, so the kernel is organised around keeping lanes busy:
+//   * every wave owns a private STREAM of rays (its chunks of the address-ordered sweep); when
+//     DRT_BVH_REFILL lanes have finished, they are refilled from the stream with a wave ballot +
+//     prefix rank -- the same atomic-free wave-local trick as the queue regions;
+//   * interior nodes are walked in a tight inner loop and leaves are postponed until the lanes
+//     meet again ("while-while"), so triangle tests run with many lanes active.
+// Exact ties keep the primitive that comes first in the flattened scene, like the reference's
+// linear scan (pathtracer.hpp:80): (t, flat index) is compared lexicographically.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
@@ -246,57 +253,112 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES_F32 * sizeof(float) / sizeof(R);
-    __shared__ R4 s_lo[LDS_NODES], s_hi[LDS_NODES];
+    __shared__ R4 s_node[LDS_NODES][4];
+    __shared__ uint32_t s_stack[DRT_BVH_STACK][DRT_BLOCK];
     const uint32_t n_lds = bvh.n_top < LDS_NODES ? bvh.n_top : LDS_NODES;
-    for (uint32_t i = threadIdx.x; i < n_lds; i += blockDim.x) {
-        s_lo[i] = bvh.node_lo[i];
-        s_hi[i] = bvh.node_hi[i];
-    }
+    for (uint32_t i = threadIdx.x; i < n_lds * 4; i += blockDim.x)
+        s_node[i >> 2][i & 3] = bvh.node[i];
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t tid = threadIdx.x;
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const uint32_t n_chunks = a.n_regions << (a.region_shift - 6);
+    const uint32_t cpr_shift = a.region_shift - 6;
+    const uint32_t n_chunks = a.n_regions << cpr_shift;
     const int n_shapes = sc->n_shapes;
-    for (uint32_t c = grid_wave(); c < n_chunks; c += n_waves) {
-        const uint32_t slot = chunk_slot(a, counts_k, c, n_chunks, lane);
-        if (slot == 0xFFFFFFFFu)
-            continue;
-        const R4 ra = ray_a[slot];
-        const R2 rb = ray_b[slot];
-        const V3<R> o = mk<R>(ra.x, ra.y, ra.z), d = mk<R>(ra.w, rb.x, rb.y);
-        R tmin = (R)INFINITY;
-        int prim = -1;
-        uint32_t best_flat = 0xFFFFFFFFu;
-        for (int s = 0; s < n_shapes; ++s) {
-            const DevShape<R> sh = sc->shapes[s];
-            if (sh.type == DRT_SHAPE_MESH)
-                continue;
-            R t;
-            const uint32_t flat = (uint32_t)sc->flat[s];
-            if (shape_intersect(sh, o, d, t) && (t < tmin || (t == tmin && flat < best_flat))) {
-                tmin = t;
-                prim = s;
-                best_flat = flat;
+
+    // the wave's stream: chunks next_chunk, next_chunk + n_waves, ...; the current chunk's rays are
+    // slots [cur_base + cur_off, cur_base + cur_cnt)
+    uint32_t next_chunk = grid_wave(), cur_base = 0, cur_cnt = 0, cur_off = 0;
+
+    bool active = false;
+    uint32_t slot = 0, cur = DRT_BVH_NONE, best_flat = 0xFFFFFFFFu;
+    int sp = 0, prim = -1;
+    V3<R> o = mk<R>(R(0), R(0), R(0)), d = o, inv_d = o;
+    R tmin = (R)INFINITY;
+
+    for (;;) {
+        // ---- refill idle lanes from the stream
+        if ((uint32_t)__popcll(__ballot(!active)) >= DRT_BVH_REFILL) {
+            bool want = !active, fresh = false;
+            for (;;) {
+                if (cur_off >= cur_cnt) {
+                    if (next_chunk >= n_chunks)
+                        break;
+                    const uint32_t w = next_chunk >> cpr_shift;
+                    const uint32_t off = (next_chunk - (w << cpr_shift)) * DRT_WAVE;
+                    const uint32_t cnt = __builtin_amdgcn_readfirstlane(counts_k[w]);
+                    cur_base = (w << a.region_shift) + off;
+                    cur_cnt = cnt > off ? (cnt - off < DRT_WAVE ? cnt - off : DRT_WAVE) : 0;
+                    cur_off = 0;
+                    next_chunk += n_waves;
+                    continue;
+                }
+                const uint64_t wmask = __ballot(want);
+                if (wmask == 0)
+                    break;
+                const uint32_t n_want = (uint32_t)__popcll(wmask), avail = cur_cnt - cur_off;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
+                if (want && rank < avail) {
+                    slot = cur_base + cur_off + rank;
+                    const R4 ra = ray_a[slot];
+                    const R2 rb = ray_b[slot];
+                    o = mk<R>(ra.x, ra.y, ra.z);
+                    d = mk<R>(ra.w, rb.x, rb.y);
+                    inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+                    tmin = (R)INFINITY;
+                    prim = -1;
+                    best_flat = 0xFFFFFFFFu;
+                    cur = 0;            // root
+                    sp = 0;
+                    want = false;
+                    fresh = true;
+                    active = true;
+                }
+                cur_off += n_want < avail ? n_want : avail;
+            }
+            if (__any(fresh)) {
+                for (int s = 0; s < n_shapes; ++s) {
+                    const DevShape<R> sh = sc->shapes[s];
+                    if (sh.type == DRT_SHAPE_MESH)
+                        continue;
+                    const uint32_t flat = (uint32_t)sc->flat[s];
+                    R t;
+                    if (fresh && shape_intersect(sh, o, d, t) && (t < tmin || (t == tmin && flat < best_flat))) {
+                        tmin = t;
+                        prim = s;
+                        best_flat = flat;
+                    }
+                }
             }
         }
-        const V3<R> inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
-        uint32_t node = bvh.n_nodes ? 0u : DRT_BVH_END;
-        while (node != DRT_BVH_END) {
-            R4 nlo, nhi;
-            if (node < n_lds) { nlo = s_lo[node]; nhi = s_hi[node]; }
-            else { nlo = bvh.node_lo[node]; nhi = bvh.node_hi[node]; }
-            const uint32_t miss = pid_unpack(nhi.w);
-            if (!box_hit(mk<R>(nlo.x, nlo.y, nlo.z), mk<R>(nhi.x, nhi.y, nhi.z), o, inv_d, tmin)) {
-                node = miss;
-                continue;
+        if (!__any(active))
+            break;
+
+        // ---- interior nodes: tight loop, leaves postponed
+        while (active && !(cur & DRT_BVH_LEAF)) {
+            R4 n0, n1, n2, n3;
+            if (cur < n_lds) { n0 = s_node[cur][0]; n1 = s_node[cur][1]; n2 = s_node[cur][2]; n3 = s_node[cur][3]; }
+            else { const R4* p = bvh.node + (size_t)cur * 4; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; }
+            R tl, tr;
+            const bool hl = box_hit(mk<R>(n0.x, n0.y, n0.z), mk<R>(n1.x, n1.y, n1.z), o, inv_d, tmin, tl);
+            const bool hr = box_hit(mk<R>(n2.x, n2.y, n2.z), mk<R>(n3.x, n3.y, n3.z), o, inv_d, tmin, tr);
+            const uint32_t l0 = pid_unpack(n0.w), l1 = pid_unpack(n1.w);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                s_stack[sp++][tid] = left_first ? l1 : l0;
+                cur = left_first ? l0 : l1;
+            } else if (hl) {
+                cur = l0;
+            } else if (hr) {
+                cur = l1;
+            } else {
+                cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
             }
-            const uint32_t link = pid_unpack(nlo.w);
-            if (!(link & 0x80000000u)) {
-                node = link;
-                continue;
-            }
-            const uint32_t first = (link & 0x7FFFFFFFu) >> 3, count = link & 7u;
+        }
+        // ---- leaves (cur is a leaf link or NONE)
+        if (active && cur != DRT_BVH_NONE) {
+            const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, count = cur & 7u;
             for (uint32_t j = first; j < first + count; ++j) {
                 const R4 ta = bvh.tri_a[j], tb = bvh.tri_b[j], tc = bvh.tri_c[j];
                 R t;
@@ -309,12 +371,15 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     }
                 }
             }
-            node = miss;
+            cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
-        HitRec<R> h;
-        h.t = tmin;
-        h.prim = prim;
-        hit[slot] = h;
+        if (active && cur == DRT_BVH_NONE) {
+            HitRec<R> h;
+            h.t = tmin;
+            h.prim = prim;
+            hit[slot] = h;
+            active = false;
+        }
     }
 }
 
