@@ -409,7 +409,8 @@ class DrtHipError(RuntimeError):
 
 
 _ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_destroy",
-                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render", "drt_hip_stream",
+                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render",
+                "drt_hip_render_gradient_image", "drt_hip_stream",
                 "drt_hip_synchronize", "drt_hip_last_error", "drt_hip_kernel_name"]
 
 
@@ -431,6 +432,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.drt_hip_update_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.drt_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
+    lib.drt_hip_render_gradient_image.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
+                                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
     lib.drt_hip_stream.argtypes = [C.c_void_p]
     lib.drt_hip_stream.restype = C.c_void_p
     lib.drt_hip_synchronize.argtypes = [C.c_void_p]
@@ -497,6 +500,27 @@ class HipRenderer:
                                      C.byref(stats))
         self._check(rc, "drt_hip_render")
         return img, grads, stats.as_dict()
+
+    def render_gradient_image(self, cam: Camera, rp: RenderParams, param: int,
+                              adjoint: Optional[np.ndarray] = None, f64: bool = False):
+        """Per-pixel gradient of ONE parameter (the reference's README figure).
+        -> (image float32 [H,W,3], gradient image float32 [H,W,3], stats dict)"""
+        assert self.scene is not None
+        d = rp.to_desc()
+        d.flags = (rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC)) | (RENDER_F64 if f64 else 0)
+        img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        gimg = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        adj_ptr = None
+        if adjoint is not None:
+            adjoint = np.ascontiguousarray(adjoint, dtype=np.float32)
+            adj_ptr = adjoint.ctypes.data_as(C.c_void_p)
+        stats = HipStats()
+        cd = cam.to_desc()
+        rc = self.lib.drt_hip_render_gradient_image(self.ctx, C.byref(cd), C.byref(d), param, adj_ptr,
+                                                    img.ctypes.data_as(C.c_void_p),
+                                                    gimg.ctypes.data_as(C.c_void_p), C.byref(stats))
+        self._check(rc, "drt_hip_render_gradient_image")
+        return img, gimg, stats.as_dict()
 
     def render_device(self, cam: Camera, rp: RenderParams, out_rgb_ptr: int, out_grad_ptr: int,
                       adjoint_ptr: int = 0, backward: bool = True, timing: bool = False,

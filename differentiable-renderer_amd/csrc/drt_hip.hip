@@ -48,7 +48,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], ray_c[2], hit, lacc, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
+    DevBuf ray_a[2], ray_b[2], ray_id[2], ray_c[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
@@ -259,7 +259,7 @@ template <typename R>
 int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                 const float* d_adjoint, float* d_out_rgb, bool backward, bool timing,
                 drt_hip_stats* st, uint32_t n_local_pixels, int depth_cap, size_t* n_count_words,
-                double* film)
+                double* film, int gimg_param = -1, double* gfilm = nullptr, float* d_out_gimg = nullptr)
 {
     typedef typename Q4<R>::T R4;
     const DevScene<R>* d_scene = sizeof(R) == 4 ? (const DevScene<R>*)ctx->d_scene_f
@@ -309,6 +309,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     }
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
+    if (gimg_param >= 0)
+        if ((rc = ensure(ctx, ctx->gpath, N * sizeof(R4))) != DRT_OK) return rc;
     if (backward) {
         if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
@@ -431,7 +433,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->launches[DRT_K_FILM]++;
                 st->units[DRT_K_FILM] += a.n_paths;
             }
-            if (backward && D > 0) {
+            if (backward && D > 0 && gimg_param >= 0) {
+                // gradient image: per-path gradient of one parameter, averaged per pixel by K5
+                if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_backward_image<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                   d_params, tape, nv, d_adjoint, (uint32_t)gimg_param, (R4*)ctx->gpath.p);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_BACKWARD]++;
+                hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
+                                   (const R4*)ctx->gpath.p, gfilm);
+            } else if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
 #define DRT_LAUNCH_BWD(NP)                                                                              \
     hipLaunchKernelGGL((k_backward<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params, \
@@ -456,6 +467,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if (film && d_out_rgb) {
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
                            a, n_local_pixels, film, d_out_rgb);
+    }
+    if (gimg_param >= 0 && gfilm && d_out_gimg) {
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
+                           a, n_local_pixels, gfilm, d_out_gimg);
     }
     HIPCHK(ctx, hipGetLastError());
     return DRT_OK;
@@ -508,7 +523,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->ray_c[0],
-                      &ctx->ray_c[1], &ctx->hit, &ctx->lacc, &ctx->tape, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
+                      &ctx->ray_c[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
     for (DevBuf* b : bufs)
         release(*b);
@@ -669,8 +684,34 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
     return DRT_OK;
 }
 
+static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                         const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
+                         int gimg_param, float* out_gimg);
+
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats)
+{
+    return render_common(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, -1, nullptr);
+}
+
+int drt_hip_render_gradient_image(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                                  int32_t param, const float* adjoint_rgb, float* out_rgb, float* out_grad_rgb,
+                                  drt_hip_stats* stats)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (!ctx->has_scene)
+        return fail(ctx, DRT_ERR_NO_SCENE, "render before upload_scene");
+    if (!rp || !out_grad_rgb || param < 0 || param >= ctx->n_params)
+        return fail(ctx, DRT_ERR_INVALID, "gradient image: bad parameter index or NULL output");
+    drt_render_params r = *rp;
+    r.flags |= DRT_RENDER_BACKWARD;
+    return render_common(ctx, cam, &r, adjoint_rgb, out_rgb, nullptr, stats, param, out_grad_rgb);
+}
+
+static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                         const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
+                         int gimg_param, float* out_gimg)
 {
     if (!ctx)
         return DRT_ERR_INVALID;
@@ -689,7 +730,7 @@ int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_rende
     const bool dev_out = (rp->flags & DRT_RENDER_DEVICE_OUT) != 0;
     const bool timing = (rp->flags & DRT_RENDER_TIMING) != 0;
     const bool f64 = (rp->flags & DRT_RENDER_F64) != 0;
-    if (backward && !out_param_grad)
+    if (backward && !out_param_grad && gimg_param < 0)
         return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
 
     auto t0 = std::chrono::steady_clock::now();
@@ -741,22 +782,36 @@ int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_rende
             }
         }
     }
+    float* d_gimg = nullptr;
+    if (gimg_param >= 0) {
+        const size_t fb = (size_t)(n_local_pixels ? n_local_pixels : 1) * 3 * sizeof(double);
+        if ((rc = ensure(ctx, ctx->gfilm, fb)) != DRT_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->gfilm.p, 0, fb, ctx->stream));
+        if (dev_out) {
+            d_gimg = out_gimg;
+        } else {
+            if ((rc = ensure(ctx, ctx->gimg_out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+            d_gimg = (float*)ctx->gimg_out.p;
+            if (n_shards > 1)
+                HIPCHK(ctx, hipMemcpyAsync(d_gimg, out_gimg, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
     size_t n_count_words = 0;
     double* d_film = out_rgb ? (double*)ctx->film.p : nullptr;   // no image requested: skip K5
     rc = DRT_OK;
     if (n_local_pixels > 0) {
         if (f64)
             rc = render_impl<double>(ctx, cam, rp, d_adj, d_out, backward, timing, &st, n_local_pixels,
-                                     depth_cap, &n_count_words, d_film);
+                                     depth_cap, &n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, d_gimg);
         else
             rc = render_impl<float>(ctx, cam, rp, d_adj, d_out, backward, timing, &st, n_local_pixels,
-                                    depth_cap, &n_count_words, d_film);
+                                    depth_cap, &n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, d_gimg);
     }
     if (rc != DRT_OK)
         return rc;
 
     // parameters that do not require grad keep a zero gradient (vector.hpp:156-162)
-    if (backward && dev_out) {
+    if (backward && dev_out && out_param_grad) {
         for (int p = 0; p < ctx->n_params; ++p)
             if (!ctx->requires_grad[p])
                 HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)p * 3, 0, 3 * sizeof(double), ctx->stream));
@@ -767,15 +822,17 @@ int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_rende
     if (!dev_out) {
         if (out_rgb)
             HIPCHK(ctx, hipMemcpyAsync(out_rgb, d_out, npix_all * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (backward)
+        if (backward && out_param_grad)
             HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_params * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (gimg_param >= 0 && out_gimg)
+            HIPCHK(ctx, hipMemcpyAsync(out_gimg, d_gimg, npix_all * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     ctx->h_segments = 0;
     if (stats && n_count_words)
         HIPCHK(ctx, hipMemcpyAsync(&ctx->h_segments, ctx->segtotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     if (sync)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!dev_out && backward)
+    if (!dev_out && backward && out_param_grad)
         for (int p = 0; p < ctx->n_params; ++p)
             if (!ctx->requires_grad[p])
                 out_param_grad[p * 3] = out_param_grad[p * 3 + 1] = out_param_grad[p * 3 + 2] = 0.0;

@@ -781,6 +781,71 @@ struct GradAcc<R, 0> {
     __device__ inline double get(R (*acc)[DRT_BLOCK], int row) const { return (double)acc[row][threadIdx.x]; }
 };
 
+// The walk of ONE path's tape (see the K6 comment above); every gradient contribution is handed
+// to acc.add(acc_lds, grad, parameter id, value).
+template <typename R, bool SMALL, typename Acc>
+__device__ inline void backward_path(const BatchArgs& a, const SceneLds<R>& lds, const R* __restrict__ params,
+                                     const TapeRec<R>* __restrict__ tape, size_t N, uint32_t i, int K, V3<R> g,
+                                     R inv_p_rr, Acc& acc, R (*acc_lds)[DRT_BLOCK], double* __restrict__ grad)
+{
+    V3<R> Ln = mk<R>(R(0), R(0), R(0));
+    for (int c0 = ((K - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
+        // prefix throughput at the start of this chunk (only for paths longer than a chunk)
+        V3<R> T = mk<R>(R(1), R(1), R(1));
+        for (int j = 0; j < c0; ++j) {
+            const TapeRec<R> tr = tape[(size_t)j * N + i];
+            T = T * load_param<R, SMALL>(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
+        }
+        R Tx[DRT_TAPE_CHUNK], Ty[DRT_TAPE_CHUNK], Tz[DRT_TAPE_CHUNK], M[DRT_TAPE_CHUNK];
+        uint32_t ID[DRT_TAPE_CHUNK];
+        TapeRec<R> trs[DRT_TAPE_CHUNK];
+#pragma unroll
+        for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+            if (c0 + j < K)
+                trs[j] = tape[(size_t)(c0 + j) * N + i];   // independent loads, all in flight
+#pragma unroll
+        for (int j = 0; j < DRT_TAPE_CHUNK; ++j) {
+            if (c0 + j < K) {
+                ID[j] = trs[j].ids;
+                M[j] = trs[j].m;
+                Tx[j] = T.x; Ty[j] = T.y; Tz[j] = T.z;
+                const uint32_t cid = ID[j] & 0xFFFFu;
+                if (cid != DRT_ID_NONE)
+                    T = T * load_param<R, SMALL>(lds, params, (int)cid) * M[j];
+            }
+        }
+#pragma unroll
+        for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
+            const int k = c0 + j;
+            if (k < K) {
+                const uint32_t cid = ID[j] & 0xFFFFu, eid = ID[j] >> 16;
+                const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
+                const V3<R> adj = g * mk<R>(Tx[j], Ty[j], Tz[j]);
+                V3<R> Lk = mk<R>(R(0), R(0), R(0));
+                if (eid != DRT_ID_NONE) {
+                    acc.add(acc_lds, grad, eid, adj * inv_pk);
+                    Lk = load_param<R, SMALL>(lds, params, (int)eid) * inv_pk;
+                }
+                if (cid != DRT_ID_NONE) {
+                    const V3<R> wgt = Ln * M[j];
+                    acc.add(acc_lds, grad, cid, adj * wgt);
+                    Lk = Lk + load_param<R, SMALL>(lds, params, (int)cid) * wgt;
+                }
+                Ln = Lk;
+            }
+        }
+    }
+}
+
+template <typename R>
+__device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ adjoint, uint32_t i)
+{
+    if (!adjoint)
+        return mk<R>(R(1), R(1), R(1));                       // render.cpp:80
+    const uint32_t gp = global_pixel(a, a.p0 + i % a.Pb);
+    return mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1], (R)adjoint[(size_t)gp * 3 + 2]);
+}
+
 template <typename R, int NP>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
@@ -802,59 +867,7 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
         const int K = (int)nv[i];
         if (K <= 0)
             continue;
-        V3<R> g = mk<R>(R(1), R(1), R(1));                     // render.cpp:80
-        if (adjoint) {
-            const uint32_t gp = global_pixel(a, a.p0 + i % a.Pb);
-            g = mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1],
-                      (R)adjoint[(size_t)gp * 3 + 2]);
-        }
-        V3<R> Ln = mk<R>(R(0), R(0), R(0));
-        for (int c0 = ((K - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
-            // prefix throughput at the start of this chunk (only for paths longer than a chunk)
-            V3<R> T = mk<R>(R(1), R(1), R(1));
-            for (int j = 0; j < c0; ++j) {
-                const TapeRec<R> tr = tape[(size_t)j * N + i];
-                T = T * load_param<R, SMALL>(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
-            }
-            R Tx[DRT_TAPE_CHUNK], Ty[DRT_TAPE_CHUNK], Tz[DRT_TAPE_CHUNK], M[DRT_TAPE_CHUNK];
-            uint32_t ID[DRT_TAPE_CHUNK];
-            TapeRec<R> trs[DRT_TAPE_CHUNK];
-#pragma unroll
-            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
-                if (c0 + j < K)
-                    trs[j] = tape[(size_t)(c0 + j) * N + i];   // independent loads, all in flight
-#pragma unroll
-            for (int j = 0; j < DRT_TAPE_CHUNK; ++j) {
-                if (c0 + j < K) {
-                    ID[j] = trs[j].ids;
-                    M[j] = trs[j].m;
-                    Tx[j] = T.x; Ty[j] = T.y; Tz[j] = T.z;
-                    const uint32_t cid = ID[j] & 0xFFFFu;
-                    if (cid != DRT_ID_NONE)
-                        T = T * load_param<R, SMALL>(lds, params, (int)cid) * M[j];
-                }
-            }
-#pragma unroll
-            for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
-                const int k = c0 + j;
-                if (k < K) {
-                    const uint32_t cid = ID[j] & 0xFFFFu, eid = ID[j] >> 16;
-                    const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
-                    const V3<R> adj = g * mk<R>(Tx[j], Ty[j], Tz[j]);
-                    V3<R> Lk = mk<R>(R(0), R(0), R(0));
-                    if (eid != DRT_ID_NONE) {
-                        ga.add(acc, grad, eid, adj * inv_pk);
-                        Lk = load_param<R, SMALL>(lds, params, (int)eid) * inv_pk;
-                    }
-                    if (cid != DRT_ID_NONE) {
-                        const V3<R> wgt = Ln * M[j];
-                        ga.add(acc, grad, cid, adj * wgt);
-                        Lk = Lk + load_param<R, SMALL>(lds, params, (int)cid) * wgt;
-                    }
-                    Ln = Lk;
-                }
-            }
-        }
+        backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, ga, acc, grad);
     }
 
     // block reduction in fp64: thread columns -> wave (shuffles) -> block (LDS), fixed order
@@ -875,6 +888,45 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
             for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
                 v += red[w][threadIdx.x];
         gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
+    }
+}
+
+// Gradient-image variant (README.md:142-145 of the reference): the gradient of ONE parameter, kept
+// per path instead of reduced -- written to a lacc-shaped buffer that K5 then averages per pixel.
+template <typename R>
+struct OneParamAcc {
+    uint32_t param;
+    V3<R> sum;
+    __device__ inline void add(R (*)[DRT_BLOCK], double* __restrict__, uint32_t id, V3<R> v)
+    {
+        if (id == param)
+            sum = sum + v;
+    }
+};
+
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_backward_image(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
+                 const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
+                 const float* __restrict__ adjoint, uint32_t param, typename Q4<R>::T* __restrict__ gpath)
+{
+    typedef typename Q4<R>::T R4;
+    __shared__ SceneLds<R> lds;
+    stage_scene(lds, sc, params);
+    const size_t N = a.n_paths;
+    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
+        OneParamAcc<R> acc;
+        acc.param = param;
+        acc.sum = mk<R>(R(0), R(0), R(0));
+        const int K = (int)nv[i];
+        if (K > 0)
+            backward_path<R, false>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, acc,
+                                    (R(*)[DRT_BLOCK]) nullptr, nullptr);
+        R4 o;
+        o.x = acc.sum.x; o.y = acc.sum.y; o.z = acc.sum.z; o.w = R(0);
+        gpath[i] = o;
     }
 }
 

@@ -168,6 +168,14 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad,
                    drt_hip_stats* stats);
+/* Per-pixel gradient image (the figure of the reference's README.md:142-145): like drt_hip_render
+ * with DRT_RENDER_BACKWARD, but instead of one summed gradient vector it returns
+ *   out_grad_rgb[pixel] = mean over the pixel's samples of d(seed . radiance) / d params[param]
+ * (the 3 channels of that one parameter), i.e. what `param.grad()` holds after back-propagating
+ * only this pixel's samples, divided by spp.  out_rgb may be NULL. */
+int drt_hip_render_gradient_image(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                                  int32_t param, const float* adjoint_rgb, float* out_rgb,
+                                  float* out_grad_rgb, drt_hip_stats* stats);
 /* stream the context launches on (a hipStream_t), for event timing / interop */
 void* drt_hip_stream(drt_hip_ctx* ctx);
 int drt_hip_synchronize(drt_hip_ctx* ctx);

@@ -281,6 +281,14 @@ typedef struct {
 
 #define ORACLE_MAX_VERTICES 4096
 
+static int32_t g_gimg_param = -1;
+static double* g_gimg_out = NULL;
+void drt_oracle_set_gradient_image(int32_t param, double* out)
+{
+    g_gimg_param = out ? param : -1;
+    g_gimg_out = out;
+}
+
 /* Camera::sample, camera.hpp:51-60 */
 static v3 camera_sample(const drt_camera_desc* cam, int x, int y, rng_t* rng)
 {
@@ -340,6 +348,13 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
         for (int x = 0; x < W && status == DRT_OK; ++x) {
             size_t pix = (size_t)y * W + x;
             v3 pixel = v3_make(0, 0, 0);
+            /* gradient image: what param.grad() gains from this pixel's samples alone */
+            double before[3] = {0, 0, 0};
+            if (want_grad && g_gimg_out && g_gimg_param >= 0 && g_gimg_param < scene->n_params)
+                for (int c = 0; c < 3; ++c) {
+                    before[c] = out_param_grad[g_gimg_param * 3 + c];
+                    out_param_grad[g_gimg_param * 3 + c] = 0.0;    /* fresh accumulator, like zeroing grad() */
+                }
             for (int i = 0; i < spp; ++i) {
                 uint64_t path = (uint64_t)pix * spp + i;
                 rng.path_key = drt_rng_path_key(rp->seed, path);
@@ -450,6 +465,12 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                 }
                 st.paths++;
             }
+            if (want_grad && g_gimg_out && g_gimg_param >= 0 && g_gimg_param < scene->n_params)
+                for (int c = 0; c < 3; ++c) {
+                    double* acc = &out_param_grad[g_gimg_param * 3 + c];
+                    g_gimg_out[pix * 3 + c] = *acc / (double)spp;
+                    *acc = before[c] + *acc;
+                }
             if (out_rgb) {
                 v3 mean = v3_div(pixel, (double)spp); /* render.cpp:82 */
                 for (int c = 0; c < 3; ++c)

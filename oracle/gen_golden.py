@@ -42,7 +42,8 @@ def run(case):
             -1, 2, (case["height"], case["width"], 3)).astype(np.float32)
     r = O.render_reference(scene, cam, rp, backward=True, adjoint=adjoint,
                            rng_mode=case.get("rng_mode", O.RNG_KEYED),
-                           dump_paths=case.get("dump_paths", 0))
+                           dump_paths=case.get("dump_paths", 0),
+                           grad_image_param=case.get("grad_image_param", -1))
     out = {"case": json.dumps(case), "grads": r["grads"],
            "segments": np.int64(r["stats"]["segments"]),
            "zero_dir_segments": np.int64(r["stats"]["zero_dir_segments"]),
@@ -58,6 +59,8 @@ def run(case):
         out["row_mean"] = r["image"].mean(1)
     if r["vertices"] is not None:
         out["vertices"] = r["vertices"]
+    if r.get("grad_image") is not None:
+        out["grad_image"] = r["grad_image"]
     path = os.path.join(GOLDEN, case["name"] + ".npz")
     np.savez_compressed(path, **out)
     print(f"{case['name']}: {r['stats']} mean={out['mean_rgb']} -> {os.path.getsize(path)} B")
@@ -88,6 +91,11 @@ SMALL = [
          absorb=0.3, seed=3, dump_paths=128),
     dict(name="g10_mesh10x12f5_32x32x4_d4", scene="mesh10x12f5", width=32, height=32, spp=4,
          min_bounces=4, absorb=1.0, seed=5, adjoint_seed=2),
+    # per-pixel gradient image of one parameter (the figure of the reference's README.md:142-145)
+    dict(name="g12_gradimage_red_48x36x8_d4", scene="cornell", width=48, height=36, spp=8, min_bounces=4,
+         absorb=1.0, seed=4, grad_image_param=0),
+    dict(name="g13_gradimage_white_40x40x6_rr", scene="cornell_specular", width=40, height=40, spp=6,
+         min_bounces=2, absorb=0.3, seed=6, grad_image_param=2, adjoint_seed=3),
     dict(name="g11_mesh40x40_48x48x4_d5", scene="mesh40x40", width=48, height=48, spp=4, min_bounces=5,
          absorb=1.0, seed=9),
 ]

@@ -66,14 +66,18 @@ def lib() -> C.CDLL:
             C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OracleStats),
             C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64]
         _lib.drt_oracle_render.restype = C.c_int
+        _lib.drt_oracle_set_gradient_image.argtypes = [C.c_int32, C.c_void_p]
+        _lib.drt_oracle_set_gradient_image.restype = None
         _lib.drt_oracle_rng_u31.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32]
         _lib.drt_oracle_rng_u31.restype = C.c_uint32
     return _lib
 
 
 def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray] = None,
-           rng_mode: int = RNG_KEYED, faithful: bool = False, dump_paths: int = 0):
-    """-> dict(image f64 [H,W,3], grads f64 [P,3] | None, stats dict, vertices f64 [n,16] | None)"""
+           rng_mode: int = RNG_KEYED, faithful: bool = False, dump_paths: int = 0,
+           grad_image_param: int = -1):
+    """-> dict(image f64 [H,W,3], grads f64 [P,3] | None, stats dict, vertices f64 [n,16] | None,
+    grad_image f64 [H,W,3] | None)"""
     sd, keep = scene.to_desc()
     cd = cam.to_desc()
     rd = rp.to_desc()
@@ -90,6 +94,11 @@ def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray]
     if dump_paths > 0:
         max_v = dump_paths * 64
         vtx = np.zeros((max_v, VERTEX_DOUBLES), dtype=np.float64)
+    gimg = None
+    if grad_image_param >= 0:
+        assert backward
+        gimg = np.zeros((cam.height, cam.width, 3), dtype=np.float64)
+        lib().drt_oracle_set_gradient_image(grad_image_param, gimg.ctypes.data_as(C.c_void_p))
     rc = lib().drt_oracle_render(C.byref(sd), C.byref(cd), C.byref(rd), rng_mode,
                                  FAITHFUL_CONTINUATION if faithful else 0, adj_ptr,
                                  img.ctypes.data_as(C.c_void_p),
@@ -97,9 +106,10 @@ def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray]
                                  C.byref(st),
                                  vtx.ctypes.data_as(C.c_void_p) if vtx is not None else None,
                                  max_v, C.byref(nv), dump_paths)
+    lib().drt_oracle_set_gradient_image(-1, None)
     if rc != 0:
         raise RuntimeError(f"drt_oracle_render failed: {rc}")
-    return {"image": img, "grads": grads,
+    return {"image": img, "grads": grads, "grad_image": gimg,
             "stats": {"paths": int(st.paths), "segments": int(st.segments),
                       "zero_dir_segments": int(st.zero_dir_segments),
                       "max_vertices": int(st.max_vertices)},
@@ -116,7 +126,7 @@ def have_reference() -> bool:
 
 
 def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, dump_paths: int,
-                     adjoint_file: str = "none"):
+                     adjoint_file: str = "none", grad_image_param: int = -1):
     with open(path, "w") as f:
         f.write(f"params {len(scene.params)}\n")
         for rgb, rg in zip(scene.params, scene.requires_grad):
@@ -142,10 +152,11 @@ def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, d
         f.write(f"camera {cam.width} {cam.height} " + " ".join(repr(float(x)) for x in v) + "\n")
         f.write(f"render {rp.spp} {rp.min_bounces} {rp.absorb!r} {rp.seed} {rng_mode} {int(backward)} {dump_paths}\n")
         f.write(f"adjoint {adjoint_file}\n")
+        f.write(f"gradimage {grad_image_param}\n")
 
 
 def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray] = None,
-                     rng_mode: int = RNG_KEYED, dump_paths: int = 0):
+                     rng_mode: int = RNG_KEYED, dump_paths: int = 0, grad_image_param: int = -1):
     """Run the UNMODIFIED reference headers through oracle/_ref/ref_harness. Same return shape as
     render(); stats carry the harness's raycast counters and its wall time."""
     if not have_reference():
@@ -157,7 +168,7 @@ def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[n
             adj_file = os.path.join(td, "adj.f32")
             np.ascontiguousarray(adjoint, dtype=np.float32).tofile(adj_file)
         sf = os.path.join(td, "scene.txt")
-        write_scene_file(sf, scene, cam, rp, rng_mode, backward, dump_paths, adj_file)
+        write_scene_file(sf, scene, cam, rp, rng_mode, backward, dump_paths, adj_file, grad_image_param)
         prefix = os.path.join(td, "out")
         subprocess.run([REF_HARNESS, sf, prefix], check=True, stderr=subprocess.DEVNULL)
         meta = json.load(open(prefix + ".json"))
@@ -166,7 +177,8 @@ def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[n
         vtx = None
         if dump_paths > 0:
             vtx = np.fromfile(prefix + ".vtx.f64").reshape(-1, VERTEX_DOUBLES)
-    return {"image": img, "grads": grads,
+        gimg = np.fromfile(prefix + ".gimg.f64").reshape(cam.height, cam.width, 3) if grad_image_param >= 0 else None
+    return {"image": img, "grads": grads, "grad_image": gimg,
             "stats": {"paths": cam.width * cam.height * rp.spp,
                       "segments": meta["raycasts"] - meta["zero_dir_raycasts"],
                       "zero_dir_segments": meta["zero_dir_raycasts"], "seconds": meta["seconds"]},

@@ -22,6 +22,7 @@
 //   camera W H vfov ex ey ez fx fy fz rx ry rz ux uy uz
 //   render spp min_bounces absorb seed rng_mode(0 keyed,1 libc) backward dump_paths
 //   adjoint <file|none>   (raw f32 W*H*3)
+//   gradimage <param|-1>  per-pixel gradient image of one parameter -> <prefix>.gimg.f64
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -201,6 +202,7 @@ int main(int argc, char** argv)
     double vfov = 1.3963, absorb = 0.5;
     V3 eye(0.), fwd(0.), right(0.), up(0.);
     std::string adjoint_file = "none";
+    int gimg_param = -1;
 
     while (in >> tok) {
         if (tok == "params") {
@@ -280,6 +282,8 @@ int main(int argc, char** argv)
             in >> spp >> min_bounces >> absorb >> g_seed >> g_rng_mode >> backward >> dump_paths;
         } else if (tok == "adjoint") {
             in >> adjoint_file;
+        } else if (tok == "gradimage") {
+            in >> gimg_param;
         } else {
             die("unknown token in scene file");
         }
@@ -310,12 +314,18 @@ int main(int argc, char** argv)
     drt::Camera<T> cam(W, H, vfov, eye, fwd, right, up);
     drt::Pathtracer<T> tracer(absorb, (size_t)min_bounces);
     std::vector<double> img((size_t)W * H * 3, 0.0);
+    std::vector<double> gimg(gimg_param >= 0 ? (size_t)W * H * 3 : 0, 0.0);
+    V3 gtotal(0.);
 
     auto t0 = std::chrono::steady_clock::now();
     for (int y = 0; y < H; ++y) {
         for (int x = 0; x < W; ++x) {
             V3 pixel(0.);
             size_t pix = (size_t)y * W + x;
+            if (gimg_param >= 0) {                       // per-pixel accumulator: zero the variable's grad
+                gtotal += params[gimg_param].grad();
+                params[gimg_param].grad() = V3(0.);
+            }
             for (int i = 0; i < spp; ++i) {
                 uint64_t path = (uint64_t)pix * spp + i;
                 g_path_key = drt_rng_path_key(g_seed, path);
@@ -339,10 +349,15 @@ int main(int argc, char** argv)
             pixel = pixel / (double)spp;
             for (int c = 0; c < 3; ++c)
                 img[pix*3 + c] = pixel[c];
+            if (gimg_param >= 0)
+                for (int c = 0; c < 3; ++c)
+                    gimg[pix*3 + c] = params[gimg_param].grad()[c] / (double)spp;
         }
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
+    if (gimg_param >= 0)
+        params[gimg_param].grad() += gtotal;
     std::vector<double> grads(params.size() * 3, 0.0);
     for (size_t i = 0; i < params.size(); ++i)
         if (param_rg[i])
@@ -357,6 +372,8 @@ int main(int argc, char** argv)
     };
     dump(".img.f64", img.data(), img.size() * sizeof(double));
     dump(".grad.f64", grads.data(), grads.size() * sizeof(double));
+    if (gimg_param >= 0)
+        dump(".gimg.f64", gimg.data(), gimg.size() * sizeof(double));
     if (dump_paths > 0)
         dump(".vtx.f64", g_log.data(), g_log.size() * sizeof(VertexLog));
 

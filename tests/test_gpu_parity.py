@@ -242,3 +242,25 @@ def test_finite_difference_of_albedo(pkg, hip):
         # polynomial of degree <= 4 in this albedo: central difference error is O(h^2 f''')
         assert abs(fd - grads[p, c]) <= 5e-3 * abs(grads[p, c])
     hip.update_params(base)
+
+
+@pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr"])
+def test_gradient_image_matches_reference(pkg, hip, name):
+    """drt_hip_render_gradient_image against the per-pixel gradients the reference produces."""
+    g = load_golden(name)
+    scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
+    p = g["case"]["grad_image_param"]
+    hip.upload_scene(scene)
+    img, gimg, st = hip.render_gradient_image(cam, rp, p, adjoint=adjoint, f64=True)
+    assert st["segments"] == int(g["segments"])
+    scale = np.abs(g["grad_image"]).max()
+    np.testing.assert_allclose(gimg, g["grad_image"].astype(np.float32), rtol=2e-7, atol=1e-7 * scale)
+    np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    img, gimg, st = hip.render_gradient_image(cam, rp, p, adjoint=adjoint)
+    bad = np.abs(gimg.astype(np.float64) - g["grad_image"]).max(-1) > PIXEL_TOL * scale
+    assert bad.mean() <= OUTLIER_FRAC
+    # its pixel sum is the ordinary gradient of that parameter
+    _, grads, _ = hip.render(cam, rp, backward=True, adjoint=adjoint)
+    np.testing.assert_allclose(gimg.astype(np.float64).sum((0, 1)) * rp.spp, grads[p], rtol=1e-5)
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
+        hip.render_gradient_image(cam, rp, 99)

@@ -32,6 +32,20 @@ def test_oracle_bit_exact_vs_reference_golden(pkg, oracle, name):
         assert r2["stats"]["segments"] == int(g["segments"]) and r2["stats"]["zero_dir_segments"] == 0
 
 
+@pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr"])
+def test_gradient_image_bit_exact(pkg, oracle, name):
+    """Per-pixel gradient of one parameter: the reference computes it by zeroing param.grad() before
+    each pixel's samples (harness); the restatement must reproduce image, gradient image and totals."""
+    g = load_golden(name)
+    scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
+    r = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, grad_image_param=g["case"]["grad_image_param"])
+    np.testing.assert_array_equal(r["image"], g["image"])
+    np.testing.assert_array_equal(r["grad_image"], g["grad_image"])
+    np.testing.assert_array_equal(r["grads"], g["grads"])
+    p = g["case"]["grad_image_param"]
+    np.testing.assert_allclose(r["grad_image"].sum((0, 1)) * rp.spp, r["grads"][p], rtol=1e-12)
+
+
 def test_libc_stream_known_answers(pkg, oracle):
     """numbers probed independently from the reference with its own unseeded
     rand() stream (64x64x8, -b 4 -p 1)."""
