@@ -21,6 +21,7 @@
 
 #include "../drt_hip.h"
 #include "camera.hpp"
+#include "mesh.hpp"
 #include "pathtracer.hpp"
 
 namespace drt { namespace hip {
@@ -48,6 +49,9 @@ struct FlatScene {
     std::vector<double> params;
     std::vector<uint8_t> requires_grad;
     std::vector<Vector<T, 3, true>> handles;   // one per parameter, sharing the user's nodes
+    std::vector<drt_mesh_desc> meshes;
+    std::vector<std::vector<double>> mesh_vertices;
+    std::vector<std::vector<uint32_t>> mesh_indices;
 
     drt_scene_desc desc() const
     {
@@ -61,6 +65,9 @@ struct FlatScene {
         d.emitters = emitters.data();
         d.params = params.data();
         d.requires_grad = requires_grad.data();
+        d.n_meshes = (int32_t)meshes.size();
+        d.reserved = 0;
+        d.meshes = meshes.data();
         return d;
     }
 };
@@ -89,7 +96,23 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
             sd.type = DRT_SHAPE_PLANE;
         else if (rec.kind == ShapeKind::Sphere)
             sd.type = DRT_SHAPE_SPHERE;
-        else
+        else if (rec.kind == ShapeKind::Mesh) {
+            auto* mesh = dynamic_cast<Mesh<T>*>(shape);
+            if (!mesh)
+                throw std::runtime_error("drt::hip: ShapeKind::Mesh reported by a shape that is not drt::Mesh");
+            sd.type = DRT_SHAPE_MESH;
+            sd.mesh = (int32_t)f.mesh_vertices.size();
+            std::vector<double> vs;
+            for (const auto& v : mesh->vertices())
+                for (int c = 0; c < 3; ++c)
+                    vs.push_back(double(v[c]));
+            std::vector<uint32_t> is;
+            for (const auto& t : mesh->triangles())
+                for (int c = 0; c < 3; ++c)
+                    is.push_back(t[c]);
+            f.mesh_vertices.push_back(std::move(vs));
+            f.mesh_indices.push_back(std::move(is));
+        } else
             throw std::runtime_error("drt::hip: shape type has no device record (describe() not implemented)");
         for (int i = 0; i < 4; ++i)
             sd.p[i] = rec.p[i];
@@ -126,6 +149,15 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
             sd.emitter = it->second;
         }
         f.shapes.push_back(sd);
+    }
+    for (std::size_t m = 0; m < f.mesh_vertices.size(); ++m) {   // pointers taken once the vectors stopped growing
+        drt_mesh_desc md{};
+        md.n_vertices = (int32_t)(f.mesh_vertices[m].size() / 3);
+        md.n_triangles = (int32_t)(f.mesh_indices[m].size() / 3);
+        md.vertices = f.mesh_vertices[m].data();
+        md.indices = f.mesh_indices[m].data();
+        md.face_material = nullptr;
+        f.meshes.push_back(md);
     }
     return f;
 }
@@ -257,6 +289,49 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
         }
     }
     return total;
+}
+
+// Per-pixel gradient image of ONE parameter (the figure of the reference's README.md:142-145):
+// gimg[pixel] = mean over the pixel's samples of d(seed . radiance)/d param.  Single device.
+template <typename T>
+inline Stats render_gradient_image(const Scene<T>& scene, const Camera<T>& cam, const Pathtracer<T>& tracer,
+                                   std::size_t spp, const Vector<T, 3, true>& param, Vector<T, 3>* img,
+                                   Vector<T, 3>* gimg, const Options& opt = Options())
+{
+    FlatScene<T> flat = flatten(scene);
+    int index = -1;
+    for (std::size_t p = 0; p < flat.handles.size(); ++p)
+        if (flat.handles[p].id() == param.id())
+            index = (int)p;
+    if (index < 0)
+        throw std::runtime_error("drt::hip::render_gradient_image: the parameter is not used by the scene");
+    const drt_scene_desc sd = flat.desc();
+    const drt_camera_desc cd = describe(cam);
+    const std::size_t npix = cam.width() * cam.height();
+    std::vector<float> rgb(npix * 3, 0.f), grad(npix * 3, 0.f);
+    Context ctx(opt.devices.empty() ? 0 : opt.devices[0]);
+    ctx.check(drt_hip_upload_scene(ctx.get(), &sd), "drt_hip_upload_scene");
+    drt_render_params rp{};
+    rp.spp = (int32_t)spp;
+    rp.min_bounces = (int32_t)tracer.min_bounces();
+    rp.absorb = tracer.absorb();
+    rp.max_depth = opt.max_depth;
+    rp.seed = opt.seed;
+    rp.flags = opt.f64 ? DRT_RENDER_F64 : 0u;
+    rp.batch_paths = opt.batch_paths;
+    drt_hip_stats st{};
+    ctx.check(drt_hip_render_gradient_image(ctx.get(), &cd, &rp, index, nullptr, rgb.data(), grad.data(), &st),
+              "drt_hip_render_gradient_image");
+    for (std::size_t i = 0; i < npix; ++i)
+        for (int c = 0; c < 3; ++c) {
+            if (img) img[i][c] = T(rgb[i * 3 + c]);
+            gimg[i][c] = T(grad[i * 3 + c]);
+        }
+    Stats out;
+    out.paths = st.paths;
+    out.segments = st.segments;
+    out.ms = st.ms_total;
+    return out;
 }
 
 } } // namespace drt::hip

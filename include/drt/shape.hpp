@@ -15,7 +15,7 @@
 
 namespace drt {
 
-enum class ShapeKind { Plane, Sphere, Other };
+enum class ShapeKind { Plane, Sphere, Mesh, Other };
 
 struct ShapeRecord {
     ShapeKind kind = ShapeKind::Other;

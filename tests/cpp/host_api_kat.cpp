@@ -12,6 +12,7 @@
 #include "drt/emitter.hpp"
 #include "drt/hip.hpp"
 #include "drt/integrate.hpp"
+#include "drt/mesh.hpp"
 #include "drt/pathtracer.hpp"
 #include "drt/shape.hpp"
 #include "drt/vector.hpp"
@@ -123,6 +124,19 @@ int main()
     MirrorBxDF<double> mirror;
     auto mdir = std::get<0>(mirror.sample(V{0, 1, 0}, V{1, 1, 0}));
     CHECK(mdir[0] == -1 && mdir[1] == 1);
+    // mesh extension: brute-force triangles on the host path, flattened for the device
+    std::vector<V> mv{V{-1, -1, 2}, V{1, -1, 2}, V{0, 1, 2}, V{0, 0, 4}};
+    std::vector<std::array<uint32_t, 3>> mt{{{0, 1, 2}}, {{0, 1, 3}}};
+    Mesh<double> mesh(mv, mt, mwhite);
+    CHECK(mesh.intersect(V{0, 0, 0}, V{0, 0, 1}, t) && close(t, 2));
+    CHECK(close(std::fabs(mesh.normal(V(0.))[2]), 1));
+    CHECK(!mesh.intersect(V{5, 5, 0}, V{0, 0, 1}, t));
+    CHECK(mesh.intersect(V{0, 0, 3}, V{0, 0, -1}, t) && close(t, 1));       // two-sided
+    Scene<double> scene2{&mesh, &s2};
+    auto flat2 = hip::flatten(scene2);
+    CHECK(flat2.meshes.size() == 1 && flat2.meshes[0].n_triangles == 2 && flat2.meshes[0].n_vertices == 4);
+    CHECK(flat2.shapes[0].type == DRT_SHAPE_MESH && flat2.shapes[0].mesh == 0 && flat2.desc().n_meshes == 1);
+    CHECK(flat2.meshes[0].vertices[3 * 3 + 2] == 4 && flat2.meshes[0].indices[5] == 3);
     std::printf("ok\n");
     return 0;
 }
