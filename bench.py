@@ -29,7 +29,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per ray segment, f32 queues
-BYTES_PER_UNIT = {"intersect": 32.0, "shade_fwd": 104.0, "shade_bwd": 112.0, "backward": 8.0}
+BYTES_PER_UNIT = {"intersect": 32.0, "shade_fwd": 80.0, "shade_bwd": 80.0, "backward": 8.0}
 
 
 def main():
@@ -134,7 +134,7 @@ def main():
              "raygen": paths, "film": paths, "gradreduce": 0}
     bpu = {"intersect": BYTES_PER_UNIT["intersect"],
            "shade": BYTES_PER_UNIT["shade_bwd" if backward else "shade_fwd"],
-           "backward": BYTES_PER_UNIT["backward"], "raygen": 48.0, "film": 16.0, "gradreduce": 0.0}
+           "backward": BYTES_PER_UNIT["backward"], "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
     per_kernel = {}
     for k in pkg.KERNEL_NAMES:
         ms = kernel_ms[k] / n_prof

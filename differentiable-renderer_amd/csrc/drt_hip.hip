@@ -48,7 +48,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], ray_c[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
@@ -305,16 +305,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ray_b[i], N * sizeof(typename Q2<R>::T))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ray_id[i], N * sizeof(uint2))) != DRT_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ray_c[i], N * sizeof(R4))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
     if (gimg_param >= 0)
         if ((rc = ensure(ctx, ctx->gpath, N * sizeof(R4))) != DRT_OK) return rc;
-    if (backward) {
-        if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
-        if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
-    }
+    if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
     const uint64_t n_pix_batches = (n_local_pixels + Pb - 1) / Pb;
     const uint64_t n_s_batches = ((uint64_t)spp + Sb - 1) / Sb;
     const uint64_t n_batches = n_pix_batches * n_s_batches;
@@ -361,9 +358,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     uint2* rid[2] = {(uint2*)ctx->ray_id[0].p, (uint2*)ctx->ray_id[1].p};
     HitRec<R>* hit = (HitRec<R>*)ctx->hit.p;
     R4* lacc = (R4*)ctx->lacc.p;
-    R4* rcq[2] = {(R4*)ctx->ray_c[0].p, (R4*)ctx->ray_c[1].p};
     TapeRec<R>* tape = (TapeRec<R>*)ctx->tape.p;
-    uint32_t* nv = backward ? (uint32_t*)ctx->nv.p : nullptr;
+    uint32_t* nv = (uint32_t*)ctx->nv.p;
     double* grad = (double*)ctx->grad.p;
     double* gpart = (double*)ctx->gpart.p;
     const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
@@ -383,7 +379,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 
             if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
             hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
-                               rid[0], lacc, nv, counts);
+                               rid[0], nv, counts);
             if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
             st->launches[DRT_K_RAYGEN]++;
             st->units[DRT_K_RAYGEN] += a.n_paths;
@@ -400,7 +396,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
 
-                TapeRec<R>* tape_k = backward ? tape + (size_t)k * a.n_paths : nullptr;
+                TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                 if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
                 {
                     int gs = g;                                // one wave per region, or persistent
@@ -409,14 +405,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         gs = ctx->n_cu * shade_bpc;
                     const uint32_t* ck = counts + (size_t)k * max_regions;
                     uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
-#define DRT_LAUNCH_SHADE(BWD, SPEC)                                                                       \
-    hipLaunchKernelGGL((k_shade<R, BWD, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene, \
-                       d_params, ra[cur], rb[cur], rid[cur], rcq[cur], hit, ra[nxt], rb[nxt], rid[nxt],   \
-                       rcq[nxt], tape_k, nv, lacc, ck, cn, bvh.tri_shade)
-                    if (backward && ctx->has_specular) DRT_LAUNCH_SHADE(true, true);
-                    else if (backward) DRT_LAUNCH_SHADE(true, false);
-                    else if (ctx->has_specular) DRT_LAUNCH_SHADE(false, true);
-                    else DRT_LAUNCH_SHADE(false, false);
+#define DRT_LAUNCH_SHADE(SPEC)                                                                            \
+    hipLaunchKernelGGL((k_shade<R, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene,      \
+                       d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, \
+                       ck, cn, bvh.tri_shade)
+                    if (ctx->has_specular) DRT_LAUNCH_SHADE(true);
+                    else DRT_LAUNCH_SHADE(false);
 #undef DRT_LAUNCH_SHADE
                 }
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
@@ -425,19 +419,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 
             hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts,
                                (uint32_t)((size_t)D * max_regions), (unsigned long long*)ctx->segtotal.p);
-            if (film) {
-                if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
-                                   lacc, film);
-                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
-                st->launches[DRT_K_FILM]++;
-                st->units[DRT_K_FILM] += a.n_paths;
-            }
             if (backward && D > 0 && gimg_param >= 0) {
                 // gradient image: per-path gradient of one parameter, averaged per pixel by K5
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                 hipLaunchKernelGGL(k_backward_image<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                   d_params, tape, nv, d_adjoint, (uint32_t)gimg_param, (R4*)ctx->gpath.p);
+                                   d_params, tape, nv, d_adjoint, (uint32_t)gimg_param, (R4*)ctx->gpath.p,
+                                   film ? lacc : (R4*)nullptr);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_BACKWARD]++;
                 hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
@@ -446,7 +433,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
 #define DRT_LAUNCH_BWD(NP)                                                                              \
     hipLaunchKernelGGL((k_backward<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params, \
-                       tape, nv, d_adjoint, gpart, grad)
+                       tape, nv, d_adjoint, gpart, grad, film ? lacc : (R4*)nullptr)
                 if (ctx->n_params <= 4) DRT_LAUNCH_BWD(4);
                 else if (ctx->n_params <= 8) DRT_LAUNCH_BWD(8);
                 else DRT_LAUNCH_BWD(0);
@@ -459,6 +446,24 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_GRADREDUCE]++;
                 st->units[DRT_K_GRADREDUCE] += (uint64_t)gp;
+            }
+            else if (D > 0 && film) {
+                // forward only: radiance of every path from its tape
+                if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_radiance<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params,
+                                   tape, nv, lacc);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_BACKWARD]++;
+            }
+            if (D <= 0 && film)
+                HIPCHK(ctx, hipMemsetAsync(lacc, 0, (size_t)a.n_paths * sizeof(R4), ctx->stream));
+            if (film) {
+                if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
+                                   lacc, film);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_FILM]++;
+                st->units[DRT_K_FILM] += a.n_paths;
             }
         }
     }
@@ -522,8 +527,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->ray_c[0],
-                      &ctx->ray_c[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
+    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
     for (DevBuf* b : bufs)
         release(*b);
@@ -658,10 +662,16 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     if (s->requires_grad)
         for (int i = 0; i < s->n_params; ++i)
             ctx->requires_grad[i] = s->requires_grad[i] ? 1 : 0;
+    // only materials that a shape or a mesh face actually uses decide the K3 instantiation
+    // (render.cpp:35 creates a specular material its scene never uses)
     ctx->has_specular = false;
-    for (int i = 0; i < s->n_materials; ++i)
-        if (s->materials[i].type == DRT_BXDF_SPECULAR)
-            ctx->has_specular = true;
+    auto uses = [&](int m) { if (m >= 0 && s->materials[m].type == DRT_BXDF_SPECULAR) ctx->has_specular = true; };
+    for (int i = 0; i < s->n_shapes; ++i) {
+        uses(s->shapes[i].material);
+        if (s->shapes[i].type == DRT_SHAPE_MESH && s->meshes[s->shapes[i].mesh].face_material)
+            for (int t = 0; t < s->meshes[s->shapes[i].mesh].n_triangles; ++t)
+                uses(s->meshes[s->shapes[i].mesh].face_material[t]);
+    }
     ctx->has_scene = true;
     return DRT_OK;
 }

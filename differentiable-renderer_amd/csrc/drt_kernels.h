@@ -14,12 +14,14 @@
 //   ray_a[2][N]  (o.x, o.y, o.z, d.x)         dense by queue slot, ping-pong per bounce
 //   ray_b[2][N]  (d.y, d.z)                    8 bytes: K2 reads ray_a + ray_b = 24 B, all used
 //   ray_id[2][N] (path index, RNG path key)    8 bytes, K3 only
-//   ray_c[2][N]  (T.r, T.g, T.b, -) throughput of the path so far (not read at depth 0: T = 1)
 //   hit[N]       (t, shape index | -1)         dense by queue slot
-//   tape[D][N]   (m_k, colour param | emission param << 16)   by path index, backward only:
-//                T_{k+1} = T_k * colour * m_k, so K6 rebuilds every T_k from 8 bytes per vertex
-//   nv[N]        vertices of the path                          (backward only)
-//   lacc[N]      (L.rgb, -) radiance accumulated along the path, by path index
+//   tape[D][N]   (m_k, colour param | emission param << 16)   by path index: everything later
+//                passes need about vertex k.  T_{k+1} = T_k * colour * m_k and
+//                L_k = E_k / p_k + colour_k * m_k * L_{k+1}, so neither the throughput nor the
+//                radiance travels through the queue: the tape walk (K6, or k_radiance when only
+//                the image is wanted) rebuilds both from 8 bytes per vertex
+//   nv[N]        vertices of the path
+//   lacc[N]      (L.rgb, -) radiance of the path = L_0, written by the tape walk, read by K5
 //   counts[D+1][n_regions]  queue lengths per depth and region (device-resident: no host round
 //                trip per bounce)
 // Path index i of a batch = (s - s0) * Pb + (pixel - p0): sample-major, so neighbouring lanes
@@ -101,7 +103,7 @@ __device__ inline uint32_t draw_index(int k, int min_bounces)
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* __restrict__ ray_b,
-         uint2* __restrict__ ray_id, typename Q4<R>::T* __restrict__ lacc, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
+         uint2* __restrict__ ray_id, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
 {
     typedef typename Q4<R>::T R4;
     const uint32_t w = grid_wave();
@@ -143,9 +145,7 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* 
             ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dx;
             rb.x = (R)dy; rb.y = (R)dz;
             rid.x = i; rid.y = key;
-            R4 zero; zero.x = zero.y = zero.z = zero.w = R(0);
-            lacc[i] = zero;
-            if (nv && !alive)
+            if (!alive)
                 nv[i] = 0;
         }
         uint32_t n_alive;
@@ -430,18 +430,17 @@ __device__ inline V3<R> load_param(const SceneLds<R>& lds, const R* __restrict__
 // what K3 consumes per ray: its queue lanes and the hit record
 template <typename R>
 struct ShadeIn {
-    typename Q4<R>::T ra, rc;
+    typename Q4<R>::T ra;
     typename Q2<R>::T rb;
     uint2 rid;
     HitRec<R> h;
 };
 
 template <typename R>
-__device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, int k,
+__device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have,
                                      const typename Q4<R>::T* __restrict__ ray_a,
                                      const typename Q2<R>::T* __restrict__ ray_b,
                                      const uint2* __restrict__ ray_id,
-                                     const typename Q4<R>::T* __restrict__ ray_c,
                                      const HitRec<R>* __restrict__ hit)
 {
     if (have) {
@@ -449,8 +448,6 @@ __device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, i
         in.rb = ray_b[slot];
         in.rid = ray_id[slot];
         in.h = hit[slot];
-        if (k > 0)
-            in.rc = ray_c[slot];
     }
 }
 
@@ -472,16 +469,15 @@ __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_
 // shades them chunk by chunk.  The loads of the NEXT chunk (same region or the next live one) are
 // issued before the current chunk is shaded, so a wave always has one chunk of loads in flight.
 // SPEC = false instantiations carry no specular code (and fewer registers) for all-diffuse scenes.
-template <typename R, bool BWD, bool SPEC>
+template <typename R, bool SPEC>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
-        const uint2* __restrict__ ray_id,
-        const typename Q4<R>::T* __restrict__ ray_c, const HitRec<R>* __restrict__ hit,
+        const uint2* __restrict__ ray_id, const HitRec<R>* __restrict__ hit,
         typename Q4<R>::T* __restrict__ next_a, typename Q2<R>::T* __restrict__ next_b,
-        uint2* __restrict__ next_id, typename Q4<R>::T* __restrict__ next_c,
+        uint2* __restrict__ next_id,
         TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
-        typename Q4<R>::T* __restrict__ lacc, const uint32_t* __restrict__ counts_k,
+        const uint32_t* __restrict__ counts_k,
         uint32_t* __restrict__ counts_next, const typename Q4<R>::T* __restrict__ tri_shade)
 {
     typedef typename Q4<R>::T R4;
@@ -492,7 +488,6 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
     const int n_shapes = lds.sc.n_shapes;
     const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
-    const R inv_pk = R(1) / pk;
     const uint32_t n_theta = draw_index(k, a.min_bounces);
     const bool next_rr = (k + 1) >= a.min_bounces;
     const bool next_cap = (k + 1) >= a.depth_cap;
@@ -504,7 +499,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
     uint32_t off = 0, running = 0;
     ShadeIn<R> cur, nxt;
     bool have = lane < cnt;
-    load_shade_in(cur, (w << a.region_shift) + lane, have, k, ray_a, ray_b, ray_id, ray_c, hit);
+    load_shade_in(cur, (w << a.region_shift) + lane, have, ray_a, ray_b, ray_id, hit);
 
     for (;;) {
         // where the next chunk is, and its loads
@@ -515,10 +510,10 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         }
         const bool more = nw < a.n_regions;
         const bool nhave = more && noff + lane < ncnt;
-        load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, k, ray_a, ray_b, ray_id, ray_c, hit);
+        load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, ray_a, ray_b, ray_id, hit);
 
         bool alive = false;
-        R4 na, nc;
+        R4 na;
         typename Q2<R>::T nb;
         if (have) {
             const R4 ra = cur.ra;
@@ -526,7 +521,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
             const HitRec<R> h = cur.h;
             const uint32_t pid = cur.rid.x;
             if (h.prim < 0) {
-                if (BWD) nv[pid] = (uint32_t)k;               // miss: pathtracer.hpp:135
+                nv[pid] = (uint32_t)k;                        // miss: pathtracer.hpp:135
             } else {
                 const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
                 const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
@@ -545,29 +540,18 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     material = (ids & 0xFFFFu) == 0xFFFFu ? -1 : (int)(ids & 0xFFFFu);
                     emitter = (ids >> 16) == 0xFFFFu ? -1 : (int)(ids >> 16);
                 }
-                V3<R> T = mk<R>(R(1), R(1), R(1));
-                if (k > 0)
-                    T = mk<R>(cur.rc.x, cur.rc.y, cur.rc.z);
+                // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
                 uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
-                if (emitter >= 0) {                            // pathtracer.hpp:113-114
+                if (emitter >= 0)
                     eid = (uint32_t)lds.sc.emitter_param[emitter];
-                    const V3<R> E = load_param(lds, params, (int)eid);
-                    R4 L = lacc[pid];
-                    L.x += T.x * E.x * inv_pk;
-                    L.y += T.y * E.y * inv_pk;
-                    L.z += T.z * E.z * inv_pk;
-                    lacc[pid] = L;
-                }
                 if (material < 0) {
                     // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
                     // continuation contributes exactly 0, the path ends here
-                    if (BWD) {
-                        TapeRec<R> tr;
-                        tr.m = R(0);
-                        tr.ids = DRT_ID_NONE | (eid << 16);
-                        tape_k[pid] = tr;
-                        nv[pid] = (uint32_t)k + 1u;
-                    }
+                    TapeRec<R> tr;
+                    tr.m = R(0);
+                    tr.ids = DRT_ID_NONE | (eid << 16);
+                    tape_k[pid] = tr;
+                    nv[pid] = (uint32_t)k + 1u;
                 } else {
                     const DevMaterial<R>& m = lds.sc.materials[material];
                     cid = (uint32_t)m.param;
@@ -607,23 +591,18 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     }
                     const R c = dot(nrm, wo);                  // pathtracer.hpp:103
                     const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
-                    const V3<R> col = load_param(lds, params, (int)cid);
-                    const V3<R> Tn = T * col * mk_;
                     // roulette / cap of depth k+1, decided here so dead rays are never queued
                     alive = !next_cap;
                     if (alive && next_rr)
                         alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                    if (BWD) {
-                        TapeRec<R> tr;
-                        tr.m = mk_;
-                        tr.ids = cid | (eid << 16);
-                        tape_k[pid] = tr;
-                        if (!alive) nv[pid] = (uint32_t)k + 1u;
-                    }
+                    TapeRec<R> tr;
+                    tr.m = mk_;
+                    tr.ids = cid | (eid << 16);
+                    tape_k[pid] = tr;
+                    if (!alive) nv[pid] = (uint32_t)k + 1u;
                     const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
                     na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
                     nb.x = wo.y; nb.y = wo.z;
-                    nc.x = Tn.x; nc.y = Tn.y; nc.z = Tn.z; nc.w = R(0);
                 }
             }
         }
@@ -633,7 +612,6 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
             next_a[ns] = na;
             next_b[ns] = nb;
             next_id[ns] = cur.rid;
-            next_c[ns] = nc;
         }
         running += n_alive;
         if (nw != w) {                                         // region finished
@@ -784,7 +762,7 @@ struct GradAcc<R, 0> {
 // The walk of ONE path's tape (see the K6 comment above); every gradient contribution is handed
 // to acc.add(acc_lds, grad, parameter id, value).
 template <typename R, bool SMALL, typename Acc>
-__device__ inline void backward_path(const BatchArgs& a, const SceneLds<R>& lds, const R* __restrict__ params,
+__device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds, const R* __restrict__ params,
                                      const TapeRec<R>* __restrict__ tape, size_t N, uint32_t i, int K, V3<R> g,
                                      R inv_p_rr, Acc& acc, R (*acc_lds)[DRT_BLOCK], double* __restrict__ grad)
 {
@@ -835,6 +813,7 @@ __device__ inline void backward_path(const BatchArgs& a, const SceneLds<R>& lds,
             }
         }
     }
+    return Ln;          // L_0: the radiance of the path
 }
 
 template <typename R>
@@ -850,8 +829,10 @@ template <typename R, int NP>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
-           const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad)
+           const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad,
+           typename Q4<R>::T* __restrict__ lacc)
 {
+    typedef typename Q4<R>::T R4;
     constexpr bool SMALL = NP > 0;
     __shared__ SceneLds<R> lds;
     __shared__ R acc[NP > 0 ? 1 : DRT_FAST_PARAMS * 3][DRT_BLOCK];
@@ -865,9 +846,14 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
         const int K = (int)nv[i];
-        if (K <= 0)
-            continue;
-        backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, ga, acc, grad);
+        V3<R> L0 = mk<R>(R(0), R(0), R(0));
+        if (K > 0)
+            L0 = backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, ga, acc, grad);
+        if (lacc) {
+            R4 o;
+            o.x = L0.x; o.y = L0.y; o.z = L0.z; o.w = R(0);
+            lacc[i] = o;
+        }
     }
 
     // block reduction in fp64: thread columns -> wave (shuffles) -> block (LDS), fixed order
@@ -891,6 +877,51 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     }
 }
 
+// Forward-only renders: the radiance of every path from its tape, deepest vertex first --
+//   L_k = E_k / p_k + colour_k * m_k * L_{k+1}
+// which is the order in which the reference's recursion returns (pathtracer.hpp:104,114,133).
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_radiance(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
+           const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
+           typename Q4<R>::T* __restrict__ lacc)
+{
+    typedef typename Q4<R>::T R4;
+    __shared__ SceneLds<R> lds;
+    stage_scene(lds, sc, params);
+    const size_t N = a.n_paths;
+    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
+        const int K = (int)nv[i];
+        V3<R> L = mk<R>(R(0), R(0), R(0));
+        for (int c0 = ((K - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0 && K > 0; c0 -= DRT_TAPE_CHUNK) {
+            TapeRec<R> trs[DRT_TAPE_CHUNK];
+#pragma unroll
+            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+                if (c0 + j < K)
+                    trs[j] = tape[(size_t)(c0 + j) * N + i];
+#pragma unroll
+            for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
+                const int k = c0 + j;
+                if (k < K) {
+                    const uint32_t cid = trs[j].ids & 0xFFFFu, eid = trs[j].ids >> 16;
+                    const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
+                    V3<R> Lk = mk<R>(R(0), R(0), R(0));
+                    if (eid != DRT_ID_NONE)
+                        Lk = load_param(lds, params, (int)eid) * inv_pk;
+                    if (cid != DRT_ID_NONE)
+                        Lk = Lk + load_param(lds, params, (int)cid) * (L * trs[j].m);
+                    L = Lk;
+                }
+            }
+        }
+        R4 o;
+        o.x = L.x; o.y = L.y; o.z = L.z; o.w = R(0);
+        lacc[i] = o;
+    }
+}
+
 // Gradient-image variant (README.md:142-145 of the reference): the gradient of ONE parameter, kept
 // per path instead of reduced -- written to a lacc-shaped buffer that K5 then averages per pixel.
 template <typename R>
@@ -908,7 +939,8 @@ template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_backward_image(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
                  const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
-                 const float* __restrict__ adjoint, uint32_t param, typename Q4<R>::T* __restrict__ gpath)
+                 const float* __restrict__ adjoint, uint32_t param, typename Q4<R>::T* __restrict__ gpath,
+                 typename Q4<R>::T* __restrict__ lacc)
 {
     typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
@@ -921,12 +953,17 @@ k_backward_image(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __res
         acc.param = param;
         acc.sum = mk<R>(R(0), R(0), R(0));
         const int K = (int)nv[i];
+        V3<R> L0 = mk<R>(R(0), R(0), R(0));
         if (K > 0)
-            backward_path<R, false>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, acc,
-                                    (R(*)[DRT_BLOCK]) nullptr, nullptr);
+            L0 = backward_path<R, false>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, acc,
+                                         (R(*)[DRT_BLOCK]) nullptr, nullptr);
         R4 o;
         o.x = acc.sum.x; o.y = acc.sum.y; o.z = acc.sum.z; o.w = R(0);
         gpath[i] = o;
+        if (lacc) {
+            o.x = L0.x; o.y = L0.y; o.z = L0.z;
+            lacc[i] = o;
+        }
     }
 }
 
