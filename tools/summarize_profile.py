@@ -20,13 +20,14 @@ def find(sub, pattern):
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_raygen", "k_intersect", "k_shade", "k_film", "k_resolve", "k_backward", "k_gradreduce", "k_sum_counts"):
+    for k in ("k_raygen", "k_intersect_mesh", "k_intersect", "k_shade", "k_film", "k_resolve", "k_backward_image",
+              "k_backward", "k_radiance", "k_gradreduce", "k_sum_counts"):
         if k in n:
             tag = k
-            if "<double" in name or "Id" in n.split(k)[-1][:3]:
+            if "<double" in name:
                 tag += "<f64>"
             if k == "k_shade":
-                tag += "<bwd>" if ("true" in name or "Lb1" in name) else "<fwd>"
+                tag += "<specular>" if "true" in name.split(">")[0] else "<diffuse>"
             return tag
     return n[:40]
 
@@ -75,8 +76,9 @@ for k, v in summary.items():
         print(f"{k:28s} fetch_raw={f/1e6:9.2f} MB  fetch_x2={2*f/1e6:9.2f} MB  write={w/1e6:9.2f} MB  total={(2*f+w)/1e6:9.2f} MB")
 json.dump({"kernels": summary, "traffic": traffic}, open(os.path.join(out, "summary.json"), "w"), indent=1)
 # bench.py's "traffic" field: PMC bytes per launch / traced average launch time, per kernel
-names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_shade<bwd>": "shade", "k_shade<fwd>": "shade_fwd",
-         "k_film": "film", "k_backward": "backward", "k_gradreduce": "gradreduce"}
+names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_intersect_mesh": "intersect", "k_shade<diffuse>": "shade",
+         "k_shade<specular>": "shade", "k_film": "film", "k_backward": "backward", "k_radiance": "backward",
+         "k_gradreduce": "gradreduce"}
 tj = {}
 for k, t in traffic.items():
     if k in names and "avg_us" in summary.get(k, {}):
