@@ -275,19 +275,13 @@ typedef struct {
     int bdiv;
     int color_param; /* -1 = no BxDF */
     int emis_param;  /* -1 = no emitter */
+    int material;    /* index into scene->materials, -1 = none */
     v3 f;            /* BxDF value */
     v3 lnext;        /* radiance returned by the recursive trace, filled by the reverse sweep */
+    v3 point, normal, dir_in;   /* geometry of the vertex (the unbiased backward re-samples here) */
 } vertex_t;
 
 #define ORACLE_MAX_VERTICES 4096
-
-static int32_t g_gimg_param = -1;
-static double* g_gimg_out = NULL;
-void drt_oracle_set_gradient_image(int32_t param, double* out)
-{
-    g_gimg_param = out ? param : -1;
-    g_gimg_out = out;
-}
 
 /* Camera::sample, camera.hpp:51-60 */
 static v3 camera_sample(const drt_camera_desc* cam, int x, int y, rng_t* rng)
@@ -303,6 +297,139 @@ static v3 camera_sample(const drt_camera_desc* cam, int x, int y, rng_t* rng)
     dir = v3_add(dir, v3_scale(right, (2. * s - 1.) * aspect * tan(cam->vfov / 2.)));
     dir = v3_add(dir, v3_scale(v3_neg(up), (2. * t - 1.) * tan(cam->vfov / 2.)));
     return v3_normalize(dir);
+}
+
+static int32_t g_gimg_param = -1;
+static double* g_gimg_out = NULL;
+void drt_oracle_set_gradient_image(int32_t param, double* out)
+{
+    g_gimg_param = out ? param : -1;
+    g_gimg_out = out;
+}
+
+typedef struct {
+    const drt_scene_desc* scene;
+    const drt_render_params* rp;
+    rng_t rng;
+    int faithful, zero_dir_miss, max_depth;
+    drt_oracle_stats st;
+    drt_oracle_vertex* vertices;
+    uint64_t max_vertices, nvlog;
+    int logging, log_ord;   /* log_ord: ordinal of the raycast within the camera sample */
+    double log_path;
+    int status;
+} walk_ctx;
+
+static v3 param_rgb(const drt_scene_desc* sc, int p)
+{
+    return v3_make(sc->params[p * 3], sc->params[p * 3 + 1], sc->params[p * 3 + 2]);
+}
+
+/* BxDF value at a vertex for a given outgoing direction (fills f, bscalar, bdiv, c) */
+static void vertex_eval(const drt_scene_desc* sc, vertex_t* v, v3 dir_out)
+{
+    const drt_material_desc* m = v->material >= 0 ? &sc->materials[v->material] : NULL;
+    if (m) {
+        v->bscalar = bxdf_scalar(m, v->normal, v->dir_in, dir_out, &v->bdiv);
+        v3 color = param_rgb(sc, m->param);
+        v->f = v->bdiv ? v3_div(color, v->bscalar) : v3_scale(color, v->bscalar);
+    } else {
+        v->bscalar = 0;
+        v->bdiv = 0;
+        v->f = v3_make(0, 0, 0); /* pathtracer.hpp:38-39 */
+    }
+    v->c = v3_dot(v->normal, dir_out);
+}
+
+/* Pathtracer::trace / scatter (pathtracer.hpp:91-136) from (orig, dir) at `depth`: the forward
+ * walk fills vtx[0..nv) and the reverse sweep
+ *   L_k = (E + (0 + ((f*L_{k+1})*c)/q)) / p
+ * (pathtracer.hpp:104 -> vector.hpp:515,532; integrate.hpp:31,34 -> vector.hpp:553,493;
+ * pathtracer.hpp:114,133) leaves the radiance of the path in *L. Returns nv. */
+static int walk(walk_ctx* w, v3 orig, v3 dir, int depth, vertex_t* vtx, v3* L)
+{
+    const drt_scene_desc* scene = w->scene;
+    const drt_render_params* rp = w->rp;
+    int nv = 0;
+    for (;;) {
+        if (w->max_depth && depth >= w->max_depth)
+            break; /* extension, not in the reference */
+        if (depth >= rp->min_bounces && rng_uniform(&w->rng) < rp->absorb)
+            break;
+        double p = depth >= rp->min_bounces ? (1 - rp->absorb) : 1;
+        v3 point = v3_make(0, 0, 0), normal = v3_make(0, 0, 0);
+        double t;
+        int zero_dir = dir.v[0] == 0 && dir.v[1] == 0 && dir.v[2] == 0;
+        hit_t hit;
+        if (zero_dir && w->zero_dir_miss) {
+            hit.shape = -1; hit.tri = -1; hit.flat = -1; hit.material = -1;
+            t = INFINITY;
+        } else {
+            hit = raycast(scene, orig, dir, &point, &normal, &t);
+        }
+        const int shape = hit.shape;
+        if (zero_dir) w->st.zero_dir_segments++; else w->st.segments++;
+        if (w->logging && w->nvlog < w->max_vertices) {
+            drt_oracle_vertex* Lg = &w->vertices[w->nvlog++];
+            memset(Lg, 0, sizeof *Lg);
+            Lg->path = w->log_path;
+            Lg->depth = w->log_ord++;   /* = depth in the forward pass; keeps counting in backward */
+            for (int c = 0; c < 3; ++c) { Lg->o[c] = orig.v[c]; Lg->d[c] = dir.v[c]; }
+            Lg->shape = shape >= 0 ? hit.flat : -1;
+            if (shape >= 0) {
+                Lg->t = t;
+                for (int c = 0; c < 3; ++c) { Lg->p[c] = point.v[c]; Lg->n[c] = normal.v[c]; }
+            }
+        }
+        if (shape < 0)
+            break;
+        if (nv >= ORACLE_MAX_VERTICES) {
+            w->status = DRT_ERR_INVALID;
+            break;
+        }
+        const drt_shape_desc* sh = &scene->shapes[shape];
+        const drt_material_desc* m = hit.material >= 0 ? &scene->materials[hit.material] : NULL;
+        vertex_t* v = &vtx[nv++];
+        v->p = p;
+        v->emis_param = sh->emitter >= 0 ? scene->emitters[sh->emitter].param : -1;
+        v->color_param = m ? m->param : -1;
+        v->material = hit.material;
+        v->point = point;
+        v->normal = normal;
+        v->dir_in = v3_neg(dir);
+        v3 dir_out = bxdf_sample(m, normal, v->dir_in, &w->rng, &v->q);
+        vertex_eval(scene, v, dir_out);
+        if (!m && !w->faithful)
+            break; /* the continuation contributes exactly 0 */
+        orig = v3_add(point, v3_scale(dir_out, 1e-3)); /* pathtracer.hpp:99 */
+        dir = dir_out;
+        ++depth;
+    }
+    if ((uint64_t)nv > w->st.max_vertices)
+        w->st.max_vertices = (uint64_t)nv;
+    v3 lnext = v3_make(0, 0, 0);
+    for (int k = nv - 1; k >= 0; --k) {
+        vertex_t* v = &vtx[k];
+        v->lnext = lnext;
+        v3 contrib = v3_div(v3_scale(v3_mul(v->f, lnext), v->c), v->q);
+        v3 diffuse = v3_add(v3_make(0, 0, 0), contrib);
+        v3 emission = v->emis_param >= 0 ? param_rgb(scene, v->emis_param) : v3_make(0, 0, 0);
+        lnext = v3_div(v3_add(emission, diffuse), v->p);
+    }
+    *L = lnext;
+    return nv;
+}
+
+static int wants_grad(const drt_scene_desc* sc, int p)
+{
+    return p >= 0 && (!sc->requires_grad || sc->requires_grad[p]);
+}
+
+static void grad_add(double* out, int p, v3 g)
+{
+    double* acc = &out[p * 3];
+    for (int c = 0; c < 3; ++c)
+        acc[c] = acc[c] + g.v[c]; /* vector.hpp:187 */
 }
 
 int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
@@ -322,150 +449,118 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
             return DRT_ERR_INVALID;
     }
     const int W = cam->width, H = cam->height, spp = rp->spp;
-    const int faithful = (oracle_flags & DRT_ORACLE_FAITHFUL_CONTINUATION) != 0;
-    const int max_depth = rp->max_depth > 0 ? rp->max_depth : 0; /* 0 = unlimited (reference) */
+    const int unbiased = (oracle_flags & DRT_ORACLE_UNBIASED) != 0;
     const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;
     const int band = rp->band_rows > 0 ? rp->band_rows : 1;
     const int want_grad = out_param_grad != NULL;
-    vertex_t* vtx = (vertex_t*)malloc(sizeof(vertex_t) * ORACLE_MAX_VERTICES);
+    vertex_t* vtx = (vertex_t*)malloc(sizeof(vertex_t) * ORACLE_MAX_VERTICES * 2);
     if (!vtx)
         return DRT_ERR_OOM;
-    drt_oracle_stats st;
-    memset(&st, 0, sizeof st);
-    uint64_t nvlog = 0;
+    vertex_t* vtx2 = vtx + ORACLE_MAX_VERTICES;
+    walk_ctx w;
+    memset(&w, 0, sizeof w);
+    w.scene = scene;
+    w.rp = rp;
+    w.faithful = (oracle_flags & DRT_ORACLE_FAITHFUL_CONTINUATION) != 0 || unbiased;
+    w.zero_dir_miss = (oracle_flags & DRT_ORACLE_ZERO_DIR_MISS) != 0 || unbiased;
+    w.max_depth = rp->max_depth > 0 ? rp->max_depth : 0; /* 0 = unlimited (reference) */
+    w.vertices = vertices;
+    w.max_vertices = max_vertices;
+    w.status = DRT_OK;
     if (want_grad)
         memset(out_param_grad, 0, sizeof(double) * 3 * (size_t)scene->n_params);
     if (rng_mode == DRT_ORACLE_RNG_LIBC)
         srand(rp->seed);
-    rng_t rng;
-    rng.mode = rng_mode;
+    w.rng.mode = rng_mode;
     v3 eye = v3_make(cam->eye[0], cam->eye[1], cam->eye[2]);
-    int status = DRT_OK;
 
-    for (int y = 0; y < H && status == DRT_OK; ++y) {
+    for (int y = 0; y < H && w.status == DRT_OK; ++y) {
         if (n_shards > 1 && (y / band) % n_shards != rp->shard)
             continue;
-        for (int x = 0; x < W && status == DRT_OK; ++x) {
+        for (int x = 0; x < W && w.status == DRT_OK; ++x) {
             size_t pix = (size_t)y * W + x;
             v3 pixel = v3_make(0, 0, 0);
             /* gradient image: what param.grad() gains from this pixel's samples alone */
             double before[3] = {0, 0, 0};
-            if (want_grad && g_gimg_out && g_gimg_param >= 0 && g_gimg_param < scene->n_params)
+            const int gimg = want_grad && g_gimg_out && g_gimg_param >= 0 && g_gimg_param < scene->n_params;
+            if (gimg)
                 for (int c = 0; c < 3; ++c) {
                     before[c] = out_param_grad[g_gimg_param * 3 + c];
-                    out_param_grad[g_gimg_param * 3 + c] = 0.0;    /* fresh accumulator, like zeroing grad() */
+                    out_param_grad[g_gimg_param * 3 + c] = 0.0; /* fresh accumulator, like zeroing grad() */
                 }
             for (int i = 0; i < spp; ++i) {
                 uint64_t path = (uint64_t)pix * spp + i;
-                rng.path_key = drt_rng_path_key(rp->seed, path);
-                rng.draw = 0;
-                int logging = vertices && path < dump_paths;
-                v3 dir = camera_sample(cam, x, y, &rng);
-                v3 orig = eye;
-                int depth = 0, nv = 0;
-                /* forward walk: Pathtracer::trace / scatter, pathtracer.hpp:91-136 */
-                for (;;) {
-                    if (max_depth && depth >= max_depth)
-                        break; /* extension, not in the reference */
-                    if (depth >= rp->min_bounces && rng_uniform(&rng) < rp->absorb)
-                        break;
-                    double p = depth >= rp->min_bounces ? (1 - rp->absorb) : 1;
-                    v3 point = v3_make(0, 0, 0), normal = v3_make(0, 0, 0);
-                    double t;
-                    int zero_dir = dir.v[0] == 0 && dir.v[1] == 0 && dir.v[2] == 0;
-                    const hit_t hit = raycast(scene, orig, dir, &point, &normal, &t);
-                    const int shape = hit.shape;
-                    if (zero_dir) st.zero_dir_segments++; else st.segments++;
-                    if (logging && nvlog < max_vertices) {
-                        drt_oracle_vertex* L = &vertices[nvlog++];
-                        memset(L, 0, sizeof *L);
-                        L->path = (double)path;
-                        L->depth = depth;
-                        for (int c = 0; c < 3; ++c) { L->o[c] = orig.v[c]; L->d[c] = dir.v[c]; }
-                        L->shape = shape >= 0 ? hit.flat : -1;
-                        if (shape >= 0) {
-                            L->t = t;
-                            for (int c = 0; c < 3; ++c) { L->p[c] = point.v[c]; L->n[c] = normal.v[c]; }
-                        }
-                    }
-                    if (shape < 0)
-                        break;
-                    if (nv >= ORACLE_MAX_VERTICES) {
-                        status = DRT_ERR_INVALID;
-                        break;
-                    }
-                    const drt_shape_desc* sh = &scene->shapes[shape];
-                    const drt_material_desc* m = hit.material >= 0 ? &scene->materials[hit.material] : NULL;
-                    vertex_t* v = &vtx[nv++];
-                    v->p = p;
-                    v->emis_param = sh->emitter >= 0 ? scene->emitters[sh->emitter].param : -1;
-                    v->color_param = m ? m->param : -1;
-                    v3 dir_in = v3_neg(dir);
-                    v3 dir_out = bxdf_sample(m, normal, dir_in, &rng, &v->q);
-                    if (m) {
-                        v->bscalar = bxdf_scalar(m, normal, dir_in, dir_out, &v->bdiv);
-                        v3 color = v3_make(scene->params[m->param * 3], scene->params[m->param * 3 + 1],
-                                           scene->params[m->param * 3 + 2]);
-                        v->f = v->bdiv ? v3_div(color, v->bscalar) : v3_scale(color, v->bscalar);
-                    } else {
-                        v->bscalar = 0;
-                        v->bdiv = 0;
-                        v->f = v3_make(0, 0, 0); /* pathtracer.hpp:38-39 */
-                    }
-                    v->c = v3_dot(normal, dir_out);
-                    if (!m && !faithful)
-                        break; /* the continuation contributes exactly 0 */
-                    orig = v3_add(point, v3_scale(dir_out, 1e-3)); /* pathtracer.hpp:99 */
-                    dir = dir_out;
-                    ++depth;
-                }
-                if ((uint64_t)nv > st.max_vertices)
-                    st.max_vertices = (uint64_t)nv;
-                /* reverse sweep: L_k = (E + (0 + ((f*L_{k+1})*c)/q)) / p
-                 * pathtracer.hpp:104 (vector.hpp:515,532), integrate.hpp:31,34
-                 * (vector.hpp:553,493), pathtracer.hpp:114,133 */
-                v3 lnext = v3_make(0, 0, 0);
-                for (int k = nv - 1; k >= 0; --k) {
-                    vertex_t* v = &vtx[k];
-                    v->lnext = lnext;
-                    v3 contrib = v3_div(v3_scale(v3_mul(v->f, lnext), v->c), v->q);
-                    v3 diffuse = v3_add(v3_make(0, 0, 0), contrib);
-                    v3 emission = v3_make(0, 0, 0);
-                    if (v->emis_param >= 0)
-                        emission = v3_make(scene->params[v->emis_param * 3],
-                                           scene->params[v->emis_param * 3 + 1],
-                                           scene->params[v->emis_param * 3 + 2]);
-                    lnext = v3_div(v3_add(emission, diffuse), v->p);
-                }
-                pixel = v3_add(pixel, v3_div(lnext, 1.0)); /* render.cpp:78, pdf = 1 */
-                /* backward: vector.hpp:420-484 walked from the root, render.cpp:80 */
+                w.rng.path_key = drt_rng_path_key(rp->seed, path);
+                w.rng.draw = 0;
+                w.logging = vertices && path < dump_paths;
+                w.log_path = (double)path;
+                w.log_ord = 0;
+                v3 dir = camera_sample(cam, x, y, &w.rng);
+                v3 L0;
+                int nv = walk(&w, eye, dir, 0, vtx, &L0);
+                pixel = v3_add(pixel, v3_div(L0, 1.0)); /* render.cpp:78, pdf = 1 */
                 if (want_grad) {
-                    v3 g = v3_make(1, 1, 1);
+                    v3 g = v3_make(1, 1, 1); /* render.cpp:80 */
                     if (adjoint_rgb)
                         g = v3_make(adjoint_rgb[pix * 3], adjoint_rgb[pix * 3 + 1], adjoint_rgb[pix * 3 + 2]);
-                    for (int k = 0; k < nv; ++k) {
-                        vertex_t* v = &vtx[k];
-                        v3 g1 = v3_div(g, v->p);                       /* ScalarDivBackward :479 */
-                        if (v->emis_param >= 0 &&
-                            (!scene->requires_grad || scene->requires_grad[v->emis_param])) {
-                            double* acc = &out_param_grad[v->emis_param * 3];
-                            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + g1.v[c]; /* :187 */
+                    if (!unbiased) {
+                        /* biased: the forward samples are reused; vector.hpp:420-484 from the root */
+                        for (int k = 0; k < nv; ++k) {
+                            vertex_t* v = &vtx[k];
+                            v3 g1 = v3_div(g, v->p);                   /* ScalarDivBackward :479 */
+                            if (wants_grad(scene, v->emis_param))
+                                grad_add(out_param_grad, v->emis_param, g1);
+                            v3 g2 = v3_div(g1, v->q);                  /* ScalarDivBackward */
+                            v3 g3 = v3_scale(g2, v->c);                /* ScalarMulBackward :457 */
+                            if (wants_grad(scene, v->color_param)) {
+                                v3 df = v3_mul(v->lnext, g3);          /* MulBackward :446 */
+                                grad_add(out_param_grad, v->color_param,
+                                         v->bdiv ? v3_div(df, v->bscalar) : v3_scale(df, v->bscalar));
+                            }
+                            g = v3_mul(v->f, g3);                      /* MulBackward :447 */
                         }
-                        v3 g2 = v3_div(g1, v->q);                      /* ScalarDivBackward */
-                        v3 g3 = v3_scale(g2, v->c);                    /* ScalarMulBackward :457 */
-                        if (v->color_param >= 0 &&
-                            (!scene->requires_grad || scene->requires_grad[v->color_param])) {
-                            v3 df = v3_mul(v->lnext, g3);              /* MulBackward :446 */
-                            v3 dc = v->bdiv ? v3_div(df, v->bscalar) : v3_scale(df, v->bscalar);
-                            double* acc = &out_param_grad[v->color_param * 3];
-                            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + dc.v[c];
+                    } else if (nv > 0) {
+                        /* unbiased: IntegrateBackward (integrate.hpp:11-24) at every vertex draws a
+                         * FRESH direction, evaluates forward(sample) -- a new suffix path -- and
+                         * back-propagates grad / pdf through it; the recursion continues down the
+                         * NEW path, whose first vertex becomes the next `cur` */
+                        vertex_t cur = vtx[0];
+                        int depth = 0;
+                        for (;;) {
+                            v3 g1 = v3_div(g, cur.p);                  /* "/ p" of trace() */
+                            if (wants_grad(scene, cur.emis_param))     /* AddBackward: emission first */
+                                grad_add(out_param_grad, cur.emis_param, g1);
+                            if (cur.material < 0) {
+                                /* no BxDF: sampler gives a zero direction without drawing, f = 0, and
+                                 * forward() still re-traces the zero-length ray (a constant 0) */
+                                v3 Lz;
+                                (void)walk(&w, cur.point, v3_make(0, 0, 0), depth + 1, vtx2, &Lz);
+                                break;
+                            }
+                            const drt_material_desc* m = &scene->materials[cur.material];
+                            double q;
+                            v3 dir_out = bxdf_sample(m, cur.normal, cur.dir_in, &w.rng, &q);
+                            vertex_eval(scene, &cur, dir_out);
+                            v3 Ls;
+                            int nv2 = walk(&w, v3_add(cur.point, v3_scale(dir_out, 1e-3)), dir_out, depth + 1, vtx2, &Ls);
+                            v3 seed = v3_div(g1, q);                   /* grad / pdf, integrate.hpp:17 */
+                            v3 g3 = v3_scale(seed, cur.c);             /* ScalarMulBackward */
+                            if (wants_grad(scene, cur.color_param)) {
+                                v3 df = v3_mul(Ls, g3);                /* MulBackward: brdf side */
+                                grad_add(out_param_grad, cur.color_param,
+                                         cur.bdiv ? v3_div(df, cur.bscalar) : v3_scale(df, cur.bscalar));
+                            }
+                            if (nv2 == 0)
+                                break;     /* the suffix is a constant: nothing below */
+                            g = v3_mul(cur.f, g3);                     /* MulBackward: radiance side */
+                            cur = vtx2[0];
+                            ++depth;
                         }
-                        g = v3_mul(v->f, g3);                          /* MulBackward :447 */
                     }
                 }
-                st.paths++;
+                w.st.paths++;
             }
-            if (want_grad && g_gimg_out && g_gimg_param >= 0 && g_gimg_param < scene->n_params)
+            if (gimg)
                 for (int c = 0; c < 3; ++c) {
                     double* acc = &out_param_grad[g_gimg_param * 3 + c];
                     g_gimg_out[pix * 3 + c] = *acc / (double)spp;
@@ -480,10 +575,10 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
     }
     free(vtx);
     if (stats)
-        *stats = st;
+        *stats = w.st;
     if (n_vertices)
-        *n_vertices = nvlog;
-    return status;
+        *n_vertices = w.nvlog;
+    return w.status;
 }
 
 /* sizeof / offsetof of the ABI records as the C compiler lays them out (host-binding tests) */

@@ -43,7 +43,9 @@ def run(case):
     r = O.render_reference(scene, cam, rp, backward=True, adjoint=adjoint,
                            rng_mode=case.get("rng_mode", O.RNG_KEYED),
                            dump_paths=case.get("dump_paths", 0),
-                           grad_image_param=case.get("grad_image_param", -1))
+                           grad_image_param=case.get("grad_image_param", -1),
+                           tracer_mode=2 if case.get("unbiased") else 0,
+                           zero_dir_miss=bool(case.get("unbiased")))
     out = {"case": json.dumps(case), "grads": r["grads"],
            "segments": np.int64(r["stats"]["segments"]),
            "zero_dir_segments": np.int64(r["stats"]["zero_dir_segments"]),
@@ -96,6 +98,17 @@ SMALL = [
          absorb=1.0, seed=4, grad_image_param=0),
     dict(name="g13_gradimage_white_40x40x6_rr", scene="cornell_specular", width=40, height=40, spp=6,
          min_bounces=2, absorb=0.3, seed=6, grad_image_param=2, adjoint_seed=3),
+    # unbiased integration operator (integrate.hpp:39-52) through the harness tracer
+    dict(name="u1_unbiased_cornell_40x30x4_rr", scene="cornell", width=40, height=30, spp=4, min_bounces=2,
+         absorb=0.4, seed=3, unbiased=True, dump_paths=64),
+    dict(name="u2_unbiased_cornell_48x48x4_d4", scene="cornell", width=48, height=48, spp=4, min_bounces=4,
+         absorb=1.0, seed=5, unbiased=True),
+    dict(name="u3_unbiased_specular_32x32x4_adj", scene="cornell_specular", width=32, height=32, spp=4,
+         min_bounces=1, absorb=0.5, seed=7, unbiased=True, adjoint_seed=4),
+    dict(name="u4_unbiased_emissive_wall_32x24x4", scene="cornell_emissive_wall", width=32, height=24, spp=4,
+         min_bounces=3, absorb=0.3, seed=9, unbiased=True),
+    dict(name="u5_unbiased_mesh10x12_24x24x3", scene="mesh10x12", width=24, height=24, spp=3, min_bounces=2,
+         absorb=0.3, seed=4, unbiased=True),
     dict(name="g11_mesh40x40_48x48x4_d5", scene="mesh40x40", width=48, height=48, spp=4, min_bounces=5,
          absorb=1.0, seed=9),
 ]

@@ -23,6 +23,8 @@ REF_HARNESS = os.path.join(ORACLE_DIR, "_ref", "ref_harness")
 
 RNG_KEYED, RNG_LIBC = 0, 1
 FAITHFUL_CONTINUATION = 0x1
+UNBIASED = 0x2          # integrate(..., unbiased=true): backward re-samples at every vertex
+ZERO_DIR_MISS = 0x4     # zero-length rays never hit (see ref_harness.cpp)
 
 
 def load_pkg():
@@ -75,7 +77,7 @@ def lib() -> C.CDLL:
 
 def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray] = None,
            rng_mode: int = RNG_KEYED, faithful: bool = False, dump_paths: int = 0,
-           grad_image_param: int = -1):
+           grad_image_param: int = -1, unbiased: bool = False, zero_dir_miss: bool = False):
     """-> dict(image f64 [H,W,3], grads f64 [P,3] | None, stats dict, vertices f64 [n,16] | None,
     grad_image f64 [H,W,3] | None)"""
     sd, keep = scene.to_desc()
@@ -100,7 +102,8 @@ def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray]
         gimg = np.zeros((cam.height, cam.width, 3), dtype=np.float64)
         lib().drt_oracle_set_gradient_image(grad_image_param, gimg.ctypes.data_as(C.c_void_p))
     rc = lib().drt_oracle_render(C.byref(sd), C.byref(cd), C.byref(rd), rng_mode,
-                                 FAITHFUL_CONTINUATION if faithful else 0, adj_ptr,
+                                 (FAITHFUL_CONTINUATION if faithful else 0) | (UNBIASED if unbiased else 0)
+                                 | (ZERO_DIR_MISS if zero_dir_miss else 0), adj_ptr,
                                  img.ctypes.data_as(C.c_void_p),
                                  grads.ctypes.data_as(C.c_void_p) if backward else None,
                                  C.byref(st),
@@ -126,7 +129,8 @@ def have_reference() -> bool:
 
 
 def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, dump_paths: int,
-                     adjoint_file: str = "none", grad_image_param: int = -1):
+                     adjoint_file: str = "none", grad_image_param: int = -1, tracer_mode: int = 0,
+                     zero_dir_miss: bool = False):
     with open(path, "w") as f:
         f.write(f"params {len(scene.params)}\n")
         for rgb, rg in zip(scene.params, scene.requires_grad):
@@ -153,11 +157,15 @@ def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, d
         f.write(f"render {rp.spp} {rp.min_bounces} {rp.absorb!r} {rp.seed} {rng_mode} {int(backward)} {dump_paths}\n")
         f.write(f"adjoint {adjoint_file}\n")
         f.write(f"gradimage {grad_image_param}\n")
+        f.write(f"mode {tracer_mode} {int(zero_dir_miss)}\n")
 
 
 def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray] = None,
-                     rng_mode: int = RNG_KEYED, dump_paths: int = 0, grad_image_param: int = -1):
-    """Run the UNMODIFIED reference headers through oracle/_ref/ref_harness. Same return shape as
+                     rng_mode: int = RNG_KEYED, dump_paths: int = 0, grad_image_param: int = -1,
+                     tracer_mode: int = 0, zero_dir_miss: bool = False):
+    """tracer_mode 0 = drt::Pathtracer, 1 = the harness tracer (biased), 2 = the harness tracer with the
+    reference's unbiased integration operator.
+    Run the UNMODIFIED reference headers through oracle/_ref/ref_harness. Same return shape as
     render(); stats carry the harness's raycast counters and its wall time."""
     if not have_reference():
         raise RuntimeError("oracle/_ref/ref_harness not built (needs /root/reference)")
@@ -168,7 +176,8 @@ def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[n
             adj_file = os.path.join(td, "adj.f32")
             np.ascontiguousarray(adjoint, dtype=np.float32).tofile(adj_file)
         sf = os.path.join(td, "scene.txt")
-        write_scene_file(sf, scene, cam, rp, rng_mode, backward, dump_paths, adj_file, grad_image_param)
+        write_scene_file(sf, scene, cam, rp, rng_mode, backward, dump_paths, adj_file, grad_image_param,
+                         tracer_mode, zero_dir_miss)
         prefix = os.path.join(td, "out")
         subprocess.run([REF_HARNESS, sf, prefix], check=True, stderr=subprocess.DEVNULL)
         meta = json.load(open(prefix + ".json"))

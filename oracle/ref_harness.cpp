@@ -23,6 +23,8 @@
 //   render spp min_bounces absorb seed rng_mode(0 keyed,1 libc) backward dump_paths
 //   adjoint <file|none>   (raw f32 W*H*3)
 //   gradimage <param|-1>  per-pixel gradient image of one parameter -> <prefix>.gimg.f64
+//   mode <tracer 0|1|2> <zero_dir_miss 0|1>   tracer 0 = drt::Pathtracer, 1 = HarnessTracer biased,
+//                         2 = HarnessTracer unbiased (integrate(..., true), integrate.hpp:39-52)
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -72,6 +74,12 @@ static bool g_cur_open = false;
 static uint64_t g_raycasts = 0, g_zero_raycasts = 0;
 static double g_cur_path = 0;
 static int g_cur_depth = 0;
+// zero-length rays never hit: the reference keeps recursing with a zero direction after a hit on
+// a shape without BxDF (pathtracer.hpp:26,102); whether that ray re-hits the light from its own
+// surface depends on the last bit of |P - C|^2 - r^2, and so does the number of draws it consumes.
+// Those rays contribute exactly 0 either way; with this switch they consume exactly one roulette
+// draw, which makes the draw positions of a following unbiased backward pass well defined.
+static bool g_zero_dir_miss = false;
 
 static void close_vertex()
 {
@@ -117,6 +125,8 @@ public:
       : drt::Shape<T>(bxdf, emitter), m_inner(std::move(inner)), m_index(index) { }
     bool intersect(V3 orig, V3 dir, double& t) const override
     {
+        if (g_zero_dir_miss && dir[0] == 0 && dir[1] == 0 && dir[2] == 0)
+            return false;
         bool hit = m_inner->intersect(orig, dir, t);
         m_last_t = t;
         return hit;
@@ -171,6 +181,68 @@ private:
     V3 m_v0, m_e1, m_e2, m_n;
 };
 
+// The reference's Pathtracer hard-codes the biased estimator (pathtracer.hpp:110-111 passes
+// `false`), so its unbiased integration operator is unreachable from it.  This tracer is the same
+// algorithm written against the reference's own pieces -- Shape::intersect/normal/bxdf/emitter,
+// internal::sample_bxdf / eval_bxdf / emission (pathtracer.hpp:17-49) and drt::integrate
+// (integrate.hpp:56-66) -- with the flag exposed.  With unbiased = false it must reproduce
+// drt::Pathtracer bit for bit (checked by tests/test_oracle_golden.py).
+class HarnessTracer {
+public:
+    HarnessTracer(double absorb, std::size_t min_bounces, bool unbiased)
+      : m_absorb(absorb), m_min_bounces(min_bounces), m_unbiased(unbiased) { }
+
+    P3 trace(const drt::Scene<T>& scene, V3 orig, V3 dir, std::size_t depth = 0) const
+    {
+        if (depth >= m_min_bounces && drt::random::uniform() < m_absorb)
+            return V3(0.);
+        double p = depth >= m_min_bounces ? (1 - m_absorb) : 1;
+        Hit hit;
+        if (!raycast(scene, orig, dir, hit))
+            return V3(0.);
+        return scatter(scene, hit, dir, depth) / p;
+    }
+
+private:
+    struct Hit { V3 point, normal; drt::BxDF<T>* bxdf; drt::Emitter<T>* emitter; };
+
+    bool raycast(const drt::Scene<T>& scene, V3 orig, V3 dir, Hit& hit) const
+    {
+        double tmin = drt::inf;
+        for (auto shape : scene) {
+            double t;
+            if (!shape->intersect(orig, dir, t) || t >= tmin)
+                continue;
+            tmin = t;
+            hit.point = orig + t * dir;
+            hit.normal = shape->normal(hit.point);
+            hit.bxdf = shape->bxdf();
+            hit.emitter = shape->emitter();
+        }
+        return !std::isinf(tmin);
+    }
+
+    P3 scatter(const drt::Scene<T>& scene, const Hit& hit, V3 dir_in, std::size_t depth) const
+    {
+        P3 diffuse = drt::integrate<T, 3>(
+            [=](const V3& dir_out) {
+                V3 orig = hit.point + 1e-3 * dir_out;
+                P3 brdf_value = drt::internal::eval_bxdf(hit.bxdf, hit.normal, -dir_in, dir_out);
+                P3 radiance = trace(scene, orig, dir_out, depth + 1);
+                double cos_theta = drt::dot(hit.normal, dir_out);
+                return brdf_value * radiance * cos_theta;
+            },
+            [=]() { return drt::internal::sample_bxdf(hit.bxdf, hit.normal, -dir_in); },
+            1, m_unbiased);
+        P3 emission = drt::internal::emission(hit.emitter);
+        return emission + diffuse;
+    }
+
+    double m_absorb;
+    std::size_t m_min_bounces;
+    bool m_unbiased;
+};
+
 struct MeshData {
     std::vector<V3> verts;
     std::vector<std::array<int, 4>> tris;   // i, j, k, material (-1 = the shape's)
@@ -202,7 +274,7 @@ int main(int argc, char** argv)
     double vfov = 1.3963, absorb = 0.5;
     V3 eye(0.), fwd(0.), right(0.), up(0.);
     std::string adjoint_file = "none";
-    int gimg_param = -1;
+    int gimg_param = -1, tracer_mode = 0, zero_dir_miss = 0;
 
     while (in >> tok) {
         if (tok == "params") {
@@ -284,6 +356,8 @@ int main(int argc, char** argv)
             in >> adjoint_file;
         } else if (tok == "gradimage") {
             in >> gimg_param;
+        } else if (tok == "mode") {
+            in >> tracer_mode >> zero_dir_miss;
         } else {
             die("unknown token in scene file");
         }
@@ -313,6 +387,8 @@ int main(int argc, char** argv)
 
     drt::Camera<T> cam(W, H, vfov, eye, fwd, right, up);
     drt::Pathtracer<T> tracer(absorb, (size_t)min_bounces);
+    HarnessTracer htracer(absorb, (size_t)min_bounces, tracer_mode == 2);
+    g_zero_dir_miss = zero_dir_miss != 0;
     std::vector<double> img((size_t)W * H * 3, 0.0);
     std::vector<double> gimg(gimg_param >= 0 ? (size_t)W * H * 3 : 0, 0.0);
     V3 gtotal(0.);
@@ -334,7 +410,8 @@ int main(int argc, char** argv)
                 g_cur_path = (double)path;
                 g_cur_depth = 0;
                 auto [dir, pdf] = cam.sample(x, y);
-                P3 radiance = tracer.trace(scene, cam.eye(), dir);
+                P3 radiance = tracer_mode == 0 ? tracer.trace(scene, cam.eye(), dir)
+                                               : htracer.trace(scene, cam.eye(), dir);
                 pixel += radiance.detach() / pdf;
                 if (backward) {
                     V3 g(1.);

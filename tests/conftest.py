@@ -57,6 +57,11 @@ SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_
                  "g11_mesh40x40_48x48x4_d5"]
 
 
+UNBIASED_GOLDENS = ["u1_unbiased_cornell_40x30x4_rr", "u2_unbiased_cornell_48x48x4_d4",
+                    "u3_unbiased_specular_32x32x4_adj", "u4_unbiased_emissive_wall_32x24x4",
+                    "u5_unbiased_mesh10x12_24x24x3"]
+
+
 @pytest.fixture(scope="session")
 def hip(pkg):
     """One context on device 0 for the gpu tests. No fallback: raises without the HIP library."""

@@ -4,7 +4,7 @@ keeps the reference's operation order and shares its libm."""
 import numpy as np
 import pytest
 
-from conftest import SMALL_GOLDENS, case_inputs, load_golden
+from conftest import SMALL_GOLDENS, UNBIASED_GOLDENS, case_inputs, load_golden
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS + ["g6_libc_64x64x8_d4"])
@@ -44,6 +44,43 @@ def test_gradient_image_bit_exact(pkg, oracle, name):
     np.testing.assert_array_equal(r["grads"], g["grads"])
     p = g["case"]["grad_image_param"]
     np.testing.assert_allclose(r["grad_image"].sum((0, 1)) * rp.spp, r["grads"][p], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", UNBIASED_GOLDENS)
+def test_unbiased_integrator_bit_exact(pkg, oracle, name):
+    """integrate(..., unbiased=true): fixtures from the reference's own integration operator driven
+    by the harness tracer (the reference's Pathtracer hard-codes the biased one).  Forward image
+    equals the biased image; backward re-samples, so the gradients are a different sample set."""
+    g = load_golden(name)
+    scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
+    dump = g["case"].get("dump_paths", 0)
+    r = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, unbiased=True, dump_paths=dump)
+    np.testing.assert_array_equal(r["image"], g["image"])
+    np.testing.assert_array_equal(r["grads"], g["grads"])
+    assert r["stats"]["segments"] == int(g["segments"])
+    assert r["stats"]["zero_dir_segments"] == int(g["zero_dir_segments"])
+    if dump:
+        np.testing.assert_array_equal(r["vertices"], g["vertices"])
+    b = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint)
+    np.testing.assert_array_equal(b["image"], r["image"])
+    assert not np.array_equal(b["grads"], r["grads"])
+
+
+@pytest.mark.skipif("not __import__('os').path.exists('/root/reference/include/drt')")
+def test_harness_tracer_is_the_reference_pathtracer(pkg, oracle):
+    """The harness's own tracer (needed to reach the unbiased operator) with unbiased = false
+    reproduces drt::Pathtracer bit for bit, and the zero-length-ray switch changes no value."""
+    oracle.build()
+    scene, cam = pkg.cornell_box(), pkg.cornell_camera(28, 20)
+    rp = pkg.RenderParams(spp=4, min_bounces=2, absorb=0.4, seed=3)
+    a = oracle.render_reference(scene, cam, rp, backward=True, tracer_mode=0)
+    b = oracle.render_reference(scene, cam, rp, backward=True, tracer_mode=1)
+    c = oracle.render_reference(scene, cam, rp, backward=True, tracer_mode=1, zero_dir_miss=True)
+    for x in (b, c):
+        np.testing.assert_array_equal(a["image"], x["image"])
+        np.testing.assert_array_equal(a["grads"], x["grads"])
+        assert a["stats"]["segments"] == x["stats"]["segments"]
+    assert a["stats"]["zero_dir_segments"] == b["stats"]["zero_dir_segments"]
 
 
 def test_libc_stream_known_answers(pkg, oracle):
