@@ -408,7 +408,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #define DRT_LAUNCH_SHADE(SPEC)                                                                            \
     hipLaunchKernelGGL((k_shade<R, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene,      \
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, \
-                       ck, cn, bvh.tri_shade)
+                       ck, cn, bvh.tri_shade, 0, (const uint32_t*)nullptr)
                     if (ctx->has_specular) DRT_LAUNCH_SHADE(true);
                     else DRT_LAUNCH_SHADE(false);
 #undef DRT_LAUNCH_SHADE

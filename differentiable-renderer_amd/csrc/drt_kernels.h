@@ -89,13 +89,19 @@ __device__ inline double u01(double, uint32_t r) { return (double)r / DRT_RAND_M
 __device__ inline float one_minus_u01(float, uint32_t r) { return (float)(2147483647u - r) * (float)(1.0 / DRT_RAND_MAX_D); }
 __device__ inline double one_minus_u01(double, uint32_t r) { return 1.0 - (double)r / DRT_RAND_MAX_D; }
 
-// index of the first BxDF draw at depth k: 2 camera draws, 2 per earlier vertex, one roulette
-// draw per depth >= min_bounces up to and including k (draw order: SURVEY 3.1)
-__device__ inline uint32_t draw_index(int k, int min_bounces)
+// Draw bookkeeping (draw order: SURVEY 3.1).  A path segment that starts at depth s has a BASE =
+// the index of its first BxDF draw (theta at depth s; the roulette draw of depth s, if any, comes
+// right before it).  The theta draw of depth k >= s is then
+//   base + 2 (k - s) + #{roulette draws at depths s+1 .. k} ,
+// phi follows it, and the roulette draw of depth k+1 (if k+1 >= min_bounces) follows phi.
+// Camera paths: s = 0, base = 2 camera draws (+1 if depth 0 has a roulette draw).
+__device__ inline uint32_t draw_offset(int k, int s, int min_bounces)
 {
-    int rr = k - min_bounces + 1;
-    return 2u + 2u * (uint32_t)k + (uint32_t)(rr > 0 ? rr : 0);
+    const int first_rr = min_bounces > s + 1 ? min_bounces : s + 1;
+    const int rr = k - first_rr + 1;
+    return 2u * (uint32_t)(k - s) + (uint32_t)(rr > 0 ? rr : 0);
 }
+__device__ inline uint32_t camera_draw_base(int min_bounces) { return 2u + (min_bounces <= 0 ? 1u : 0u); }
 
 // ---- K1 ---------------------------------------------------------------------------------------
 // One wave per queue region: generates the camera rays of its region's paths and compacts the
@@ -451,6 +457,61 @@ __device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have,
     }
 }
 
+// what was hit: position, normal (as the reference's Shape::normal returns it), material, emitter
+template <typename R>
+__device__ inline void resolve_hit(const SceneLds<R>& lds, const typename Q4<R>::T* __restrict__ tri_shade,
+                                   int prim, V3<R> P, V3<R>& nrm, int& material, int& emitter)
+{
+    if (prim < lds.sc.n_shapes) {
+        const DevShape<R>& sh = lds.sc.shapes[prim];
+        nrm = shape_normal(sh, P);
+        material = sh.material;
+        emitter = sh.emitter;
+    } else {                                       // triangle: per-triangle record
+        const typename Q4<R>::T ts = tri_shade[prim - lds.sc.n_shapes];
+        const uint32_t ids = pid_unpack(ts.w);
+        nrm = mk<R>(ts.x, ts.y, ts.z);
+        material = (ids & 0xFFFFu) == 0xFFFFu ? -1 : (int)(ids & 0xFFFFu);
+        emitter = (ids >> 16) == 0xFFFFu ? -1 : (int)(ids >> 16);
+    }
+}
+
+// BxDF::sample + BxDF::operator() for one vertex: r1, r2 are the two 31-bit draws; returns the
+// sampled direction wo, its pdf q and the scalar bs with f = colour * bs.
+//   Diffuse  (bxdf.hpp:56-83):  theta = asin(sqrt(u1)) => sin = sqrt(u1), cos = sqrt(1-u1); 1 - u1
+//            comes from the exact integer RAND_MAX - r so cos (and the pdf) is never rounded to 0
+//   Specular (bxdf.hpp:85-124): cos^2(theta) = u1^(2/(e+2)); sin^2 formed in double
+template <typename R, bool SPEC>
+__device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, uint32_t r1, uint32_t r2,
+                                   V3<R>& wo, R& q, R& bs)
+{
+    const R u2 = u01(R(0), r2);
+    R sphi, cphi;
+    sincospi_r(R(2) * u2, &sphi, &cphi);                       // phi = 2 pi u2
+    V3<R> tg, bt;
+    make_frame(nrm, tg, bt);
+    if (!SPEC || m.type == DRT_BXDF_DIFFUSE) {
+        const R st = sqrt_r(u01(R(0), r1)), ct = sqrt_r(one_minus_u01(R(0), r1));
+        wo = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
+        q = ct * (R)(1.0 / DRT_PI);
+        bs = (R)(1.0 / DRT_PI);                                // bxdf.hpp:63-67: color / pi
+    } else {
+        const double c2 = pow((double)r1 / DRT_RAND_MAX_D, 2.0 / ((double)m.exponent + 2.0));
+        const R ct = sqrt_r((R)c2), st = sqrt_r((R)(1.0 - c2));
+        const V3<R> wi = -d;
+        V3<R> hv = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
+        if (dot(hv, wi) < R(0))
+            hv = reflect(hv, nrm);
+        wo = reflect(wi, hv);
+        q = m.norm * pow_r(ct, m.exponent + R(1)) * st;
+        const V3<R> hw = normalize(wi + wo);                   // bxdf.hpp:91-104
+        const R ch = dot(nrm, hw);
+        R s2 = (R(1) - ch) * (R(1) + ch);
+        s2 = s2 > R(0) ? s2 : R(0);
+        bs = m.norm * pow_r(ch, m.exponent) * sqrt_r(s2);
+    }
+}
+
 // first region >= w (stepping by n_waves) that has live rays; its count in cnt
 __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_k, uint32_t w, uint32_t n_waves,
                                             uint32_t n_regions, uint32_t& cnt)
@@ -478,7 +539,8 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         uint2* __restrict__ next_id,
         TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
         const uint32_t* __restrict__ counts_k,
-        uint32_t* __restrict__ counts_next, const typename Q4<R>::T* __restrict__ tri_shade)
+        uint32_t* __restrict__ counts_next, const typename Q4<R>::T* __restrict__ tri_shade,
+        int seg_start, const uint32_t* __restrict__ draw_base)
 {
     typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
@@ -486,9 +548,10 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const int n_shapes = lds.sc.n_shapes;
     const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
-    const uint32_t n_theta = draw_index(k, a.min_bounces);
+    // camera paths start at depth 0 with a closed-form base; re-sampled suffixes (unbiased
+    // backward) start at seg_start with a per-path base
+    const uint32_t n_off = draw_offset(k, seg_start, a.min_bounces) + (draw_base ? 0u : camera_draw_base(a.min_bounces));
     const bool next_rr = (k + 1) >= a.min_bounces;
     const bool next_cap = (k + 1) >= a.depth_cap;
 
@@ -528,18 +591,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                 const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
                 V3<R> nrm;
                 int material, emitter;
-                if (h.prim < n_shapes) {
-                    const DevShape<R>& sh = lds.sc.shapes[h.prim];
-                    nrm = shape_normal(sh, P);
-                    material = sh.material;
-                    emitter = sh.emitter;
-                } else {                                       // triangle: per-triangle record
-                    const R4 ts = tri_shade[h.prim - n_shapes];
-                    const uint32_t ids = pid_unpack(ts.w);
-                    nrm = mk<R>(ts.x, ts.y, ts.z);
-                    material = (ids & 0xFFFFu) == 0xFFFFu ? -1 : (int)(ids & 0xFFFFu);
-                    emitter = (ids >> 16) == 0xFFFFu ? -1 : (int)(ids >> 16);
-                }
+                resolve_hit(lds, tri_shade, h.prim, P, nrm, material, emitter);
                 // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
                 uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
                 if (emitter >= 0)
@@ -556,39 +608,10 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     const DevMaterial<R>& m = lds.sc.materials[material];
                     cid = (uint32_t)m.param;
                     const uint32_t key = cur.rid.y;
-                    const uint32_t r1 = drt_rng_draw(key, n_theta);
-                    const R u2 = u01(R(0), drt_rng_draw(key, n_theta + 1));
-                    R sphi, cphi;
-                    sincospi_r(R(2) * u2, &sphi, &cphi);       // phi = 2 pi u2
-                    V3<R> tg, bt;
-                    make_frame(nrm, tg, bt);
+                    const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
                     V3<R> wo;
                     R q, bs;
-                    if (!SPEC || m.type == DRT_BXDF_DIFFUSE) {
-                        // bxdf.hpp:69-79: theta = asin(sqrt(u1)) => sin = sqrt(u1), cos = sqrt(1-u1);
-                        // 1 - u1 comes from the exact integer RAND_MAX - r so cos (and the pdf)
-                        // is never rounded to 0
-                        const R st = sqrt_r(u01(R(0), r1)), ct = sqrt_r(one_minus_u01(R(0), r1));
-                        wo = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
-                        q = ct * (R)(1.0 / DRT_PI);
-                        bs = (R)(1.0 / DRT_PI);                // bxdf.hpp:63-67: color / pi
-                    } else {
-                        // bxdf.hpp:106-120: cos^2(theta) = u1^(2/(e+2)); sin^2 formed in double
-                        const double c2 = pow((double)r1 / DRT_RAND_MAX_D, 2.0 / ((double)m.exponent + 2.0));
-                        const R ct = sqrt_r((R)c2), st = sqrt_r((R)(1.0 - c2));
-                        const V3<R> wi = -d;
-                        V3<R> hv = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
-                        if (dot(hv, wi) < R(0))
-                            hv = reflect(hv, nrm);
-                        wo = reflect(wi, hv);
-                        q = m.norm * pow_r(ct, m.exponent + R(1)) * st;
-                        // bxdf.hpp:91-104
-                        const V3<R> hw = normalize(wi + wo);
-                        const R ch = dot(nrm, hw);
-                        R s2 = (R(1) - ch) * (R(1) + ch);
-                        s2 = s2 > R(0) ? s2 : R(0);
-                        bs = m.norm * pow_r(ch, m.exponent) * sqrt_r(s2);
-                    }
+                    sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
                     const R c = dot(nrm, wo);                  // pathtracer.hpp:103
                     const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
                     // roulette / cap of depth k+1, decided here so dead rays are never queued
