@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="cornell", help="cornell (headline) | cornell_specular | mesh<lat>x<lon>[f<n>] | random<seed>")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--unbiased", action="store_true", help="backward with the unbiased integration operator")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16)
@@ -69,7 +70,8 @@ def main():
     cam = pkg.cornell_camera(a.width, a.height)
     backward = not a.forward_only
     rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
-                          shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths)
+                          shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
+                          flags=pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0)
 
     r = pkg.HipRenderer(local_rank)          # raises without libdrt_hip.so / a device: no fallback
     r.upload_scene(scene)

@@ -32,6 +32,7 @@ RENDER_DEVICE_OUT = 0x2
 RENDER_SYNC = 0x4
 RENDER_TIMING = 0x8
 RENDER_F64 = 0x10
+RENDER_UNBIASED = 0x20
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce"]
 
@@ -473,7 +474,8 @@ class HipRenderer:
                     "drt_hip_update_params")
 
     def render(self, cam: Camera, rp: RenderParams, backward: bool = False,
-               adjoint: Optional[np.ndarray] = None, timing: bool = False, f64: bool = False):
+               adjoint: Optional[np.ndarray] = None, timing: bool = False, f64: bool = False,
+               unbiased: bool = False):
         """Host-buffer render. -> (image float32 [H,W,3], grads float64 [P,3] or None, stats dict)."""
         assert self.scene is not None
         flags = rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC)
@@ -483,6 +485,8 @@ class HipRenderer:
             flags |= RENDER_TIMING
         if f64:
             flags |= RENDER_F64
+        if unbiased:
+            flags |= RENDER_UNBIASED
         d = rp.to_desc()
         d.flags = flags
         img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)

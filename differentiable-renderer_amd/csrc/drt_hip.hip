@@ -48,7 +48,8 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, counts, segtotal, film, gpart, grad, adjoint, out;
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv,
+        ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
@@ -310,6 +311,28 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
     if (gimg_param >= 0)
         if ((rc = ensure(ctx, ctx->gpath, N * sizeof(R4))) != DRT_OK) return rc;
+    const bool unbiased = backward && (rp->flags & DRT_RENDER_UNBIASED) != 0 && gimg_param < 0;
+    ChainState<R> cs;
+    memset(&cs, 0, sizeof cs);
+    if (unbiased) {
+        typedef typename Q2<R>::T R2c;
+        if ((rc = ensure(ctx, ctx->ch_cva, N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_cvb, N * sizeof(R2c))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_cvh, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_nxa, N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_nxb, N * sizeof(R2c))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_nxh, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_g, N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_w, N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_lsuf, N * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_ids, N * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_ndraw, N * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ch_dbase, N * sizeof(uint32_t))) != DRT_OK) return rc;
+        cs.cv_a = (R4*)ctx->ch_cva.p; cs.cv_b = (R2c*)ctx->ch_cvb.p; cs.cv_hit = (HitRec<R>*)ctx->ch_cvh.p;
+        cs.nx_a = (R4*)ctx->ch_nxa.p; cs.nx_b = (R2c*)ctx->ch_nxb.p; cs.nx_hit = (HitRec<R>*)ctx->ch_nxh.p;
+        cs.g = (R4*)ctx->ch_g.p; cs.w = (R4*)ctx->ch_w.p; cs.lsuf = (R4*)ctx->ch_lsuf.p;
+        cs.ids = (uint32_t*)ctx->ch_ids.p; cs.ndraw = (uint32_t*)ctx->ch_ndraw.p; cs.dbase = (uint32_t*)ctx->ch_dbase.p;
+    }
     if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
     const uint64_t n_pix_batches = (n_local_pixels + Pb - 1) / Pb;
@@ -333,6 +356,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     a.band = rp->band_rows > 0 ? rp->band_rows : 1;
     a.min_bounces = rp->min_bounces;
     a.depth_cap = D;
+    a.cap_is_roulette = (rp->absorb >= 1.0 && rp->min_bounces == D) ? 1 : 0;
     a.absorb = rp->absorb;
     a.seed = rp->seed;
     for (int i = 0; i < 3; ++i) {
@@ -395,6 +419,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                        ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
+                if (unbiased && k == 0)   // the camera ray's hit is the first chain vertex of the backward pass
+                    hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur], rb[cur],
+                                       rid[cur], hit, counts + (size_t)k * max_regions, cs.cv_a, cs.cv_b, cs.cv_hit);
 
                 TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                 if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
@@ -405,13 +432,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         gs = ctx->n_cu * shade_bpc;
                     const uint32_t* ck = counts + (size_t)k * max_regions;
                     uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
-#define DRT_LAUNCH_SHADE(SPEC)                                                                            \
+#define DRT_LAUNCH_SHADE(SPEC, SEG, DBASE)                                                                \
     hipLaunchKernelGGL((k_shade<R, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene,      \
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, \
-                       ck, cn, bvh.tri_shade, 0, (const uint32_t*)nullptr)
-                    if (ctx->has_specular) DRT_LAUNCH_SHADE(true);
-                    else DRT_LAUNCH_SHADE(false);
-#undef DRT_LAUNCH_SHADE
+                       ck, cn, bvh.tri_shade, SEG, DBASE)
+                    if (ctx->has_specular) DRT_LAUNCH_SHADE(true, 0, (const uint32_t*)nullptr);
+                    else DRT_LAUNCH_SHADE(false, 0, (const uint32_t*)nullptr);
                 }
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_SHADE]++;
@@ -429,6 +455,65 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->launches[DRT_K_BACKWARD]++;
                 hipLaunchKernelGGL(k_film<R>, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, a,
                                    (const R4*)ctx->gpath.p, gfilm);
+            } else if (unbiased && D > 0) {
+                // forward radiance from the tape, then the adjoint rounds (see drt_kernels.h)
+                if (film)
+                    hipLaunchKernelGGL(k_radiance<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params,
+                                       tape, nv, lacc);
+                hipLaunchKernelGGL(k_adj_init<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, tape, nv, d_adjoint, cs);
+                for (int r = 0; r < D; ++r) {
+                    const int s = r + 1;
+                    HIPCHK(ctx, hipMemsetAsync(counts + (size_t)s * max_regions, 0,
+                                               (size_t)(D + 1 - s) * max_regions * sizeof(uint32_t), ctx->stream));
+                    if (ctx->has_specular)
+                        hipLaunchKernelGGL((k_adj_vertex<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene,
+                                           d_params, cs, bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv,
+                                           counts + (size_t)s * max_regions);
+                    else
+                        hipLaunchKernelGGL((k_adj_vertex<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene,
+                                           d_params, cs, bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv,
+                                           counts + (size_t)s * max_regions);
+                    for (int k = s; k < D; ++k) {
+                        const int cur = k & 1, nxt = cur ^ 1;
+                        const uint32_t* ck = counts + (size_t)k * max_regions;
+                        uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
+                        if (ctx->has_mesh)
+                            hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                               bvh, ra[cur], rb[cur], hit, ck);
+                        else
+                            hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                               ra[cur], rb[cur], hit, ck);
+                        st->launches[DRT_K_INTERSECT]++;
+                        if (k == s)
+                            hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur],
+                                               rb[cur], rid[cur], hit, ck, cs.nx_a, cs.nx_b, cs.nx_hit);
+                        TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
+                        const int gs = g;
+                        if (ctx->has_specular) DRT_LAUNCH_SHADE(true, s, (const uint32_t*)cs.dbase);
+                        else DRT_LAUNCH_SHADE(false, s, (const uint32_t*)cs.dbase);
+                        st->launches[DRT_K_SHADE]++;
+                    }
+                    if (s < D)
+                        hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream,
+                                           counts + (size_t)s * max_regions, (uint32_t)((size_t)(D - s) * max_regions),
+                                           (unsigned long long*)ctx->segtotal.p);
+                    hipLaunchKernelGGL(k_radiance_from<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, s, d_scene,
+                                       d_params, tape, nv, cs);
+                    if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
+                    if (ctx->n_params <= 4)
+                        hipLaunchKernelGGL((k_adj_accumulate<R, 4>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
+                                           d_scene, d_params, tape, nv, cs, gpart, grad);
+                    else if (ctx->n_params <= 8)
+                        hipLaunchKernelGGL((k_adj_accumulate<R, 8>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
+                                           d_scene, d_params, tape, nv, cs, gpart, grad);
+                    else
+                        hipLaunchKernelGGL((k_adj_accumulate<R, 0>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
+                                           d_scene, d_params, tape, nv, cs, gpart, grad);
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                    st->launches[DRT_K_BACKWARD]++;
+                    hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast, grad);
+                    st->launches[DRT_K_GRADREDUCE]++;
+                }
             } else if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
 #define DRT_LAUNCH_BWD(NP)                                                                              \
@@ -467,6 +552,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             }
         }
     }
+#undef DRT_LAUNCH_SHADE
     st->batches = batch;
     st->paths = total_paths;
     if (film && d_out_rgb) {
@@ -527,7 +613,9 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
+    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+                      &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
+                      &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
     for (DevBuf* b : bufs)
         release(*b);

@@ -28,6 +28,7 @@ namespace drt { namespace hip {
 
 struct Options {
     bool backward = false;          // also back-propagate (render.cpp:80, commented out there)
+    bool unbiased = false;          // backward with the unbiased integration operator (integrate.hpp:39-52)
     uint32_t seed = 1;
     int max_depth = 0;              // 0 = library default (64)
     std::vector<int> devices = {0}; // pixel-row bands are dealt round-robin to these devices
@@ -240,7 +241,8 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
             rp.shard = d;
             rp.n_shards = n_dev;
             rp.band_rows = opt.band_rows;
-            rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u);
+            rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
+                       (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
             rp.batch_paths = opt.batch_paths;
             ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, frames[d].data(),
                                      opt.backward ? grads[d].data() : nullptr, &stats[d]),

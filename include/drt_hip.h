@@ -115,6 +115,11 @@ typedef struct drt_camera_desc {
 #define DRT_RENDER_SYNC       0x4u  /* with DEVICE_OUT: synchronise the stream before return */
 #define DRT_RENDER_TIMING     0x8u  /* bracket every kernel launch with HIP events -> stats */
 #define DRT_RENDER_F64        0x10u /* compute in double on the device (verification mode) */
+#define DRT_RENDER_UNBIASED   0x20u /* with BACKWARD: the reference's unbiased integration operator
+                                       (integrate.hpp:39-52, README.md:104-136): backward draws a
+                                       FRESH direction at every vertex and traces a new suffix path
+                                       (O(depth^2) segments).  Draw positions follow the reference
+                                       with zero-length rays never hitting (oracle/ref_harness.cpp). */
 
 typedef struct drt_render_params {
     int32_t spp;            /* samples per pixel            (args.hpp:36-43, -n) */

@@ -3,7 +3,7 @@
 // -p/--absorb-prob 0.5, -o/--output (required), -h/--help, --version (0.1).  TCLAP (branch 1.4 in
 // the reference's .gitmodules) is not available here, so this is a small self-contained parser.
 // Additive flags for the device path: --backend cpu|hip, --backward, --seed, --max-depth,
-// --devices a,b,..., --f64.
+// --devices a,b,..., --f64, --unbiased (backward with integrate(..., unbiased = true)).
 #pragma once
 
 #include <cstddef>
@@ -25,6 +25,7 @@ struct Args {
     // additive
     std::string backend = "hip";
     bool backward = false;
+    bool unbiased = false;
     unsigned seed = 1;
     int max_depth = 0;
     std::vector<int> devices = {0};
@@ -43,7 +44,7 @@ inline bool parse_args(int argc, const char* const* argv, Args* args)
     auto usage = [&](FILE* f) {
         std::fprintf(f,
             "USAGE: %s -o <string> [-x <integer>] [-y <integer>] [-n <integer>] [-b <integer>] [-p <number>]\n"
-            "       [--backend cpu|hip] [--backward] [--seed <integer>] [--max-depth <integer>]\n"
+            "       [--backend cpu|hip] [--backward] [--unbiased] [--seed <integer>] [--max-depth <integer>]\n"
             "       [--devices a,b,...] [--f64] [--version] [-h]\n\n"
             "A simple differentiable path tracer\n"
             "  -x, --width        Output image width (640)\n"
@@ -68,6 +69,7 @@ inline bool parse_args(int argc, const char* const* argv, Args* args)
         else if (a == "-o" || a == "--output") { if (!value(v)) return false; args->output = v; have_output = true; }
         else if (a == "--backend") { if (!value(v)) return false; args->backend = v; if (args->backend != "cpu" && args->backend != "hip") return false; }
         else if (a == "--backward") { args->backward = true; }
+        else if (a == "--unbiased") { args->backward = true; args->unbiased = true; }
         else if (a == "--f64") { args->f64 = true; }
         else if (a == "--seed") { if (!value(v)) return false; args->seed = (unsigned)std::strtoul(v, &end, 10); if (*end) return false; }
         else if (a == "--max-depth") { if (!value(v)) return false; args->max_depth = (int)std::strtol(v, &end, 10); if (*end) return false; }

@@ -65,6 +65,7 @@ int main(int argc, const char* argv[])
     if (args.backend == "hip") {
         hip::Options opt;
         opt.backward = args.backward;
+        opt.unbiased = args.unbiased;
         opt.seed = args.seed;
         opt.max_depth = args.max_depth;
         opt.devices = args.devices;
