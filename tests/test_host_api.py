@@ -133,3 +133,19 @@ def test_app_on_the_device_matches_its_cpu_backend(app, tmp_path):
     assert np.abs(ia - ib).max() <= 2e-3 * ib.max()
     c = sh([app, "-o", str(tmp_path / "hip64.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "4", "-p", "1", "--backward", "--f64"])
     np.testing.assert_allclose(parse_grads(c.stdout), gb, rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_app_multi_device_path_and_unbiased_flag(app, tmp_path):
+    """The C++ glue's multi-device split (one host thread + one context per entry of --devices),
+    exercised with two contexts on the same GPU: rows dealt to both, gradients summed on the host.
+    Also the --unbiased flag end to end."""
+    one = sh([app, "-o", str(tmp_path / "a.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "3", "-p", "0.3", "--backward"])
+    two = sh([app, "-o", str(tmp_path / "b.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "3", "-p", "0.3", "--backward",
+              "--devices", "0,0"])
+    np.testing.assert_allclose(parse_grads(two.stdout), parse_grads(one.stdout), rtol=1e-7)
+    np.testing.assert_array_equal(read_exr_half_rgba(str(tmp_path / "a.exr")), read_exr_half_rgba(str(tmp_path / "b.exr")))
+    unb = sh([app, "-o", str(tmp_path / "c.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "3", "-p", "0.3", "--unbiased"])
+    gu, gb = parse_grads(unb.stdout), parse_grads(one.stdout)
+    assert not np.allclose(gu, gb, rtol=1e-6) and np.allclose(gu, gb, rtol=0.2)
+    np.testing.assert_array_equal(read_exr_half_rgba(str(tmp_path / "a.exr")), read_exr_half_rgba(str(tmp_path / "c.exr")))
