@@ -86,6 +86,9 @@ struct DevBvh {
 #define DRT_BVH_LDS_NODES_F32 128    // 8 KB of LDS per block (f32); f64 stages half as many
 #define DRT_BVH_STACK 32             // per-lane traversal stack in LDS (the builder bounds the depth at 30)
 #define DRT_BVH_REFILL 16            // idle lanes needed before the wave pulls new rays from its stream
+#ifndef DRT_BVH_DESCEND_MIN
+#define DRT_BVH_DESCEND_MIN 20       // the interior-node loop runs while at least this many lanes descend
+#endif
 
 // ---- small vector math -----------------------------------------------------------------------
 template <typename R>

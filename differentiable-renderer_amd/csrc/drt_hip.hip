@@ -411,12 +411,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             for (int k = 0; k < D; ++k) {
                 const int cur = k & 1, nxt = cur ^ 1;
                 if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                if (ctx->has_mesh)
+                hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                   ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                if (ctx->has_mesh)   // continues from the analytic hit: (t, primitive) refined by the BVH walk
                     hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                        bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
-                else
-                    hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                       ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_INTERSECT]++;
                 if (unbiased && k == 0)   // the camera ray's hit is the first chain vertex of the backward pass
@@ -477,12 +476,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         const int cur = k & 1, nxt = cur ^ 1;
                         const uint32_t* ck = counts + (size_t)k * max_regions;
                         uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
+                        hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                           ra[cur], rb[cur], hit, ck);
                         if (ctx->has_mesh)
                             hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                                bvh, ra[cur], rb[cur], hit, ck);
-                        else
-                            hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                               ra[cur], rb[cur], hit, ck);
                         st->launches[DRT_K_INTERSECT]++;
                         if (k == s)
                             hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur],

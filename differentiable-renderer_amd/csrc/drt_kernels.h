@@ -191,6 +191,8 @@ __device__ inline void closest_hit2(const DevScene<R>* __restrict__ sc, int n_sh
 #pragma unroll 3
     for (int s = 0; s < n_shapes; ++s) {
         const DevShape<R> sh = sc->shapes[s];
+        if (sh.type == DRT_SHAPE_MESH)
+            continue;                 // its triangles are k_intersect_mesh's business
         R t0, t1;
         const bool hit0 = shape_intersect(sh, o0, d0, t0);
         const bool hit1 = shape_intersect(sh, o1, d1, t1);
@@ -241,8 +243,9 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
 }
 
 // ---- K2 (scenes with triangle meshes) -----------------------------------------------------------
-// One closest-hit query = the analytic shapes, then an ORDERED walk of the BVH (near child first,
-// far child on a 32-entry per-lane stack in LDS).  The top of the tree is staged in LDS once per
+// One closest-hit query = the analytic shapes (done by k_intersect at full lane efficiency just
+// before; this kernel starts from that hit record), then an ORDERED walk of the BVH (near child
+// first, far child on a 32-entry per-lane stack in LDS).  The top of the tree is staged in LDS once per
 // block; deeper nodes and the triangles come from L2.  Incoherent rays make traversal lengths
 // wildly different from lane to lane, so the kernel is organised around keeping lanes busy:
 //   * every wave owns a private STREAM of rays (its chunks of the address-ordered sweep); when
@@ -256,7 +259,7 @@ template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                  const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
-                 HitRec<R>* __restrict__ hit, const uint32_t* __restrict__ counts_k)
+                 HitRec<R>* hit, const uint32_t* __restrict__ counts_k)
 {
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
@@ -287,7 +290,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     for (;;) {
         // ---- refill idle lanes from the stream
         if ((uint32_t)__popcll(__ballot(!active)) >= DRT_BVH_REFILL) {
-            bool want = !active, fresh = false;
+            bool want = !active;
             for (;;) {
                 if (cur_off >= cur_cnt) {
                     if (next_chunk >= n_chunks)
@@ -311,40 +314,36 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     slot = cur_base + cur_off + rank;
                     const R4 ra = ray_a[slot];
                     const R2 rb = ray_b[slot];
+                    const HitRec<R> h0 = hit[slot];             // closest analytic shape (k_intersect)
                     o = mk<R>(ra.x, ra.y, ra.z);
                     d = mk<R>(ra.w, rb.x, rb.y);
                     inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
-                    tmin = (R)INFINITY;
-                    prim = -1;
-                    best_flat = 0xFFFFFFFFu;
+                    tmin = h0.t;
+                    prim = h0.prim;
+                    best_flat = h0.prim >= 0 ? (uint32_t)sc->flat[h0.prim] : 0xFFFFFFFFu;
                     cur = 0;            // root
                     sp = 0;
                     want = false;
-                    fresh = true;
                     active = true;
                 }
                 cur_off += n_want < avail ? n_want : avail;
-            }
-            if (__any(fresh)) {
-                for (int s = 0; s < n_shapes; ++s) {
-                    const DevShape<R> sh = sc->shapes[s];
-                    if (sh.type == DRT_SHAPE_MESH)
-                        continue;
-                    const uint32_t flat = (uint32_t)sc->flat[s];
-                    R t;
-                    if (fresh && shape_intersect(sh, o, d, t) && (t < tmin || (t == tmin && flat < best_flat))) {
-                        tmin = t;
-                        prim = s;
-                        best_flat = flat;
-                    }
-                }
             }
         }
         if (!__any(active))
             break;
 
-        // ---- interior nodes: tight loop, leaves postponed
-        while (active && !(cur & DRT_BVH_LEAF)) {
+        // ---- interior nodes: tight loop, leaves postponed; left as soon as too few lanes still
+        // descend (the others already hold a leaf and would only wait)
+        for (;;) {
+            const bool descending = active && !(cur & DRT_BVH_LEAF);
+            const uint64_t dmask = __ballot(descending);
+            if (dmask == 0)
+                break;
+            if ((uint32_t)__popcll(dmask) < DRT_BVH_DESCEND_MIN &&
+                __ballot(active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) != 0)
+                break;
+            if (!descending)
+                continue;
             R4 n0, n1, n2, n3;
             if (cur < n_lds) { n0 = s_node[cur][0]; n1 = s_node[cur][1]; n2 = s_node[cur][2]; n3 = s_node[cur][3]; }
             else { const R4* p = bvh.node + (size_t)cur * 4; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; }
@@ -364,8 +363,8 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
             }
         }
-        // ---- leaves (cur is a leaf link or NONE)
-        if (active && cur != DRT_BVH_NONE) {
+        // ---- leaves
+        if (active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) {
             const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, count = cur & 7u;
             for (uint32_t j = first; j < first + count; ++j) {
                 const R4 ta = bvh.tri_a[j], tb = bvh.tri_b[j], tc = bvh.tri_c[j];
