@@ -364,6 +364,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         a.right[i] = cam->right[i]; a.up[i] = cam->up[i];
     }
     a.region_size = region_size;
+    a.bvh_refill = getenv("DRT_HIP_BVH_REFILL") ? (uint32_t)atoi(getenv("DRT_HIP_BVH_REFILL")) : DRT_BVH_REFILL;
+    a.bvh_descend_min = getenv("DRT_HIP_BVH_DESCEND_MIN") ? (uint32_t)atoi(getenv("DRT_HIP_BVH_DESCEND_MIN")) : DRT_BVH_DESCEND_MIN;
     a.region_shift = region_shift;
     {   // smallest r with !(double(r) / RAND_MAX < absorb): the roulette test as an integer compare
         double guess = floor(rp->absorb * DRT_RAND_MAX_D);

@@ -45,6 +45,7 @@ struct BatchArgs {
     uint32_t Sb, s0;         // samples in the batch, first sample
     uint32_t n_regions, region_size, region_shift;   // queue regions, one wave each; region_size = 1 << region_shift >= 64
     uint32_t rr_threshold;   // r31 < rr_threshold  <=>  double(r31) / RAND_MAX < absorb (exact)
+    uint32_t bvh_refill, bvh_descend_min;   // traversal knobs (defaults DRT_BVH_REFILL / DRT_BVH_DESCEND_MIN)
     // image / sharding
     int32_t W, H, spp;
     int32_t shard, n_shards, band;
@@ -289,7 +290,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
 
     for (;;) {
         // ---- refill idle lanes from the stream
-        if ((uint32_t)__popcll(__ballot(!active)) >= DRT_BVH_REFILL) {
+        if ((uint32_t)__popcll(__ballot(!active)) >= a.bvh_refill) {
             bool want = !active;
             for (;;) {
                 if (cur_off >= cur_cnt) {
@@ -339,7 +340,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             const uint64_t dmask = __ballot(descending);
             if (dmask == 0)
                 break;
-            if ((uint32_t)__popcll(dmask) < DRT_BVH_DESCEND_MIN &&
+            if ((uint32_t)__popcll(dmask) < a.bvh_descend_min &&
                 __ballot(active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) != 0)
                 break;
             if (!descending)
