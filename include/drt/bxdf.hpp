@@ -42,7 +42,7 @@ template <typename T>
 inline std::array<Vector<T, 3>, 3> make_frame(const Vector<T, 3>& normal)
 {
     const Vector<T, 3> ex{1., 0., 0.}, ey{0., 1., 0.};
-    const bool use_x = std::abs(dot(ex, normal)) < std::abs(dot(ey, normal));
+    const bool use_x = std::abs(real(dot(ex, normal))) < std::abs(real(dot(ey, normal)));
     const Vector<T, 3>& e = use_x ? ex : ey;
     const Vector<T, 3> tangent = normalize(e - normal * dot(e, normal));
     const Vector<T, 3> bitangent = normalize(cross(normal, tangent));
@@ -94,7 +94,7 @@ public:
                                   const Vector<T, 3>& dir_out) const override
     {
         const Vector<T, 3> half = normalize(dir_in + dir_out);
-        const double c = dot(normal, half);
+        const double c = real(dot(normal, half));
         const double s = std::sqrt(1 - c * c);
         const double lobe = (m_shininess + 2) / (2 * pi) * std::pow(c, m_shininess) * s;
         return lobe * m_albedo;
@@ -105,7 +105,7 @@ public:
         const double theta = std::acos(std::sqrt(std::pow(random::uniform(), 2 / (m_shininess + 2))));
         const double phi = 2 * pi * random::uniform();
         auto half = internal::angle_to_dir(theta, phi, internal::make_frame(normal));
-        if (dot(half, dir_in) < 0)
+        if (real(dot(half, dir_in)) < 0)
             half = reflect(half, normal);
         const auto dir = reflect(dir_in, half);
         const double pdf = (m_shininess + 2) / (2 * pi) * std::pow(std::cos(theta), m_shininess + 1) * std::sin(theta);
@@ -127,7 +127,7 @@ public:
     Vector<T, 3, true> operator()(const Vector<T, 3>& normal, const Vector<T, 3>&,
                                   const Vector<T, 3>& dir_out) const override
     {
-        return Vector<T, 3, true>(T(1 / dot(normal, dir_out)));   // cancels the cosine
+        return Vector<T, 3, true>(T(1 / real(dot(normal, dir_out))));   // cancels the cosine
     }
 
     std::tuple<Vector<T, 3>, double> sample(const Vector<T, 3>& normal, const Vector<T, 3>& dir_in) const override

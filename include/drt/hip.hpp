@@ -86,7 +86,7 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
         param_of[h.id()] = idx;
         f.handles.push_back(h);
         for (int c = 0; c < 3; ++c)
-            f.params.push_back(double(h[c]));
+            f.params.push_back(double(real(h[c])));
         f.requires_grad.push_back(h.requires_grad() ? 1 : 0);
         return idx;
     };
@@ -106,7 +106,7 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
             std::vector<double> vs;
             for (const auto& v : mesh->vertices())
                 for (int c = 0; c < 3; ++c)
-                    vs.push_back(double(v[c]));
+                    vs.push_back(double(real(v[c])));
             std::vector<uint32_t> is;
             for (const auto& t : mesh->triangles())
                 for (int c = 0; c < 3; ++c)
@@ -171,10 +171,10 @@ inline drt_camera_desc describe(const Camera<T>& cam)
     c.height = (int32_t)cam.height();
     c.vfov = cam.vfov();
     for (int i = 0; i < 3; ++i) {
-        c.eye[i] = double(cam.eye()[i]);
-        c.forward[i] = double(cam.forward()[i]);
-        c.right[i] = double(cam.right()[i]);
-        c.up[i] = double(cam.up()[i]);
+        c.eye[i] = double(real(cam.eye()[i]));
+        c.forward[i] = double(real(cam.forward()[i]));
+        c.right[i] = double(real(cam.right()[i]));
+        c.up[i] = double(real(cam.up()[i]));
     }
     return c;
 }
@@ -220,7 +220,7 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
         adj.resize(npix * 3);
         for (std::size_t i = 0; i < npix; ++i)
             for (int c = 0; c < 3; ++c)
-                adj[i * 3 + c] = float(adjoint[i][c]);
+                adj[i * 3 + c] = float(real(adjoint[i][c]));
     }
     const std::size_t P = flat.requires_grad.size();
     std::vector<std::vector<float>> frames(n_dev, std::vector<float>(npix * 3, 0.f));

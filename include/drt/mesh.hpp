@@ -37,19 +37,19 @@ public:
         for (std::size_t k = 0; k < m_corners.size(); ++k) {
             const Corner& c = m_corners[k];
             const Vector<T, 3> pvec = cross(dir, c.e2);
-            const double det = dot(c.e1, pvec);
+            const double det = real(dot(c.e1, pvec));
             if (det == 0)
                 continue;
             const double inv = 1 / det;
             const Vector<T, 3> tvec = orig - c.v0;
-            const double u = dot(tvec, pvec) * inv;
+            const double u = real(dot(tvec, pvec)) * inv;
             if (u < 0 || u > 1)
                 continue;
             const Vector<T, 3> qvec = cross(tvec, c.e1);
-            const double v = dot(dir, qvec) * inv;
+            const double v = real(dot(dir, qvec)) * inv;
             if (v < 0 || u + v > 1)
                 continue;
-            const double tk = dot(c.e2, qvec) * inv;
+            const double tk = real(dot(c.e2, qvec)) * inv;
             if (!(tk > 0) || tk >= best)
                 continue;
             best = tk;

@@ -104,7 +104,7 @@ private:
                 const Vector<T, 3> next_orig = hit.point + 1e-3 * dir_out;
                 Vector<T, 3, true> f = internal::eval_bxdf(hit.bxdf, hit.normal, toward_viewer, dir_out);
                 Vector<T, 3, true> incoming = trace(scene, next_orig, dir_out, depth + 1);
-                const double cosine = dot(hit.normal, dir_out);
+                const double cosine = real(dot(hit.normal, dir_out));
                 return f * incoming * cosine;
             },
             [=]() { return internal::sample_bxdf(hit.bxdf, hit.normal, toward_viewer); },

@@ -50,8 +50,8 @@ public:
 
     bool intersect(Vector<T, 3> orig, Vector<T, 3> dir, double& t) const override
     {
-        const double height = dot(orig, m_n) - m_d;
-        t = height / dot(dir, -m_n);
+        const double height = real(dot(orig, m_n)) - m_d;
+        t = height / real(dot(dir, -m_n));
         return t > 0;
     }
 
@@ -61,7 +61,7 @@ public:
     {
         ShapeRecord r;
         r.kind = ShapeKind::Plane;
-        r.p[0] = double(m_n[0]); r.p[1] = double(m_n[1]); r.p[2] = double(m_n[2]); r.p[3] = m_d;
+        r.p[0] = real(m_n[0]); r.p[1] = real(m_n[1]); r.p[2] = real(m_n[2]); r.p[3] = m_d;
         return r;
     }
 
@@ -81,8 +81,8 @@ public:
     {
         orig -= m_c;
         const double a = 1;                       // unit direction assumed
-        const double b = 2 * dot(orig, dir);
-        const double c = dot(orig, orig) - m_r * m_r;
+        const double b = 2 * real(dot(orig, dir));
+        const double c = real(dot(orig, orig)) - m_r * m_r;
         const double disc = b * b - 4 * a * c;
         if (disc < 0)
             return false;
@@ -105,7 +105,7 @@ public:
     {
         ShapeRecord r;
         r.kind = ShapeKind::Sphere;
-        r.p[0] = double(m_c[0]); r.p[1] = double(m_c[1]); r.p[2] = double(m_c[2]); r.p[3] = m_r;
+        r.p[0] = real(m_c[0]); r.p[1] = real(m_c[1]); r.p[2] = real(m_c[2]); r.p[3] = m_r;
         return r;
     }
 

@@ -32,6 +32,12 @@ namespace drt {
 template <typename T, std::size_t N, bool Autograd = false>
 class Vector;
 
+// value part of a scalar: identity for built-in types, the real part of a drt::Dual (dual.hpp).
+// Geometry (hit distances, cosines, pdfs) is never differentiated (README.md:147-151), so the
+// plugins take real() of such quantities; this is what lets T = Dual<double> compile end to end.
+inline double real(double x) { return x; }
+inline float real(float x) { return x; }
+
 // ---- plain value vector ------------------------------------------------------------------------
 template <typename T, std::size_t N>
 class Vector<T, N> {

@@ -109,9 +109,9 @@ inline void write_exr(const char* fname, const Vector<T, 3>* data, std::size_t w
         for (size_t x = 0; x < width; ++x) {
             const Vector<T, 3>& rgb = data[y * width + x];
             line[0 * width + x] = one;                                   // A
-            line[1 * width + x] = float_to_half((float)double(rgb[2]));  // B
-            line[2 * width + x] = float_to_half((float)double(rgb[1]));  // G
-            line[3 * width + x] = float_to_half((float)double(rgb[0]));  // R
+            line[1 * width + x] = float_to_half((float)real(rgb[2]));  // B
+            line[2 * width + x] = float_to_half((float)real(rgb[1]));  // G
+            line[3 * width + x] = float_to_half((float)real(rgb[0]));  // R
         }
         const int32_t yy = (int32_t)y, size = (int32_t)line_bytes;
         std::fwrite(&yy, 4, 1, f);

@@ -55,6 +55,15 @@ def test_host_api_known_answers(tmp_path):
     assert out.strip() == "ok", out
 
 
+def test_dual_numbers_end_to_end_match_reverse_mode(tmp_path):
+    """SURVEY 8f rank 4 / README.md:140: T = Dual<double> through shapes, BxDFs and the path tracer
+    (does not compile in the reference); forward-mode derivatives == reverse-mode gradients."""
+    exe = str(tmp_path / "dual")
+    sh(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "cpp", "dual_end_to_end.cpp"), "-o", exe])
+    assert sh([exe]).stdout.startswith("ok")
+
+
 def parse_grads(text):
     g = {}
     for name, a, b, c in re.findall(r"grad (\w+)\s*= \(([^,]+), ([^,]+), ([^)]+)\)", text):
