@@ -553,6 +553,21 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         }
     }
 #undef DRT_LAUNCH_SHADE
+    // debugging aid: DRT_HIP_DUMP_PATH=<path index in the last batch> prints that path's tape
+    if (const char* e = getenv("DRT_HIP_DUMP_PATH")) {
+        const size_t i = (size_t)atoll(e);
+        if (i < a.n_paths && D > 0) {
+            (void)hipStreamSynchronize(ctx->stream);
+            uint32_t k_nv = 0;
+            (void)hipMemcpy(&k_nv, nv + i, sizeof k_nv, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[drt_hip] path %zu: %u vertices\n", i, k_nv);
+            for (uint32_t k = 0; k < k_nv && k < (uint32_t)D; ++k) {
+                TapeRec<R> tr;
+                (void)hipMemcpy(&tr, tape + (size_t)k * a.n_paths + i, sizeof tr, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[drt_hip]   k=%u m=%.9g colour=%u emission=%u\n", k, (double)tr.m, tr.ids & 0xFFFFu, tr.ids >> 16);
+            }
+        }
+    }
     st->batches = batch;
     st->paths = total_paths;
     if (film && d_out_rgb) {

@@ -487,6 +487,11 @@ template <typename R, bool SPEC>
 __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, uint32_t r1, uint32_t r2,
                                    V3<R>& wo, R& q, R& bs)
 {
+    // The two end points of the theta draw are singular: u1 = 1 gives cos(theta) = 0 and pdf 0 in
+    // the diffuse sampler (0/0 here; the reference survives only because cos(asin(1.0)) is 6e-17 in
+    // fp64), u1 = 0 or 1 give pdf 0 in the specular one (inf/NaN in the reference too).  At ~1e9
+    // draws per render a 2^-31 event happens, so the draw is kept one step inside the interval.
+    r1 = r1 < 1u ? 1u : (r1 > 2147483646u ? 2147483646u : r1);
     const R u2 = u01(R(0), r2);
     R sphi, cphi;
     sincospi_r(R(2) * u2, &sphi, &cphi);                       // phi = 2 pi u2
@@ -506,8 +511,18 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
             hv = reflect(hv, nrm);
         wo = reflect(wi, hv);
         q = m.norm * pow_r(ct, m.exponent + R(1)) * st;
-        const V3<R> hw = normalize(wi + wo);                   // bxdf.hpp:91-104
-        const R ch = dot(nrm, hw);
+        // bxdf.hpp:91-104 re-derives the half vector as normalize(dir_in + dir_out).  That sum is
+        // 2 (h . wi) h: when h is nearly perpendicular to wi it cancels, and in f32 it can cancel
+        // to exactly 0 (-> NaN; seen once per ~3e7 paths at depth 12).  f32 therefore uses the
+        // identity halfway = sign(h . wi) h; f64 keeps the literal form (exact parity, and enough
+        // headroom).
+        R ch;
+        if (sizeof(R) == 4) {
+            ch = dot(hv, wi) < R(0) ? -dot(nrm, hv) : dot(nrm, hv);
+        } else {
+            const V3<R> hw = normalize(wi + wo);
+            ch = dot(nrm, hw);
+        }
         R s2 = (R(1) - ch) * (R(1) + ch);
         s2 = s2 > R(0) ? s2 : R(0);
         bs = m.norm * pow_r(ch, m.exponent) * sqrt_r(s2);
@@ -616,6 +631,13 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                     sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
                     const R c = dot(nrm, wo);                  // pathtracer.hpp:103
                     const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
+#ifdef DRT_DEBUG_NAN
+                    if (!(mk_ == mk_) || mk_ > R(1e30) || mk_ < R(-1e30))
+                        printf("[k_shade] pid %u k %d type %d: bs %g c %g q %g pk %g | nrm %g %g %g | d %g %g %g | wo %g %g %g | t %g prim %d\n",
+                               pid, k, m.type, (double)bs, (double)c, (double)q, (double)pk, (double)nrm.x, (double)nrm.y,
+                               (double)nrm.z, (double)d.x, (double)d.y, (double)d.z, (double)wo.x, (double)wo.y, (double)wo.z,
+                               (double)h.t, h.prim);
+#endif
                     // roulette / cap of depth k+1, decided here so dead rays are never queued
                     alive = !next_cap;
                     if (alive && next_rr)

@@ -301,3 +301,18 @@ def test_unbiased_and_biased_gradients_agree_statistically(pkg, hip):
     _, gu, su = hip.render(cam, rp, backward=True, unbiased=True)
     assert su["segments"] > 2 * sb["segments"]
     np.testing.assert_allclose(gu, gb, rtol=0.03)
+
+
+def test_f32_half_vector_singularity_regression(pkg, hip):
+    """Row 848 of a 1024x1024x32 depth-12 render with the specular sphere: sample 21 of pixel
+    (976, 848) reflects almost straight through (h . wi ~ 0); the literal normalize(wi + wo) of
+    bxdf.hpp:97 cancelled to normalize(0) = NaN in f32 and poisoned the pixel and every gradient."""
+    scene = pkg.cornell_box(front_specular=True)
+    cam = pkg.cornell_camera(1024, 1024)
+    rp = pkg.RenderParams(spp=32, min_bounces=12, absorb=1.0, seed=3, shard=848, n_shards=1024, band_rows=1)
+    hip.upload_scene(scene)
+    img, grads, _ = hip.render(cam, rp, backward=True)
+    assert np.isfinite(img).all() and np.isfinite(grads).all()
+    img64, grads64, _ = hip.render(cam, rp, backward=True, f64=True)
+    np.testing.assert_allclose(img[848, 976], img64[848, 976], rtol=2e-3, atol=1e-6)
+    assert grad_rel_err(grads, grads64) < 1e-4
