@@ -177,31 +177,45 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* 
 // chunks of all regions in address order (neighbouring waves stream neighbouring kilobytes, which
 // keeps DRAM pages open) and skips the chunks beyond a region's live count.  Two chunks are in
 // flight per wave (their loads are issued before either is consumed).
-// Closest hit of TWO independent rays in one pass over the shapes: each shape record is fetched
-// once (scalar load) for both, and the two dependency chains interleave.
-template <typename R>
-__device__ inline void closest_hit2(const DevScene<R>* __restrict__ sc, int n_shapes,
-                                    typename Q4<R>::T ra0, typename Q2<R>::T rb0,
-                                    typename Q4<R>::T ra1, typename Q2<R>::T rb1,
-                                    HitRec<R>& h0, HitRec<R>& h1)
+// Closest hit of NR independent rays in one pass over the shapes: each shape record is fetched
+// once (scalar load) for all of them, and their dependency chains interleave.
+#ifndef DRT_K2_RAYS
+#define DRT_K2_RAYS 2
+#endif
+template <typename R, int NR>
+__device__ inline void closest_hit_n(const DevScene<R>* __restrict__ sc, int n_shapes,
+                                     const typename Q4<R>::T (&ra)[NR], const typename Q2<R>::T (&rb)[NR],
+                                     HitRec<R> (&h)[NR])
 {
-    const V3<R> o0 = mk<R>(ra0.x, ra0.y, ra0.z), d0 = mk<R>(ra0.w, rb0.x, rb0.y);
-    const V3<R> o1 = mk<R>(ra1.x, ra1.y, ra1.z), d1 = mk<R>(ra1.w, rb1.x, rb1.y);
-    R tmin0 = (R)INFINITY, tmin1 = (R)INFINITY;
-    int prim0 = -1, prim1 = -1;
+    V3<R> o[NR], d[NR];
+    R tmin[NR];
+    int prim[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        o[r] = mk<R>(ra[r].x, ra[r].y, ra[r].z);
+        d[r] = mk<R>(ra[r].w, rb[r].x, rb[r].y);
+        tmin[r] = (R)INFINITY;
+        prim[r] = -1;
+    }
 #pragma unroll 3
     for (int s = 0; s < n_shapes; ++s) {
         const DevShape<R> sh = sc->shapes[s];
         if (sh.type == DRT_SHAPE_MESH)
             continue;                 // its triangles are k_intersect_mesh's business
-        R t0, t1;
-        const bool hit0 = shape_intersect(sh, o0, d0, t0);
-        const bool hit1 = shape_intersect(sh, o1, d1, t1);
-        if (hit0 && !(t0 >= tmin0)) { tmin0 = t0; prim0 = s; }          // pathtracer.hpp:80
-        if (hit1 && !(t1 >= tmin1)) { tmin1 = t1; prim1 = s; }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            R t;
+            if (shape_intersect(sh, o[r], d[r], t) && !(t >= tmin[r])) {   // pathtracer.hpp:80
+                tmin[r] = t;
+                prim[r] = s;
+            }
+        }
     }
-    h0.t = tmin0; h0.prim = prim0;
-    h1.t = tmin1; h1.prim = prim1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        h[r].t = tmin[r];
+        h[r].prim = prim[r];
+    }
 }
 
 // slot of this lane in chunk c, or 0xFFFFFFFF when the lane has no live ray there
@@ -229,17 +243,24 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
     const uint32_t n_chunks = a.n_regions << (a.region_shift - 6);
     const int n_shapes = sc->n_shapes;
-    for (uint32_t c = grid_wave(); c < n_chunks; c += 2 * n_waves) {
-        const uint32_t s0 = chunk_slot(a, counts_k, c, n_chunks, lane);
-        const uint32_t s1 = chunk_slot(a, counts_k, c + n_waves, n_chunks, lane);
-        R4 ra0 = {}, ra1 = {};
-        R2 rb0 = {}, rb1 = {};
-        if (s0 != 0xFFFFFFFFu) { ra0 = ray_a[s0]; rb0 = ray_b[s0]; }
-        if (s1 != 0xFFFFFFFFu) { ra1 = ray_a[s1]; rb1 = ray_b[s1]; }
-        HitRec<R> h0, h1;
-        closest_hit2<R>(sc, n_shapes, ra0, rb0, ra1, rb1, h0, h1);
-        if (s0 != 0xFFFFFFFFu) hit[s0] = h0;
-        if (s1 != 0xFFFFFFFFu) hit[s1] = h1;
+    constexpr int NR = DRT_K2_RAYS;
+    for (uint32_t c = grid_wave(); c < n_chunks; c += NR * n_waves) {
+        uint32_t slot[NR];
+        R4 ra[NR];
+        R2 rb[NR];
+        HitRec<R> h[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            slot[r] = chunk_slot(a, counts_k, c + (uint32_t)r * n_waves, n_chunks, lane);
+            ra[r] = R4{};
+            rb[r] = R2{};
+            if (slot[r] != 0xFFFFFFFFu) { ra[r] = ray_a[slot[r]]; rb[r] = ray_b[slot[r]]; }
+        }
+        closest_hit_n<R, NR>(sc, n_shapes, ra, rb, h);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (slot[r] != 0xFFFFFFFFu)
+                hit[slot[r]] = h[r];
     }
 }
 
