@@ -54,6 +54,8 @@ struct drt_hip_ctx {
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
     unsigned long long h_segments = 0;
+    unsigned long long* h_probe = nullptr;   // pinned: queue-length polls of deep-cap renders
+    DevBuf probe;
 };
 
 namespace {
@@ -256,6 +258,24 @@ int grid_for(const drt_hip_ctx* ctx, uint64_t work)
     return (int)blocks;
 }
 
+// Number of rays queued at one depth (sum over regions).  A host round trip: only used every few
+// bounces when the depth cap is deep (roulette-terminated renders), to stop launching on empty queues.
+int queue_length(drt_hip_ctx* ctx, const uint32_t* counts_row, uint32_t n_regions, unsigned long long* out)
+{
+    int rc;
+    if ((rc = ensure(ctx, ctx->probe, sizeof(unsigned long long))) != DRT_OK) return rc;
+    if (!ctx->h_probe)
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_probe, sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_sum_counts, dim3(16), dim3(DRT_BLOCK), 0, ctx->stream, counts_row, n_regions,
+                       (unsigned long long*)ctx->probe.p);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_probe, ctx->probe.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *ctx->h_probe;
+    return DRT_OK;
+}
+#define DRT_POLL_EVERY 4
+
 template <typename R>
 int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                 const float* d_adjoint, float* d_out_rgb, bool backward, bool timing,
@@ -412,6 +432,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 
             for (int k = 0; k < D; ++k) {
                 const int cur = k & 1, nxt = cur ^ 1;
+                if (D > 2 * DRT_POLL_EVERY && k >= DRT_POLL_EVERY && k % DRT_POLL_EVERY == 0) {
+                    unsigned long long live = 0;
+                    if ((rc = queue_length(ctx, counts + (size_t)k * max_regions, max_regions, &live)) != DRT_OK) return rc;
+                    if (live == 0)
+                        break;        // every path has ended: deeper queues stay empty
+                }
                 if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
                 hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                    ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
@@ -474,8 +500,21 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         hipLaunchKernelGGL((k_adj_vertex<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene,
                                            d_params, cs, bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv,
                                            counts + (size_t)s * max_regions);
-                    for (int k = s; k < D; ++k) {
+                    bool chains_done = false;
+                    if (D > 2 * DRT_POLL_EVERY && r >= 2) {
+                        // no suffix ray queued in this round => every chain ends with this round
+                        unsigned long long live = 0;
+                        if ((rc = queue_length(ctx, counts + (size_t)s * max_regions, max_regions, &live)) != DRT_OK) return rc;
+                        chains_done = live == 0;
+                    }
+                    for (int k = s; k < D && !chains_done; ++k) {
                         const int cur = k & 1, nxt = cur ^ 1;
+                        if (D > 2 * DRT_POLL_EVERY && k - s >= DRT_POLL_EVERY && (k - s) % DRT_POLL_EVERY == 0) {
+                            unsigned long long live = 0;
+                            if ((rc = queue_length(ctx, counts + (size_t)k * max_regions, max_regions, &live)) != DRT_OK) return rc;
+                            if (live == 0)
+                                break;
+                        }
                         const uint32_t* ck = counts + (size_t)k * max_regions;
                         uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
                         hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
@@ -513,6 +552,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     st->launches[DRT_K_BACKWARD]++;
                     hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast, grad);
                     st->launches[DRT_K_GRADREDUCE]++;
+                    if (chains_done)
+                        break;
                 }
             } else if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
@@ -639,6 +680,9 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     if (ctx->d_scene_d) (void)hipFree(ctx->d_scene_d);
     if (ctx->d_params_f) (void)hipFree(ctx->d_params_f);
     if (ctx->d_params_d) (void)hipFree(ctx->d_params_d);
+    if (ctx->h_probe)
+        (void)hipHostFree(ctx->h_probe);
+    release(ctx->probe);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
     if (ctx->stream)
