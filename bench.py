@@ -32,6 +32,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 BYTES_PER_UNIT = {"intersect": 32.0, "shade_fwd": 80.0, "shade_bwd": 80.0, "backward": 8.0}
 
 
+def _oracle_shard(args):
+    """Worker of the all-cores CPU figure: one row-band shard of the sample, in its own process."""
+    scene_name, w, h, spp, depth, backward, shard, n_shards = args
+    pkg = entry.load_package()
+    oracle = entry.load_oracle()
+    rp = pkg.RenderParams(spp=spp, min_bounces=depth, absorb=1.0, seed=1, shard=shard, n_shards=n_shards, band_rows=4)
+    r = oracle.render(pkg.scene_by_name(scene_name), pkg.cornell_camera(w, h), rp, backward=backward)
+    return r["stats"]["segments"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,6 +57,8 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle on every host core (independent row-band processes)")
     a = ap.parse_args()
 
     import torch
@@ -182,6 +194,18 @@ def main():
             img_d, g_d, _ = r.render(cam, crp, backward=True)
             gerr = float(np.abs(g_d - ref["grads"]).max() / np.abs(ref["grads"]).max())
             cpu_baseline["grad_max_rel_err_vs_cpu"] = gerr
+        if a.cpu_all_cores:
+            # the reference is single-threaded by construction (global rand()); this is N independent
+            # processes, each rendering its interleaved row bands of the same sample
+            import multiprocessing as mp
+            n = min(os.cpu_count() or 1, 64)
+            jobs = [(a.scene, a.width, a.height, a.cpu_spp, a.depth, backward, i, n) for i in range(n)]
+            with mp.get_context("spawn").Pool(n) as pool:
+                t2 = time.perf_counter()
+                segs = sum(pool.map(_oracle_shard, jobs))
+                dt2 = time.perf_counter() - t2
+            cpu_baseline["all_cores"] = {"value": round(segs / dt2 * 1e-6, 2), "unit": "Mray/s", "cores": n,
+                                         "note": "N independent row-band processes of the same sample (includes process start-up)"}
 
     if rank == 0:
         line = {

@@ -316,3 +316,39 @@ def test_f32_half_vector_singularity_regression(pkg, hip):
     img64, grads64, _ = hip.render(cam, rp, backward=True, f64=True)
     np.testing.assert_allclose(img[848, 976], img64[848, 976], rtol=2e-3, atol=1e-6)
     assert grad_rel_err(grads, grads64) < 1e-4
+
+
+def test_malformed_scenes_are_rejected_not_crashed(pkg):
+    """Random corruptions of a valid scene description: the library must answer with
+    DRT_ERR_INVALID / DRT_ERR_UNSUPPORTED (or accept a still-valid scene), never crash, and stay
+    usable afterwards."""
+    r = pkg.HipRenderer(0)
+    rs = np.random.RandomState(7)
+    cam = pkg.cornell_camera(8, 8)
+    for trial in range(60):
+        sc = pkg.random_scene(trial % 5) if trial % 3 else pkg.cornell_with_mesh(6, 8, per_face_params=3)
+        kind = rs.randint(7)
+        if kind == 0:
+            i = rs.randint(len(sc.shapes)); t, m, e, p = sc.shapes[i]; sc.shapes[i] = (t, int(rs.randint(-5, 200)), e, p)
+        elif kind == 1:
+            i = rs.randint(len(sc.shapes)); t, m, e, p = sc.shapes[i]; sc.shapes[i] = (t, m, int(rs.randint(-5, 200)), p)
+        elif kind == 2:
+            i = rs.randint(len(sc.shapes)); t, m, e, p = sc.shapes[i]; sc.shapes[i] = (int(rs.randint(3, 9)), m, e, p)
+        elif kind == 3:
+            i = rs.randint(len(sc.materials)); t, p, ex = sc.materials[i]; sc.materials[i] = (t, int(rs.randint(-3, 500)), ex)
+        elif kind == 4:
+            i = rs.randint(len(sc.materials)); t, p, ex = sc.materials[i]; sc.materials[i] = (int(rs.randint(2, 6)), p, ex)
+        elif kind == 5 and sc.emitters:
+            sc.emitters[rs.randint(len(sc.emitters))] = int(rs.randint(-3, 500))
+        elif kind == 6 and sc.meshes:
+            v, idx, fm = sc.meshes[0]; idx = idx.copy(); idx[rs.randint(len(idx)), rs.randint(3)] = 10 ** 6; sc.meshes[0] = (v, idx, fm)
+        try:
+            r.upload_scene(sc)
+            img, _, _ = r.render(cam, pkg.RenderParams(spp=1, min_bounces=2, absorb=0.5), backward=True)
+            assert img.shape == (8, 8, 3)
+        except pkg.DrtHipError as ex:
+            assert "DRT_ERR_INVALID" in str(ex) or "DRT_ERR_UNSUPPORTED" in str(ex)
+    r.upload_scene(pkg.cornell_box())
+    img, g, _ = r.render(cam, pkg.RenderParams(spp=2, min_bounces=2, absorb=0.5), backward=True)
+    assert np.isfinite(img).all() and np.isfinite(g).all()
+    r.close()
