@@ -198,7 +198,7 @@ def main():
             # the reference is single-threaded by construction (global rand()); this is N independent
             # processes, each rendering its interleaved row bands of the same sample
             import multiprocessing as mp
-            n = min(os.cpu_count() or 1, 64)
+            n = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
             jobs = [(a.scene, a.width, a.height, a.cpu_spp, a.depth, backward, i, n) for i in range(n)]
             with mp.get_context("spawn").Pool(n) as pool:
                 # start the workers and load the checker in each of them before the clock starts
@@ -207,7 +207,7 @@ def main():
                 segs = sum(pool.map(_oracle_shard, jobs, chunksize=1))
                 dt2 = time.perf_counter() - t2
             cpu_baseline["all_cores"] = {"value": round(segs / dt2 * 1e-6, 2), "unit": "Mray/s", "cores": n,
-                                         "note": "N independent row-band processes of the same sample, workers warmed up"}
+                                         "note": "N independent row-band processes of the same sample, workers warmed up; N = usable CPUs reported by the OS (a container CPU quota may be lower)"}
 
     if rank == 0:
         line = {
