@@ -1,8 +1,9 @@
 // drt_bvh.h -- host-side BVH construction for the triangle-mesh extension (all meshes of a scene
-// share ONE tree).  Binned-SAH top-down build with a bounded depth, emitted as interior nodes
-// that carry the boxes of BOTH children (one fetch on the device yields two box tests and the
-// near/far order); leaves are not nodes, a child link is either an interior node index or a
-// triangle range.  The first `top` nodes are the top of the tree in breadth-first order (K2 stages
+// share ONE tree).  Binned-SAH top-down binary build with a bounded depth, COLLAPSED to a 4-wide
+// tree: every emitted node carries the boxes of up to four children (one fetch on the device
+// yields four box tests and their near-to-far order, and the tree is half as deep -- the walk is
+// bound by dependent node fetches); leaves are not nodes, a child link is either an interior
+// node index or a triangle range.  The first `top` nodes are the top of the tree in breadth-first order (K2 stages
 // them in LDS), the rest follow depth-first (subtrees contiguous).
 #pragma once
 
@@ -25,14 +26,16 @@ struct Tri {
 
 // child link: bit 31 clear = interior node index; bit 31 set = leaf, (first << 3) | count in the
 // low bits (count 0 = empty child, its box is inverted so it is never entered)
+constexpr int kWidth = 4;
 struct Node {
-    double lo[2][3], hi[2][3];   // [0] = left child, [1] = right child
-    uint32_t child[2];
+    double lo[kWidth][3], hi[kWidth][3];
+    uint32_t child[kWidth];
 };
 
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr int kMaxLeaf = 4;
-constexpr int kMaxDepth = 30;     // the device keeps a 32-entry traversal stack per lane
+constexpr int kMaxDepth = 20;     // binary depth <= 20 => 4-wide depth <= 10 => at most 3 * 10 pushes:
+                                  // the device's 32-entry per-lane stack cannot overflow
 
 struct Built {
     std::vector<Node> nodes;      // final order, root = 0
@@ -195,33 +198,63 @@ inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
     const std::vector<detail::Tmp>& t = b.tmp;
     out.order = b.idx;
     auto leaf_link = [&](int u) { return kLeaf | (t[u].first << 3) | t[u].count; };
+    auto is_leaf = [&](int u) { return t[u].left < 0; };
+    // children of wide node u: start from its two binary children, keep splitting the interior
+    // child with the largest box until there are kWidth of them (or only leaves are left)
+    auto wide_children = [&](int u, int out[kWidth]) {
+        int n = 0;
+        out[n++] = t[u].left;
+        out[n++] = t[u].right;
+        while (n < kWidth) {
+            int best = -1;
+            double best_area = -1;
+            for (int i = 0; i < n; ++i)
+                if (!is_leaf(out[i]) && detail::area(t[out[i]].lo, t[out[i]].hi) > best_area) {
+                    best_area = detail::area(t[out[i]].lo, t[out[i]].hi);
+                    best = i;
+                }
+            if (best < 0)
+                break;
+            const int c = out[best];
+            out[best] = t[c].left;
+            out[n++] = t[c].right;
+        }
+        return n;
+    };
     auto set_child = [&](Node& nd, int side, int u, uint32_t link) {
         for (int a = 0; a < 3; ++a) { nd.lo[side][a] = t[u].lo[a] - pad; nd.hi[side][a] = t[u].hi[a] + pad; }
         nd.child[side] = link;
     };
-    if (t[0].left < 0) {          // the whole scene is one leaf: a root with one real child
+    auto set_empty = [&](Node& nd, int side) {
+        for (int a = 0; a < 3; ++a) { nd.lo[side][a] = INFINITY; nd.hi[side][a] = -INFINITY; }
+        nd.child[side] = kLeaf;     // leaf with count 0; the inverted box is never entered
+    };
+    if (is_leaf(0)) {             // the whole scene is one leaf: a root with one real child
         Node nd;
         set_child(nd, 0, 0, leaf_link(0));
-        for (int a = 0; a < 3; ++a) { nd.lo[1][a] = INFINITY; nd.hi[1][a] = -INFINITY; }
-        nd.child[1] = kLeaf;
+        for (int sde = 1; sde < kWidth; ++sde)
+            set_empty(nd, sde);
         out.nodes.push_back(nd);
         out.top = 1;
         return out;
     }
-    // interior nodes only; physical order: breadth-first prefix of at most max_top, then depth-first
+    // wide nodes = the binary nodes that survive the collapse; physical order: breadth-first prefix
+    // of at most max_top, then depth-first
     const uint32_t n = (uint32_t)t.size();
     std::vector<uint32_t> pos(n, 0xFFFFFFFFu), at;
     std::vector<int> frontier;
     {
         std::queue<int> q;
         q.push(0);
-        while (!q.empty() && at.size() + q.size() <= max_top) {
+        while (!q.empty() && at.size() < max_top) {
             const int u = q.front();
             q.pop();
             pos[u] = (uint32_t)at.size();
             at.push_back((uint32_t)u);
-            if (t[t[u].left].left >= 0) q.push(t[u].left);
-            if (t[t[u].right].left >= 0) q.push(t[u].right);
+            int ch[kWidth];
+            const int nc = wide_children(u, ch);
+            for (int i = 0; i < nc; ++i)
+                if (!is_leaf(ch[i])) q.push(ch[i]);
         }
         while (!q.empty()) { frontier.push_back(q.front()); q.pop(); }
     }
@@ -232,17 +265,111 @@ inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
         stack.pop_back();
         pos[u] = (uint32_t)at.size();
         at.push_back((uint32_t)u);
-        if (t[t[u].right].left >= 0) stack.push_back(t[u].right);
-        if (t[t[u].left].left >= 0) stack.push_back(t[u].left);
+        int ch[kWidth];
+        const int nc = wide_children(u, ch);
+        for (int i = nc - 1; i >= 0; --i)
+            if (!is_leaf(ch[i])) stack.push_back(ch[i]);
     }
     out.nodes.resize(at.size());
     for (size_t i = 0; i < at.size(); ++i) {
-        const int u = (int)at[i];
-        const int l = t[u].left, r = t[u].right;
-        set_child(out.nodes[i], 0, l, t[l].left >= 0 ? pos[l] : leaf_link(l));
-        set_child(out.nodes[i], 1, r, t[r].left >= 0 ? pos[r] : leaf_link(r));
+        int ch[kWidth];
+        const int nc = wide_children((int)at[i], ch);
+        for (int c = 0; c < kWidth; ++c) {
+            if (c < nc)
+                set_child(out.nodes[i], c, ch[c], is_leaf(ch[c]) ? leaf_link(ch[c]) : pos[ch[c]]);
+            else
+                set_empty(out.nodes[i], c);
+        }
     }
     return out;
+}
+
+// ---- device encoding: one 4-wide node in 64 bytes ---------------------------------------------
+// The walk is bound by the address rate of per-lane divergent 16-byte loads, so bytes per visit
+// are what count: child boxes are stored as 8-bit offsets on a per-node power-of-two grid,
+//   word 0..2  origin.xyz (f32, <= every child's lo)       word 3   grid exponent bytes ex | ey<<8 | ez<<16
+//   word 4..7  links of children 0..3
+//   word 8..10 q_lo.x, q_lo.y, q_lo.z (one byte per child) word 11..13  q_hi.x, q_hi.y, q_hi.z
+//   word 14,15 unused
+// child c, axis a:  lo = origin[a] + q_lo[a][c] * 2^(e[a]-127),  hi likewise.  The encoder checks
+// that the decoded box -- evaluated exactly AND as the device's f32 fma evaluates it -- contains
+// the child's true box, so the f32 and the f64 kernels both stay conservative.
+struct QNode {
+    uint32_t w[16];
+};
+
+inline float grid_scale(uint32_t ebyte)
+{
+    const uint32_t bits = ebyte << 23;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+inline QNode quantise(const Node& n)
+{
+    QNode q;
+    memset(&q, 0, sizeof q);
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, ebytes = 0;
+    for (int a = 0; a < 3; ++a) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int c = 0; c < kWidth; ++c)
+            if (n.child[c] != kLeaf) {
+                lo = std::min(lo, n.lo[c][a]);
+                hi = std::max(hi, n.hi[c][a]);
+            }
+        float origin = (float)lo;
+        if ((double)origin > lo)
+            origin = nextafterf(origin, -INFINITY);
+        int e;
+        (void)frexp(std::max(hi - (double)origin, 1e-30) / 255.0, &e);     // 2^e > extent / 255
+        uint32_t eb = (uint32_t)std::min(std::max(e + 127, 1), 254);
+        for (;;) {                                         // grow the grid until every child fits in 8 bits
+            const float sc = grid_scale(eb);
+            bool ok = true;
+            qlo[a] = qhi[a] = 0;
+            for (int c = 0; c < kWidth && ok; ++c) {
+                if (n.child[c] == kLeaf)
+                    continue;
+                auto decoded_le = [&](long v, double x) { return (double)fmaf((float)v, sc, origin) <= x && (double)origin + (double)v * (double)sc <= x; };
+                auto decoded_ge = [&](long v, double x) { return (double)fmaf((float)v, sc, origin) >= x && (double)origin + (double)v * (double)sc >= x; };
+                long l = (long)floor((n.lo[c][a] - (double)origin) / (double)sc);
+                l = std::min(std::max(l, 0L), 255L);
+                while (l > 0 && !decoded_le(l, n.lo[c][a])) --l;
+                long h = (long)ceil((n.hi[c][a] - (double)origin) / (double)sc);
+                h = std::max(h, 0L);
+                while (h <= 255 && !decoded_ge(h, n.hi[c][a])) ++h;
+                if (h > 255 || !decoded_le(l, n.lo[c][a])) { ok = false; break; }
+                qlo[a] |= (uint32_t)l << (8 * c);
+                qhi[a] |= (uint32_t)h << (8 * c);
+            }
+            if (ok || eb >= 254)
+                break;
+            ++eb;
+        }
+        memcpy(&q.w[a], &origin, 4);
+        ebytes |= eb << (8 * a);
+    }
+    q.w[3] = ebytes;
+    for (int c = 0; c < kWidth; ++c)
+        q.w[4 + c] = n.child[c];
+    for (int a = 0; a < 3; ++a) {
+        q.w[8 + a] = qlo[a];
+        q.w[11 + a] = qhi[a];
+    }
+    return q;
+}
+
+// decoded child box as the device sees it (tests and debugging)
+inline void decode(const QNode& q, int c, double lo[3], double hi[3])
+{
+    for (int a = 0; a < 3; ++a) {
+        float origin;
+        memcpy(&origin, &q.w[a], 4);
+        const double sc = grid_scale((q.w[3] >> (8 * a)) & 0xFFu);
+        lo[a] = (double)origin + (double)((q.w[8 + a] >> (8 * c)) & 0xFFu) * sc;
+        hi[a] = (double)origin + (double)((q.w[11 + a] >> (8 * c)) & 0xFFu) * sc;
+    }
 }
 
 } // namespace drt_bvh

@@ -65,16 +65,18 @@ __device__ inline uint32_t pid_unpack(float v) { return __float_as_uint(v); }
 __device__ inline uint32_t pid_unpack(double v) { return (uint32_t)v; }
 
 // ---- triangle meshes (extension): one BVH over all triangles of the scene ---------------------
-// Interior node i = four 16-byte lanes (64 B in f32), the boxes of BOTH children live in the parent:
-//   node[i][0] = (left.lo.xyz,  left link)     link: bit 31 clear = interior node index,
-//   node[i][1] = (left.hi.xyz,  right link)          bit 31 set   = leaf: first << 3 | count
-//   node[i][2] = (right.lo.xyz, -)
-//   node[i][3] = (right.hi.xyz, -)
+// 4-wide node i = four 16-byte words (64 B whatever the compute type; drt_bvh.h: QNode): child boxes
+// are 8-bit offsets on a per-node power-of-two grid, decoded with one fma per bound
+//   node[i][0] = (origin.xyz as f32 bits, grid exponent bytes ex | ey << 8 | ez << 16)
+//   node[i][1] = links of children 0..3     bit 31 clear = interior node index,
+//                                           bit 31 set   = leaf: first << 3 | count (0 = no child)
+//   node[i][2] = (q_lo.x, q_lo.y, q_lo.z, q_hi.x)   one byte per child in each word
+//   node[i][3] = (q_hi.y, q_hi.z, -, -)
 //   tri_a/b/c[j] (leaf order) = (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, global index, flat index, -)
 //   tri_shade[g] (global triangle order) = (normal.xyz, material | emitter << 16)
 template <typename R>
 struct DevBvh {
-    const typename Q4<R>::T* node;      // [n_nodes][4]
+    const uint4* node;                  // [n_nodes][4]
     const typename Q4<R>::T* tri_a;
     const typename Q4<R>::T* tri_b;
     const typename Q4<R>::T* tri_c;
@@ -83,8 +85,8 @@ struct DevBvh {
 };
 #define DRT_BVH_NONE 0xFFFFFFFFu
 #define DRT_BVH_LEAF 0x80000000u
-#define DRT_BVH_LDS_NODES_F32 128    // 8 KB of LDS per block (f32); f64 stages half as many
-#define DRT_BVH_STACK 32             // per-lane traversal stack in LDS (the builder bounds the depth at 30)
+#define DRT_BVH_LDS_NODES 128        // 8 KB of LDS per block: the breadth-first top of the tree
+#define DRT_BVH_STACK 32             // per-lane traversal stack in LDS (4-wide depth <= 10, <= 3 pushes a level)
 #define DRT_BVH_REFILL 16            // idle lanes needed before the wave pulls new rays from its stream
 #ifndef DRT_BVH_DESCEND_MIN
 #define DRT_BVH_DESCEND_MIN 20       // the interior-node loop runs while at least this many lanes descend
@@ -117,6 +119,8 @@ __device__ inline float div_r(float a, float b) { return a * __builtin_amdgcn_rc
 __device__ inline double div_r(double a, double b) { return a / b; }
 __device__ inline float min_r(float a, float b) { return fminf(a, b); }   // NaN-ignoring (v_min_f32)
 __device__ inline double min_r(double a, double b) { return fmin(a, b); }
+__device__ inline float fma_r(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ inline double fma_r(double a, double b, double c) { return fma(a, b, c); }
 __device__ inline float max_r(float a, float b) { return fmaxf(a, b); }
 __device__ inline double max_r(double a, double b) { return fmax(a, b); }
 __device__ inline float abs_r(float x) { return fabsf(x); }

@@ -143,27 +143,10 @@ template <typename R>
 int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_bvh::Tri>& tris, DevBvh<R>* out)
 {
     typedef typename Q4<R>::T R4;
-    std::vector<R4> nodes(b.nodes.size() * 4);
+    std::vector<uint4> nodes(b.nodes.size() * 4);
     for (size_t i = 0; i < b.nodes.size(); ++i) {
-        const drt_bvh::Node& n = b.nodes[i];
-        for (int side = 0; side < 2; ++side) {
-            R4& lo = nodes[i * 4 + side * 2];
-            R4& hi = nodes[i * 4 + side * 2 + 1];
-            R* l = &lo.x;
-            R* h = &hi.x;
-            for (int a = 0; a < 3; ++a) {
-                l[a] = (R)n.lo[side][a];
-                h[a] = (R)n.hi[side][a];
-                if (sizeof(R) == 4) {   // boxes must stay conservative after rounding: round outwards
-                    if ((double)l[a] > n.lo[side][a]) l[a] = (R)nextafterf((float)l[a], -INFINITY);
-                    if ((double)h[a] < n.hi[side][a]) h[a] = (R)nextafterf((float)h[a], INFINITY);
-                }
-            }
-            lo.w = R(0);
-            hi.w = R(0);
-        }
-        nodes[i * 4 + 0].w = link_bits(R(0), n.child[0]);
-        nodes[i * 4 + 1].w = link_bits(R(0), n.child[1]);
+        const drt_bvh::QNode q = drt_bvh::quantise(b.nodes[i]);
+        memcpy(&nodes[i * 4], q.w, sizeof q.w);
     }
     std::vector<R4> ta(b.order.size()), tb(b.order.size()), tc(b.order.size()), ts(tris.size());
     for (size_t j = 0; j < b.order.size(); ++j) {
@@ -178,7 +161,7 @@ int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_
         ts[t.global].w = link_bits(R(0), t.ids);
     }
     int rc;
-    if ((rc = upload_array(ctx, nodes, &out->node)) != DRT_OK) return rc;
+    if ((rc = upload_array<uint4>(ctx, nodes, &out->node)) != DRT_OK) return rc;
     if ((rc = upload_array(ctx, ta, &out->tri_a)) != DRT_OK) return rc;
     if ((rc = upload_array(ctx, tb, &out->tri_b)) != DRT_OK) return rc;
     if ((rc = upload_array(ctx, tc, &out->tri_c)) != DRT_OK) return rc;
@@ -797,7 +780,7 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
                 return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: more than 2^28 triangles");
             const double diag = sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
                                      (hi[2] - lo[2]) * (hi[2] - lo[2]));
-            const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES_F32, 1e-5 * (diag > 0 ? diag : 1.0));
+            const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES, 1e-5 * (diag > 0 ? diag : 1.0));
             if ((rc = upload_bvh<float>(ctx, built, tris, &ctx->bvh_f)) != DRT_OK) return rc;
             if ((rc = upload_bvh<double>(ctx, built, tris, &ctx->bvh_d)) != DRT_OK) return rc;
             ctx->has_mesh = true;

@@ -285,8 +285,8 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
 {
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
-    constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES_F32 * sizeof(float) / sizeof(R);
-    __shared__ R4 s_node[LDS_NODES][4];
+    constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES;
+    __shared__ uint4 s_node[LDS_NODES][4];
     __shared__ uint32_t s_stack[DRT_BVH_STACK][DRT_BLOCK];
     const uint32_t n_lds = bvh.n_top < LDS_NODES ? bvh.n_top : LDS_NODES;
     for (uint32_t i = threadIdx.x; i < n_lds * 4; i += blockDim.x)
@@ -366,24 +366,43 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 break;
             if (!descending)
                 continue;
-            R4 n0, n1, n2, n3;
-            if (cur < n_lds) { n0 = s_node[cur][0]; n1 = s_node[cur][1]; n2 = s_node[cur][2]; n3 = s_node[cur][3]; }
-            else { const R4* p = bvh.node + (size_t)cur * 4; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; }
-            R tl, tr;
-            const bool hl = box_hit(mk<R>(n0.x, n0.y, n0.z), mk<R>(n1.x, n1.y, n1.z), o, inv_d, tmin, tl);
-            const bool hr = box_hit(mk<R>(n2.x, n2.y, n2.z), mk<R>(n3.x, n3.y, n3.z), o, inv_d, tmin, tr);
-            const uint32_t l0 = pid_unpack(n0.w), l1 = pid_unpack(n1.w);
-            if (hl && hr) {
-                const bool left_first = tl <= tr;
-                s_stack[sp++][tid] = left_first ? l1 : l0;
-                cur = left_first ? l0 : l1;
-            } else if (hl) {
-                cur = l0;
-            } else if (hr) {
-                cur = l1;
+            uint4 w0, w1, w2, w3;
+            if (cur < n_lds) {
+                w0 = s_node[cur][0]; w1 = s_node[cur][1]; w2 = s_node[cur][2]; w3 = s_node[cur][3];
             } else {
-                cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
+                const uint4* p = bvh.node + (size_t)cur * 4;
+                w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
             }
+            // decode the grid, then four box tests; a miss sorts to the end with t = +inf
+            const R ox = (R)__uint_as_float(w0.x), oy = (R)__uint_as_float(w0.y), oz = (R)__uint_as_float(w0.z);
+            const R sx = (R)__uint_as_float((w0.w & 0xFFu) << 23), sy = (R)__uint_as_float((w0.w & 0xFF00u) << 15),
+                    sz = (R)__uint_as_float((w0.w & 0xFF0000u) << 7);
+            R tc[4];
+            uint32_t lc[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const V3<R> lo = mk<R>(fma_r((R)((w2.x >> (8 * c)) & 0xFFu), sx, ox), fma_r((R)((w2.y >> (8 * c)) & 0xFFu), sy, oy),
+                                       fma_r((R)((w2.z >> (8 * c)) & 0xFFu), sz, oz));
+                const V3<R> hi = mk<R>(fma_r((R)((w2.w >> (8 * c)) & 0xFFu), sx, ox), fma_r((R)((w3.x >> (8 * c)) & 0xFFu), sy, oy),
+                                       fma_r((R)((w3.y >> (8 * c)) & 0xFFu), sz, oz));
+                R tn;
+                const bool hitc = box_hit(lo, hi, o, inv_d, tmin, tn) && lc[c] != DRT_BVH_LEAF;
+                tc[c] = hitc ? tn : (R)INFINITY;
+            }
+            // near-to-far order: 5-comparator sorting network on (t, link)
+#define DRT_CSWAP(i, j) { const bool sw = tc[j] < tc[i]; const R tt = sw ? tc[j] : tc[i]; const R tu = sw ? tc[i] : tc[j]; \
+                          const uint32_t lt = sw ? lc[j] : lc[i]; const uint32_t lu = sw ? lc[i] : lc[j];                \
+                          tc[i] = tt; tc[j] = tu; lc[i] = lt; lc[j] = lu; }
+            DRT_CSWAP(0, 1) DRT_CSWAP(2, 3) DRT_CSWAP(0, 2) DRT_CSWAP(1, 3) DRT_CSWAP(1, 2)
+#undef DRT_CSWAP
+            // farthest first onto the stack, nearest becomes current
+            if (tc[3] < (R)INFINITY) s_stack[sp++][tid] = lc[3];
+            if (tc[2] < (R)INFINITY) s_stack[sp++][tid] = lc[2];
+            if (tc[1] < (R)INFINITY) s_stack[sp++][tid] = lc[1];
+            if (tc[0] < (R)INFINITY)
+                cur = lc[0];
+            else
+                cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
         // ---- leaves
         if (active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) {
