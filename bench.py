@@ -29,7 +29,8 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per ray segment, f32 queues
-BYTES_PER_UNIT = {"intersect": 32.0, "shade_fwd": 80.0, "shade_bwd": 80.0, "backward": 8.0}
+# shade_fused: K2 folded into K3 (analytic scenes): ray 24 + id 8 read; ray 24 + id 8 + tape 8 written
+BYTES_PER_UNIT = {"intersect": 32.0, "shade": 80.0, "shade_fused": 72.0, "backward": 8.0}
 
 
 def _oracle_shard(args):
@@ -147,7 +148,7 @@ def main():
     units = {"intersect": segments, "shade": segments, "backward": segments,
              "raygen": paths, "film": paths, "gradreduce": 0}
     bpu = {"intersect": BYTES_PER_UNIT["intersect"],
-           "shade": BYTES_PER_UNIT["shade_bwd" if backward else "shade_fwd"],
+           "shade": BYTES_PER_UNIT["shade" if kernel_launches["intersect"] else "shade_fused"],
            "backward": BYTES_PER_UNIT["backward"], "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
     per_kernel = {}
     for k in pkg.KERNEL_NAMES:

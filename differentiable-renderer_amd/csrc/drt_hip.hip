@@ -393,6 +393,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     double* gpart = (double*)ctx->gpart.p;
     const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
 
+    // K2 folded into K3 whenever nothing else consumes the hit records
+    static const bool fuse_env = !(getenv("DRT_HIP_FUSE") && atoi(getenv("DRT_HIP_FUSE")) == 0);
+    const bool fused = fuse_env && !ctx->has_mesh && !unbiased;
     uint64_t batch = 0;
     for (uint32_t p0 = 0; p0 < n_local_pixels; p0 += Pb) {
         for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += Sb, ++batch) {
@@ -421,14 +424,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (live == 0)
                         break;        // every path has ended: deeper queues stay empty
                 }
-                if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                   ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
-                if (ctx->has_mesh)   // continues from the analytic hit: (t, primitive) refined by the BVH walk
-                    hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                       bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
-                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
-                st->launches[DRT_K_INTERSECT]++;
+                if (!fused) {
+                    if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
+                    hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                       ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                    if (ctx->has_mesh)   // continues from the analytic hit: (t, primitive) refined by the BVH walk
+                        hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                           bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                    st->launches[DRT_K_INTERSECT]++;
+                }
                 if (unbiased && k == 0)   // the camera ray's hit is the first chain vertex of the backward pass
                     hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur], rb[cur],
                                        rid[cur], hit, counts + (size_t)k * max_regions, cs.cv_a, cs.cv_b, cs.cv_hit);
@@ -442,12 +447,17 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         gs = ctx->n_cu * shade_bpc;
                     const uint32_t* ck = counts + (size_t)k * max_regions;
                     uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
-#define DRT_LAUNCH_SHADE(SPEC, SEG, DBASE)                                                                \
-    hipLaunchKernelGGL((k_shade<R, SPEC>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene,      \
+#define DRT_LAUNCH_SHADE(SPEC, FUSE, SEG, DBASE)                                                          \
+    hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene, \
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, \
                        ck, cn, bvh.tri_shade, SEG, DBASE)
-                    if (ctx->has_specular) DRT_LAUNCH_SHADE(true, 0, (const uint32_t*)nullptr);
-                    else DRT_LAUNCH_SHADE(false, 0, (const uint32_t*)nullptr);
+                    if (fused) {
+                        if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
+                        else DRT_LAUNCH_SHADE(false, true, 0, (const uint32_t*)nullptr);
+                    } else {
+                        if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, 0, (const uint32_t*)nullptr);
+                        else DRT_LAUNCH_SHADE(false, false, 0, (const uint32_t*)nullptr);
+                    }
                 }
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_SHADE]++;
@@ -511,8 +521,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                                rb[cur], rid[cur], hit, ck, cs.nx_a, cs.nx_b, cs.nx_hit);
                         TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                         const int gs = g;
-                        if (ctx->has_specular) DRT_LAUNCH_SHADE(true, s, (const uint32_t*)cs.dbase);
-                        else DRT_LAUNCH_SHADE(false, s, (const uint32_t*)cs.dbase);
+                        if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, s, (const uint32_t*)cs.dbase);
+                        else DRT_LAUNCH_SHADE(false, false, s, (const uint32_t*)cs.dbase);
                         st->launches[DRT_K_SHADE]++;
                     }
                     if (s < D)

@@ -197,19 +197,35 @@ __device__ inline void closest_hit_n(const DevScene<R>* __restrict__ sc, int n_s
         tmin[r] = (R)INFINITY;
         prim[r] = -1;
     }
-#pragma unroll 3
+    // The record of shape s + 1 is requested (scalar loads) before shape s is tested, so the scalar
+    // cache latency hides behind the arithmetic; the type is wave-uniform, so the plane and the
+    // sphere tests sit behind a real branch (the empty asm keeps the compiler from if-converting
+    // it back into "compute both, select").
+    DevShape<R> sh = sc->shapes[0];
     for (int s = 0; s < n_shapes; ++s) {
-        const DevShape<R> sh = sc->shapes[s];
-        if (sh.type == DRT_SHAPE_MESH)
-            continue;                 // its triangles are k_intersect_mesh's business
+        const DevShape<R> nx = sc->shapes[s + 1 < n_shapes ? s + 1 : s];
+        if (sh.type == DRT_SHAPE_PLANE) {
+            const V3<R> n = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            R t;
-            if (shape_intersect(sh, o[r], d[r], t) && !(t >= tmin[r])) {   // pathtracer.hpp:80
-                tmin[r] = t;
-                prim[r] = s;
+            for (int r = 0; r < NR; ++r) {
+                const R t = div_r(dot(o[r], n) - sh.p[3], -dot(d[r], n));      // shape.hpp:49-59
+                if (t > R(0) && !(t >= tmin[r])) {                              // pathtracer.hpp:80
+                    tmin[r] = t;
+                    prim[r] = s;
+                }
             }
-        }
+        } else if (sh.type == DRT_SHAPE_SPHERE) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                R t;
+                if (shape_intersect(sh, o[r], d[r], t) && !(t >= tmin[r])) {
+                    tmin[r] = t;
+                    prim[r] = s;
+                }
+            }
+        }                                 // a mesh record: its triangles are k_intersect_mesh's business
+        sh = nx;
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -485,7 +501,7 @@ struct ShadeIn {
 };
 
 template <typename R>
-__device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have,
+__device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, bool with_hit,
                                      const typename Q4<R>::T* __restrict__ ray_a,
                                      const typename Q2<R>::T* __restrict__ ray_b,
                                      const uint2* __restrict__ ray_id,
@@ -495,7 +511,8 @@ __device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have,
         in.ra = ray_a[slot];
         in.rb = ray_b[slot];
         in.rid = ray_id[slot];
-        in.h = hit[slot];
+        if (with_hit)
+            in.h = hit[slot];
     }
 }
 
@@ -587,7 +604,10 @@ __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_
 // shades them chunk by chunk.  The loads of the NEXT chunk (same region or the next live one) are
 // issued before the current chunk is shaded, so a wave always has one chunk of loads in flight.
 // SPEC = false instantiations carry no specular code (and fewer registers) for all-diffuse scenes.
-template <typename R, bool SPEC>
+// FUSED = true: the closest hit over the analytic shapes is computed HERE from the ray just loaded
+// (K2 folded into K3): no hit lane, no second read of the ray -- 72 instead of 120 bytes per
+// segment.  Used whenever nothing else needs the hit records (no mesh, no unbiased chain vertices).
+template <typename R, bool SPEC, bool FUSED>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
@@ -619,7 +639,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
     uint32_t off = 0, running = 0;
     ShadeIn<R> cur, nxt;
     bool have = lane < cnt;
-    load_shade_in(cur, (w << a.region_shift) + lane, have, ray_a, ray_b, ray_id, hit);
+    load_shade_in(cur, (w << a.region_shift) + lane, have, !FUSED, ray_a, ray_b, ray_id, hit);
 
     for (;;) {
         // where the next chunk is, and its loads
@@ -630,7 +650,7 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         }
         const bool more = nw < a.n_regions;
         const bool nhave = more && noff + lane < ncnt;
-        load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, ray_a, ray_b, ray_id, hit);
+        load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
 
         bool alive = false;
         R4 na;
@@ -638,7 +658,16 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         if (have) {
             const R4 ra = cur.ra;
             const typename Q2<R>::T rb = cur.rb;
-            const HitRec<R> h = cur.h;
+            HitRec<R> h;
+            if (FUSED) {
+                const R4 ra1[1] = {ra};
+                const typename Q2<R>::T rb1[1] = {rb};
+                HitRec<R> h1[1];
+                closest_hit_n<R, 1>(sc, lds.sc.n_shapes, ra1, rb1, h1);
+                h = h1[0];
+            } else {
+                h = cur.h;
+            }
             const uint32_t pid = cur.rid.x;
             if (h.prim < 0) {
                 nv[pid] = (uint32_t)k;                        // miss: pathtracer.hpp:135
