@@ -560,14 +560,30 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
         q = ct * (R)(1.0 / DRT_PI);
         bs = (R)(1.0 / DRT_PI);                                // bxdf.hpp:63-67: color / pi
     } else {
-        const double c2 = pow((double)r1 / DRT_RAND_MAX_D, 2.0 / ((double)m.exponent + 2.0));
-        const R ct = sqrt_r((R)c2), st = sqrt_r((R)(1.0 - c2));
+        // cos^2 = u^(2/(e+2)) and sin^2 = 1 - cos^2.  f64 forms them literally.  f32 goes through
+        // x = log(u) * 2/(e+2) <= 0: cos^2 = exp(x), sin^2 = -expm1(x), with log(u) taken as
+        // log1p(-(1-u)) from the EXACT integer RAND_MAX - r1 when u is near 1 -- both keep full
+        // relative accuracy where the literal form cancels, without a double-precision pow.
+        R ct, st, x_half = R(0);
+        if (sizeof(R) == 4) {
+            const float u = u01(0.f, r1), w = one_minus_u01(0.f, r1);
+            const float lu = w < 0.5f ? log1pf(-w) : logf(u);
+            const float x = lu * (2.0f / ((float)m.exponent + 2.0f));
+            ct = (R)sqrt_r(expf(x));
+            st = (R)sqrt_r(-expm1f(x));
+            x_half = (R)(0.5f * x);
+        } else {
+            const double c2 = pow((double)r1 / DRT_RAND_MAX_D, 2.0 / ((double)m.exponent + 2.0));
+            ct = sqrt_r((R)c2);
+            st = sqrt_r((R)(1.0 - c2));
+        }
         const V3<R> wi = -d;
         V3<R> hv = tg * (cphi * st) + bt * (sphi * st) + nrm * ct;
         if (dot(hv, wi) < R(0))
             hv = reflect(hv, nrm);
         wo = reflect(wi, hv);
-        q = m.norm * pow_r(ct, m.exponent + R(1)) * st;
+        // pdf: cos^(e+1) = exp((e+1) * log(cos)), and log(cos) = x / 2 is already known in f32
+        q = m.norm * (sizeof(R) == 4 ? (R)expf((float)((m.exponent + R(1)) * x_half)) : pow_r(ct, m.exponent + R(1))) * st;
         // bxdf.hpp:91-104 re-derives the half vector as normalize(dir_in + dir_out).  That sum is
         // 2 (h . wi) h: when h is nearly perpendicular to wi it cancels, and in f32 it can cancel
         // to exactly 0 (-> NaN; seen once per ~3e7 paths at depth 12).  f32 therefore uses the
