@@ -26,8 +26,10 @@ def short(name):
             tag = k
             if "<double" in name:
                 tag += "<f64>"
-            if k == "k_shade":
-                tag += "<specular>" if "true" in name.split(">")[0] else "<diffuse>"
+            if k == "k_shade":      # k_shade<R, SPEC, FUSED>
+                targs = [t.strip() for t in name.split("<", 1)[1].split(">")[0].split(",")]
+                tag += "<specular" if len(targs) > 1 and targs[1] == "true" else "<diffuse"
+                tag += ",fused>" if len(targs) > 2 and targs[2] == "true" else ">"
             return tag
     return n[:40]
 
@@ -77,7 +79,7 @@ for k, v in summary.items():
 json.dump({"kernels": summary, "traffic": traffic}, open(os.path.join(out, "summary.json"), "w"), indent=1)
 # bench.py's "traffic" field: PMC bytes per launch / traced average launch time, per kernel
 names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_intersect_mesh": "intersect", "k_shade<diffuse>": "shade",
-         "k_shade<specular>": "shade", "k_film": "film", "k_backward": "backward", "k_radiance": "backward",
+         "k_shade<specular>": "shade", "k_shade<diffuse,fused>": "shade", "k_shade<specular,fused>": "shade", "k_film": "film", "k_backward": "backward", "k_radiance": "backward",
          "k_gradreduce": "gradreduce"}
 tj = {}
 for k, t in traffic.items():
