@@ -393,9 +393,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     double* gpart = (double*)ctx->gpart.p;
     const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
 
-    // K2 folded into K3 whenever nothing else consumes the hit records
+    // K2 folded into K3 wherever nothing else consumes the hit records: never with a mesh (the BVH
+    // walk is its own kernel); in the unbiased backward every depth but the first of a chain, whose
+    // hit is saved as the next chain vertex
     static const bool fuse_env = !(getenv("DRT_HIP_FUSE") && atoi(getenv("DRT_HIP_FUSE")) == 0);
-    const bool fused = fuse_env && !ctx->has_mesh && !unbiased;
+    const bool can_fuse = fuse_env && !ctx->has_mesh;
     uint64_t batch = 0;
     for (uint32_t p0 = 0; p0 < n_local_pixels; p0 += Pb) {
         for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += Sb, ++batch) {
@@ -424,6 +426,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (live == 0)
                         break;        // every path has ended: deeper queues stay empty
                 }
+                // unbiased: the camera ray's hit is the first chain vertex of the backward pass; K3 saves
+                // it itself unless a mesh keeps the hit in a separate kernel's hands
+                const bool fused = can_fuse;
+                const bool save_here = unbiased && k == 0;
+                R4* sv_a = save_here && fused ? cs.cv_a : (R4*)nullptr;
+                typename Q2<R>::T* sv_b = save_here && fused ? cs.cv_b : (typename Q2<R>::T*)nullptr;
+                HitRec<R>* sv_hit = save_here && fused ? cs.cv_hit : (HitRec<R>*)nullptr;
                 if (!fused) {
                     if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
@@ -434,7 +443,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_INTERSECT]++;
                 }
-                if (unbiased && k == 0)   // the camera ray's hit is the first chain vertex of the backward pass
+                if (save_here && !fused)
                     hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur], rb[cur],
                                        rid[cur], hit, counts + (size_t)k * max_regions, cs.cv_a, cs.cv_b, cs.cv_hit);
 
@@ -450,7 +459,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #define DRT_LAUNCH_SHADE(SPEC, FUSE, SEG, DBASE)                                                          \
     hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene, \
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, \
-                       ck, cn, bvh.tri_shade, SEG, DBASE)
+                       ck, cn, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
                     if (fused) {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, true, 0, (const uint32_t*)nullptr);
@@ -510,19 +519,30 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         }
                         const uint32_t* ck = counts + (size_t)k * max_regions;
                         uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
-                        hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                           ra[cur], rb[cur], hit, ck);
-                        if (ctx->has_mesh)
-                            hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                               bvh, ra[cur], rb[cur], hit, ck);
-                        st->launches[DRT_K_INTERSECT]++;
-                        if (k == s)
+                        const bool fused = can_fuse;
+                        R4* sv_a = k == s && fused ? cs.nx_a : (R4*)nullptr;
+                        typename Q2<R>::T* sv_b = k == s && fused ? cs.nx_b : (typename Q2<R>::T*)nullptr;
+                        HitRec<R>* sv_hit = k == s && fused ? cs.nx_hit : (HitRec<R>*)nullptr;
+                        if (!fused) {
+                            hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                               ra[cur], rb[cur], hit, ck);
+                            if (ctx->has_mesh)
+                                hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                                   bvh, ra[cur], rb[cur], hit, ck);
+                            st->launches[DRT_K_INTERSECT]++;
+                        }
+                        if (k == s && !fused)
                             hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur],
                                                rb[cur], rid[cur], hit, ck, cs.nx_a, cs.nx_b, cs.nx_hit);
                         TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                         const int gs = g;
-                        if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, s, (const uint32_t*)cs.dbase);
-                        else DRT_LAUNCH_SHADE(false, false, s, (const uint32_t*)cs.dbase);
+                        if (fused) {
+                            if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, s, (const uint32_t*)cs.dbase);
+                            else DRT_LAUNCH_SHADE(false, true, s, (const uint32_t*)cs.dbase);
+                        } else {
+                            if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, s, (const uint32_t*)cs.dbase);
+                            else DRT_LAUNCH_SHADE(false, false, s, (const uint32_t*)cs.dbase);
+                        }
                         st->launches[DRT_K_SHADE]++;
                     }
                     if (s < D)

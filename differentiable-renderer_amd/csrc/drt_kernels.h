@@ -633,7 +633,9 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
         const uint32_t* __restrict__ counts_k,
         uint32_t* __restrict__ counts_next, const typename Q4<R>::T* __restrict__ tri_shade,
-        int seg_start, const uint32_t* __restrict__ draw_base)
+        int seg_start, const uint32_t* __restrict__ draw_base,
+        typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
+        HitRec<R>* __restrict__ save_hit)
 {
     typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
@@ -685,6 +687,11 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
                 h = cur.h;
             }
             const uint32_t pid = cur.rid.x;
+            if (save_a) {          // unbiased backward: this ray and its hit are the path's next chain vertex
+                save_a[pid] = ra;
+                save_b[pid] = rb;
+                save_hit[pid] = h;
+            }
             if (h.prim < 0) {
                 nv[pid] = (uint32_t)k;                        // miss: pathtracer.hpp:135
             } else {
@@ -1152,7 +1159,8 @@ k_backward_image(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __res
 // keeps a CHAIN VERTEX (the incoming ray and its hit, depth r) and the gradient g arriving there.
 // Round r:  k_adj_vertex  (E-gradient bookkeeping, fresh theta/phi, suffix ray queued at depth r+1)
 //           K2/K3 over depths r+1 .. D-1   (the ordinary bounce loop writes the suffix's tape)
-//           k_save_vertex after K2 at depth r+1 (the suffix's first vertex is the next chain vertex)
+//           the suffix's first ray + hit = the next chain vertex: saved by K3 at depth r+1 (path-indexed;
+//           k_save_vertex does the same as a separate pass when a mesh keeps K2 a kernel of its own)
 //           k_radiance_from(r+1)            (L' of the suffix from its tape)
 //           k_adj_accumulate                (gradients of round r, g and chain vertex of round r+1)
 template <typename R>
