@@ -174,7 +174,10 @@ def main():
                 "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json) over the profiled launch time" if traffic else None,
                 "avg_launch_ms": round(dk["ms_per_step"] / max(1, dk["launches_per_step"]), 4),
-                "traversal_kernel": per_kernel.get("intersect"), "kernels": per_kernel}
+                # the kernel that finds the closest hit: k_intersect(+mesh), or k_shade when K2 is folded into it
+                "traversal_kernel": dict(per_kernel.get("intersect") or per_kernel.get("shade") or {},
+                                         name="k_intersect" if "intersect" in per_kernel else "k_shade<fused>"),
+                "kernels": per_kernel}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -212,7 +215,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Mray/s (fwd+bwd), Cornell 512x512 @64spp depth 8" if backward else "Mray/s (fwd), Cornell 512x512 @64spp depth 8",
+            "metric": f"Mray/s ({'fwd+bwd' if backward else 'fwd'}), Cornell {a.width}x{a.height} @{a.spp}spp depth {a.depth}",
             "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
