@@ -213,6 +213,21 @@ def main():
             cpu_baseline["all_cores"] = {"value": round(segs / dt2 * 1e-6, 2), "unit": "Mray/s", "cores": n,
                                          "note": "N independent row-band processes of the same sample, workers warmed up; N = usable CPUs reported by the OS (a container CPU quota may be lower)"}
 
+    # the same call through the host-buffer entry point (synchronous, image and gradients copied to
+    # pageable host memory over PCIe): reported beside `value`, never as `value`
+    host_buffers = None
+    if rank == 0 and world == 1:
+        hrp = pkg.RenderParams(spp=a.spp, min_bounces=a.depth, absorb=1.0, seed=1, batch_paths=a.batch_paths)
+        n_host = max(1, min(a.steps, 5))
+        r.render(cam, hrp, backward=backward, unbiased=a.unbiased and backward)
+        t3 = time.perf_counter()
+        for _ in range(n_host):
+            r.render(cam, hrp, backward=backward, unbiased=a.unbiased and backward)
+        dt3 = (time.perf_counter() - t3) / n_host
+        host_buffers = {"value": round(total_segments / dt3 * 1e-6, 2), "unit": "Mray/s",
+                        "ms_per_step": round(dt3 * 1e3, 4),
+                        "note": "drt_hip_render with host out_rgb / out_param_grad (synchronous, PCIe D2H of the image included)"}
+
     if rank == 0:
         line = {
             "metric": f"Mray/s ({'fwd+bwd' if backward else 'fwd'}), Cornell {a.width}x{a.height} @{a.spp}spp depth {a.depth}",
@@ -225,7 +240,7 @@ def main():
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
                        "parallelism": f"pixel-row bands x{world}, 1 grad all-reduce" if world > 1 else "1 GPU",
                        "batches_per_step": stats["batches"]},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
         }
         print(json.dumps(line))
     if use_dist:

@@ -55,6 +55,11 @@ struct drt_hip_ctx {
     std::vector<TimedLaunch> timed;
     unsigned long long h_segments = 0;
     unsigned long long* h_probe = nullptr;   // pinned: queue-length polls of deep-cap renders
+    // pinned staging of everything a host-buffer render returns: [segments 8 B | grads | image | gradient
+    // image] arrive by DMA in one go, then plain memcpys into the caller's (pageable) buffers -- a
+    // pageable hipMemcpy of the 3 MB image alone cost 1 ms
+    uint8_t* h_stage = nullptr;
+    size_t h_stage_cap = 0;
     DevBuf probe;
 };
 
@@ -695,6 +700,8 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     if (ctx->d_params_d) (void)hipFree(ctx->d_params_d);
     if (ctx->h_probe)
         (void)hipHostFree(ctx->h_probe);
+    if (ctx->h_stage)
+        (void)hipHostFree(ctx->h_stage);
     release(ctx->probe);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
@@ -989,19 +996,43 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     }
 
     const bool sync = !dev_out || (rp->flags & DRT_RENDER_SYNC) || timing || stats;
+    const size_t img_bytes = npix_all * 3 * sizeof(float), grad_bytes = (size_t)ctx->n_params * 3 * sizeof(double);
+    const size_t off_grad = 16, off_img = off_grad + ((grad_bytes + 15) & ~(size_t)15), off_gimg = off_img + img_bytes;
+    {
+        const size_t need = off_gimg + img_bytes;
+        if (ctx->h_stage_cap < need) {
+            if (ctx->h_stage)
+                (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr;
+            ctx->h_stage_cap = 0;
+            HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage, need));
+            ctx->h_stage_cap = need;
+        }
+    }
     if (!dev_out) {
         if (out_rgb)
-            HIPCHK(ctx, hipMemcpyAsync(out_rgb, d_out, npix_all * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + off_img, d_out, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (backward && out_param_grad)
-            HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_params * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + off_grad, ctx->grad.p, grad_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (gimg_param >= 0 && out_gimg)
-            HIPCHK(ctx, hipMemcpyAsync(out_gimg, d_gimg, npix_all * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + off_gimg, d_gimg, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     ctx->h_segments = 0;
-    if (stats && n_count_words)
-        HIPCHK(ctx, hipMemcpyAsync(&ctx->h_segments, ctx->segtotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    const bool want_segments = stats && n_count_words;
+    if (want_segments)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     if (sync)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (want_segments)
+        memcpy(&ctx->h_segments, ctx->h_stage, sizeof(unsigned long long));
+    if (!dev_out) {
+        if (out_rgb)
+            memcpy(out_rgb, ctx->h_stage + off_img, img_bytes);
+        if (backward && out_param_grad)
+            memcpy(out_param_grad, ctx->h_stage + off_grad, grad_bytes);
+        if (gimg_param >= 0 && out_gimg)
+            memcpy(out_gimg, ctx->h_stage + off_gimg, img_bytes);
+    }
     if (!dev_out && backward && out_param_grad)
         for (int p = 0; p < ctx->n_params; ++p)
             if (!ctx->requires_grad[p])
