@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdrt_hip.so")
 
 # ---- enums / flags (include/drt_hip.h) ------------------------------------------------------
 SHAPE_PLANE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2
-BXDF_DIFFUSE, BXDF_SPECULAR = 0, 1
+BXDF_DIFFUSE, BXDF_SPECULAR, BXDF_MIRROR = 0, 1, 2
 RENDER_BACKWARD = 0x1
 RENDER_DEVICE_OUT = 0x2
 RENDER_SYNC = 0x4
@@ -125,6 +125,11 @@ class Scene:
         return len(self.materials) - 1
 
     # AreaEmitter(emission), emitter.hpp:17
+    def mirror(self) -> int:
+        """drt::MirrorBxDF (bxdf.hpp:126-144, repaired): no colour parameter."""
+        self.materials.append((BXDF_MIRROR, -1, 0.0))
+        return len(self.materials) - 1
+
     def area_emitter(self, param: int) -> int:
         self.emitters.append(param)
         return len(self.emitters) - 1
@@ -187,13 +192,16 @@ class Scene:
         return d, [shapes, mats, emis, params, rg, meshes, self.meshes]
 
 
-def cornell_box(front_specular: bool = False, emissive_wall: bool = False) -> Scene:
+def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front_mirror: bool = False,
+                mirror_wall: bool = False) -> Scene:
     """The hard-coded scene of /root/reference/src/render.cpp:26-59 (same order, same values).
 
     front_specular: sphere_front uses SpecularBxDF(white, 30) (render.cpp:35 creates it, the
     reference scene leaves it unused; BASELINE config 5 uses it).
     emissive_wall: the back plane additionally carries an emitter (a shape with BOTH a BxDF and
-    an emitter: several emission terms per path)."""
+    an emitter: several emission terms per path).
+    front_mirror / mirror_wall: sphere_front / the back plane use MirrorBxDF (unit normals only: a
+    mirror off the non-unit right wall would hand the spheres a non-unit direction)."""
     s = Scene()
     red = s.parameter((0.5, 0, 0), True, "red")                 # render.cpp:26
     green = s.parameter((0, 0.5, 0), True, "green")             # :27
@@ -204,7 +212,8 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False) -> Sc
     diffuse_white = s.diffuse(white)                            # :34
     specular_white = s.specular(white, 30)                      # :35
     emitter = s.area_emitter(emission)                          # :36
-    s.sphere((0., 0., 3.), 1., specular_white if front_specular else diffuse_white)  # :39
+    mirror = s.mirror() if (front_mirror or mirror_wall) else -1
+    s.sphere((0., 0., 3.), 1., mirror if front_mirror else (specular_white if front_specular else diffuse_white))  # :39
     s.sphere((-1., 1., 4.5), 1., diffuse_white)                 # :40
     s.plane((-1., 0., 0.), -3., diffuse_red)                    # :41 left
     s.plane((1., 0., 0.1), -3., diffuse_green)                  # :42 right (normal NOT unit)
@@ -212,7 +221,7 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False) -> Sc
         glow = s.parameter((0.05, 0.1, 0.2), True, "glow")
         s.plane((0., 0., -1.), -6., diffuse_white, s.area_emitter(glow))
     else:
-        s.plane((0., 0., -1.), -6., diffuse_white)              # :43 back
+        s.plane((0., 0., -1.), -6., mirror if mirror_wall else diffuse_white)   # :43 back
     s.plane((0, 0, 1), 0, diffuse_white)                        # :44 front
     s.plane((0., 1., 0.), -3., diffuse_white)                   # :45 ground
     s.plane((0., -1., 0.), -3., diffuse_white)                  # :46 ceiling
@@ -309,6 +318,10 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box(front_specular=True)
     if name == "cornell_emissive_wall":
         return cornell_box(emissive_wall=True)
+    if name == "cornell_mirror":
+        return cornell_box(front_mirror=True)
+    if name == "cornell_mirror_wall":
+        return cornell_box(front_specular=True, mirror_wall=True)
     if name.startswith("random"):
         return random_scene(int(name[len("random"):]))
     if name.startswith("mesh"):          # mesh<n_lat>x<n_lon>[f<per-face params>]

@@ -35,7 +35,8 @@ struct drt_hip_ctx {
 
     bool has_scene = false;
     bool has_specular = false;
-    int n_params = 0, n_shapes = 0;
+    int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)
+    int n_user_params = 0;            // what the caller uploaded and gets gradients for
     std::vector<uint8_t> requires_grad;
     std::vector<drt_material_desc> materials;
     DevScene<float>* d_scene_f = nullptr;
@@ -184,7 +185,12 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     ds.n_shapes = s->n_shapes;
     ds.n_materials = s->n_materials;
     ds.n_emitters = s->n_emitters;
-    ds.n_params = s->n_params;
+    // a mirror has no colour parameter (bxdf.hpp:126-144): its materials point at an internal constant
+    // (1, 1, 1) appended after the caller's parameters (never reported, never differentiated)
+    bool any_mirror = false;
+    for (int i = 0; i < s->n_materials; ++i)
+        any_mirror = any_mirror || s->materials[i].type == DRT_BXDF_MIRROR;
+    ds.n_params = s->n_params + (any_mirror ? 1 : 0);
     int flat = 0;
     for (int i = 0; i < s->n_shapes; ++i) {
         ds.flat[i] = flat;
@@ -197,14 +203,14 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     }
     for (int i = 0; i < s->n_materials; ++i) {
         ds.materials[i].type = s->materials[i].type;
-        ds.materials[i].param = s->materials[i].param;
+        ds.materials[i].param = s->materials[i].type == DRT_BXDF_MIRROR ? s->n_params : s->materials[i].param;
         ds.materials[i].exponent = (R)s->materials[i].exponent;
         ds.materials[i].norm = (R)((s->materials[i].exponent + 2.0) / (2.0 * DRT_PI));
     }
     for (int i = 0; i < s->n_emitters; ++i)
         ds.emitter_param[i] = s->emitters[i].param;
-    params.resize((size_t)s->n_params * 3);
-    for (size_t i = 0; i < params.size(); ++i)
+    params.assign((size_t)ds.n_params * 3, R(1));
+    for (size_t i = 0; i < (size_t)s->n_params * 3; ++i)
         params[i] = (R)s->params[i];
 }
 
@@ -716,7 +722,7 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
         return DRT_ERR_INVALID;
     if (!s || s->n_shapes < 0 || s->n_shapes > DRT_MAX_SHAPES || s->n_materials < 0 ||
         s->n_materials > DRT_MAX_MATERIALS || s->n_emitters < 0 || s->n_emitters > DRT_MAX_EMITTERS ||
-        s->n_params < 0 || s->n_params >= (int)DRT_ID_NONE ||
+        s->n_params < 0 || s->n_params + 1 >= (int)DRT_ID_NONE ||
         (s->n_shapes && !s->shapes) || (s->n_materials && !s->materials) ||
         (s->n_emitters && !s->emitters) || (s->n_params && !s->params))
         return fail(ctx, DRT_ERR_INVALID, "scene: bad counts or null arrays");
@@ -742,7 +748,7 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     }
     for (int i = 0; i < s->n_materials; ++i) {
         if (s->materials[i].type == DRT_BXDF_MIRROR)
-            return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: DRT_BXDF_MIRROR is reserved (the reference's does not compile)");
+            continue;                  // no colour parameter
         if (s->materials[i].type != DRT_BXDF_DIFFUSE && s->materials[i].type != DRT_BXDF_SPECULAR)
             return fail(ctx, DRT_ERR_INVALID, "scene: unknown material type");
         if (s->materials[i].param < 0 || s->materials[i].param >= s->n_params)
@@ -776,6 +782,7 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     if (rc == DRT_OK) rc = up((void**)&ctx->d_scene_d, hd, sizeof *hd);
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_f, pf.data(), pf.size() * sizeof(float));
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_d, pd.data(), pd.size() * sizeof(double));
+    const int n_dev_params = hf->n_params;   // user parameters + internal constants
     delete hf;
     delete hd;
     if (rc != DRT_OK)
@@ -823,16 +830,20 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
             ctx->has_mesh = true;
         }
     }
-    ctx->n_params = s->n_params;
+    ctx->n_user_params = s->n_params;
+    ctx->n_params = n_dev_params;      // + the internal constant of mirror materials, if any
     ctx->n_shapes = s->n_shapes;
-    ctx->requires_grad.assign((size_t)s->n_params, 1);
+    ctx->requires_grad.assign((size_t)ctx->n_params, 1);
+    if (ctx->n_params > s->n_params)
+        ctx->requires_grad[(size_t)s->n_params] = 0;
     if (s->requires_grad)
         for (int i = 0; i < s->n_params; ++i)
             ctx->requires_grad[i] = s->requires_grad[i] ? 1 : 0;
     // only materials that a shape or a mesh face actually uses decide the K3 instantiation
     // (render.cpp:35 creates a specular material its scene never uses)
     ctx->has_specular = false;
-    auto uses = [&](int m) { if (m >= 0 && s->materials[m].type == DRT_BXDF_SPECULAR) ctx->has_specular = true; };
+    // (mirrors live in the specular instantiation too)
+    auto uses = [&](int m) { if (m >= 0 && s->materials[m].type != DRT_BXDF_DIFFUSE) ctx->has_specular = true; };
     for (int i = 0; i < s->n_shapes; ++i) {
         uses(s->shapes[i].material);
         if (s->shapes[i].type == DRT_SHAPE_MESH && s->meshes[s->shapes[i].mesh].face_material)
@@ -852,7 +863,7 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
     if (!params)
         return fail(ctx, DRT_ERR_INVALID, "params is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<float> pf((size_t)ctx->n_params * 3);
+    std::vector<float> pf((size_t)ctx->n_user_params * 3);   // internal constants keep their values
     for (size_t i = 0; i < pf.size(); ++i)
         pf[i] = (float)params[i];
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -879,7 +890,7 @@ int drt_hip_render_gradient_image(drt_hip_ctx* ctx, const drt_camera_desc* cam, 
         return DRT_ERR_INVALID;
     if (!ctx->has_scene)
         return fail(ctx, DRT_ERR_NO_SCENE, "render before upload_scene");
-    if (!rp || !out_grad_rgb || param < 0 || param >= ctx->n_params)
+    if (!rp || !out_grad_rgb || param < 0 || param >= ctx->n_user_params)
         return fail(ctx, DRT_ERR_INVALID, "gradient image: bad parameter index or NULL output");
     drt_render_params r = *rp;
     r.flags |= DRT_RENDER_BACKWARD;
@@ -989,14 +1000,14 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
 
     // parameters that do not require grad keep a zero gradient (vector.hpp:156-162)
     if (backward && dev_out && out_param_grad) {
-        for (int p = 0; p < ctx->n_params; ++p)
+        for (int p = 0; p < ctx->n_user_params; ++p)
             if (!ctx->requires_grad[p])
                 HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)p * 3, 0, 3 * sizeof(double), ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_user_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
 
     const bool sync = !dev_out || (rp->flags & DRT_RENDER_SYNC) || timing || stats;
-    const size_t img_bytes = npix_all * 3 * sizeof(float), grad_bytes = (size_t)ctx->n_params * 3 * sizeof(double);
+    const size_t img_bytes = npix_all * 3 * sizeof(float), grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
     const size_t off_grad = 16, off_img = off_grad + ((grad_bytes + 15) & ~(size_t)15), off_gimg = off_img + img_bytes;
     {
         const size_t need = off_gimg + img_bytes;
@@ -1034,7 +1045,7 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
             memcpy(out_gimg, ctx->h_stage + off_gimg, img_bytes);
     }
     if (!dev_out && backward && out_param_grad)
-        for (int p = 0; p < ctx->n_params; ++p)
+        for (int p = 0; p < ctx->n_user_params; ++p)
             if (!ctx->requires_grad[p])
                 out_param_grad[p * 3] = out_param_grad[p * 3 + 1] = out_param_grad[p * 3 + 2] = 0.0;
 

@@ -548,6 +548,16 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
     // the diffuse sampler (0/0 here; the reference survives only because cos(asin(1.0)) is 6e-17 in
     // fp64), u1 = 0 or 1 give pdf 0 in the specular one (inf/NaN in the reference too).  At ~1e9
     // draws per render a 2^-31 event happens, so the draw is kept one step inside the interval.
+    if (SPEC && m.type == DRT_BXDF_MIRROR) {
+        // bxdf.hpp:126-144 (repaired): dir = reflect(dir_in, n), pdf 1, f = 1 / cos on every channel;
+        // its two draws are skipped, not used.  The colour parameter is the scene's internal
+        // constant (1, 1, 1), so tape, radiance and gradient kernels need no special case.
+        const V3<R> wi = -d;
+        wo = reflect(wi, nrm);
+        q = R(1);
+        bs = R(1) / dot(nrm, wo);
+        return;
+    }
     r1 = r1 < 1u ? 1u : (r1 > 2147483646u ? 2147483646u : r1);
     const R u2 = u01(R(0), r2);
     R sphi, cphi;

@@ -5,7 +5,9 @@
 // Gram-Schmidt frame that keeps the normal AS GIVEN) is the reference's.
 // Additive: kind()/parameter()/exponent() so a scene can be flattened for the device.
 // MirrorBxDF: the reference's does not compile once instantiated (:135 returns a double where a
-// Vector is expected); here it is a well-formed delta reflector with the same interface.
+// Vector is expected); here it is a well-formed delta reflector with the same interface.  Its
+// sample() draws and discards two numbers: in this build every BxDF sample advances the stream by
+// two draws, so the position of a draw is a closed form of the depth (device path, drt_hip.h).
 #pragma once
 
 #include <array>
@@ -132,6 +134,8 @@ public:
 
     std::tuple<Vector<T, 3>, double> sample(const Vector<T, 3>& normal, const Vector<T, 3>& dir_in) const override
     {
+        (void)random::uniform();
+        (void)random::uniform();
         return std::make_tuple(reflect(dir_in, normal), 1.0);
     }
 

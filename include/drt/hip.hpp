@@ -127,9 +127,11 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
                     md.type = DRT_BXDF_DIFFUSE;
                 else if (b->kind() == BxDFKind::Specular)
                     md.type = DRT_BXDF_SPECULAR;
+                else if (b->kind() == BxDFKind::Mirror)
+                    md.type = DRT_BXDF_MIRROR;
                 else
                     throw std::runtime_error("drt::hip: BxDF type has no device record");
-                md.param = param_index(*b->parameter());
+                md.param = md.type == DRT_BXDF_MIRROR ? -1 : param_index(*b->parameter());
                 md.exponent = b->exponent();
                 it = material_of.emplace(b, (int)f.materials.size()).first;
                 f.materials.push_back(md);

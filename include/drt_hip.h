@@ -54,7 +54,9 @@ typedef enum drt_status {
  *      src/render.cpp:22; the device converts to its compute type) ------------------------ */
 
 enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2 };
-enum { DRT_BXDF_DIFFUSE = 0, DRT_BXDF_SPECULAR = 1, DRT_BXDF_MIRROR = 2 /* reserved */ };
+enum { DRT_BXDF_DIFFUSE = 0, DRT_BXDF_SPECULAR = 1,
+       DRT_BXDF_MIRROR = 2 /* bxdf.hpp:126-144 repaired: f = 1/cos, dir = reflect(dir_in, n), pdf 1; param = -1;
+                              its sample discards two draws (see drt_rng_u31) */ };
 
 typedef struct drt_shape_desc {
     int32_t type;      /* DRT_SHAPE_* */
@@ -81,7 +83,7 @@ typedef struct drt_mesh_desc {
 
 typedef struct drt_material_desc {
     int32_t type;      /* DRT_BXDF_* */
-    int32_t param;     /* index of the colour parameter (bxdf.hpp:82,122 m_color) */
+    int32_t param;     /* index of the colour parameter (bxdf.hpp:82,122 m_color); MIRROR: -1 */
     double exponent;   /* SPECULAR only (bxdf.hpp:123), not differentiable */
 } drt_material_desc;
 

@@ -229,6 +229,15 @@ static v3 bxdf_sample(const drt_material_desc* m, v3 normal, v3 dir_in, rng_t* r
         return v3_make(0, 0, 0);
     }
     v3 frame[3];
+    if (m->type == DRT_BXDF_MIRROR) {
+        /* bxdf.hpp:137-142 (reflect(dir_in, normal), pdf 1).  Convention of this build (harness
+         * plugin, host API, oracle, device): EVERY BxDF sample advances the stream by two draws, so a
+         * draw's position is a closed form of the depth; the mirror discards its two. */
+        (void)rng_uniform(rng);
+        (void)rng_uniform(rng);
+        *pdf = 1;
+        return v3_reflect(dir_in, normal);
+    }
     if (m->type == DRT_BXDF_DIFFUSE) {
         double theta = asin(sqrt(rng_uniform(rng)));
         double phi = 2 * k_pi * rng_uniform(rng);
@@ -257,6 +266,10 @@ static double bxdf_scalar(const drt_material_desc* m, v3 normal, v3 dir_in, v3 d
     if (m->type == DRT_BXDF_DIFFUSE) {
         *is_div = 1;
         return k_pi;
+    }
+    if (m->type == DRT_BXDF_MIRROR) {
+        *is_div = 1;                      /* bxdf.hpp:133-135: 1 / cos_theta, on every channel */
+        return v3_dot(normal, dir_out);
     }
     v3 halfway = v3_normalize(v3_add(dir_in, dir_out));
     double cos_theta = v3_dot(normal, halfway);
@@ -331,7 +344,7 @@ static void vertex_eval(const drt_scene_desc* sc, vertex_t* v, v3 dir_out)
     const drt_material_desc* m = v->material >= 0 ? &sc->materials[v->material] : NULL;
     if (m) {
         v->bscalar = bxdf_scalar(m, v->normal, v->dir_in, dir_out, &v->bdiv);
-        v3 color = param_rgb(sc, m->param);
+        v3 color = m->param >= 0 ? param_rgb(sc, m->param) : v3_make(1, 1, 1);   /* mirror: no colour */
         v->f = v->bdiv ? v3_div(color, v->bscalar) : v3_scale(color, v->bscalar);
     } else {
         v->bscalar = 0;

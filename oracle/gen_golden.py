@@ -109,6 +109,18 @@ SMALL = [
          min_bounces=3, absorb=0.3, seed=9, unbiased=True),
     dict(name="u5_unbiased_mesh10x12_24x24x3", scene="mesh10x12", width=24, height=24, spp=3, min_bounces=2,
          absorb=0.3, seed=4, unbiased=True),
+    # MirrorBxDF: the reference's class with its one compile defect repaired, as a plugin of the harness
+    # (FixedMirror in oracle/ref_harness.cpp) inside the unmodified reference path tracer
+    dict(name="m1_mirror_48x48x6_d6", scene="cornell_mirror", width=48, height=48, spp=6, min_bounces=6,
+         absorb=1.0, seed=13, dump_paths=96),
+    dict(name="m2_mirror_wall_40x32x6_rr_adj", scene="cornell_mirror_wall", width=40, height=32, spp=6,
+         min_bounces=2, absorb=0.3, seed=17, adjoint_seed=6),
+    dict(name="m3_mirror_libc_32x32x4_d4", scene="cornell_mirror", width=32, height=32, spp=4, min_bounces=4,
+         absorb=1.0, seed=1, rng_mode=O.RNG_LIBC),
+    dict(name="m4_mirror_gradimage_white_32x32x6", scene="cornell_mirror_wall", width=32, height=32, spp=6,
+         min_bounces=3, absorb=0.3, seed=8, grad_image_param=2),
+    dict(name="u6_unbiased_mirror_32x24x4_rr", scene="cornell_mirror", width=32, height=24, spp=4, min_bounces=2,
+         absorb=0.4, seed=19, unbiased=True),
     dict(name="g11_mesh40x40_48x48x4_d5", scene="mesh40x40", width=48, height=48, spp=4, min_bounces=5,
          absorb=1.0, seed=9),
 ]

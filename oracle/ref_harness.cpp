@@ -89,6 +89,26 @@ static void close_vertex()
     }
 }
 
+// The reference's MirrorBxDF (bxdf.hpp:126-144) with its one defect repaired: operator() there
+// returns a double where a Vector is expected and does not compile once instantiated.  Same value
+// (1 / cos_theta on every channel), same sample (reflect(dir_in, normal), pdf 1).  Convention of this
+// build: every BxDF sample advances the random stream by two draws (so the position of a draw is a
+// closed form of the depth); the mirror draws and discards its two.
+class FixedMirror : public drt::BxDF<T> {
+public:
+    drt::Vector<T, 3, true> operator()(const V3& normal, const V3&, const V3& dir_out) const override
+    {
+        double cos_theta = drt::dot(normal, dir_out);
+        return drt::Vector<T, 3, true>(V3(1 / cos_theta));
+    }
+    std::tuple<V3, double> sample(const V3& normal, const V3& dir_in) const override
+    {
+        (void)drt::random::uniform();
+        (void)drt::random::uniform();
+        return std::make_tuple(drt::reflect(dir_in, normal), 1.0);
+    }
+};
+
 // First entry of the scene: never hits, counts raycast() calls (pathtracer.hpp:72-89 calls
 // intersect on every shape, in order, once per raycast).
 class CountingShape : public drt::Shape<T> {
@@ -294,6 +314,8 @@ int main(int argc, char** argv)
                     materials.push_back(std::make_shared<drt::DiffuseBxDF<T>>(params.at(param)));
                 else if (type == DRT_BXDF_SPECULAR)
                     materials.push_back(std::make_shared<drt::SpecularBxDF<T>>(params.at(param), e));
+                else if (type == DRT_BXDF_MIRROR)
+                    materials.push_back(std::make_shared<FixedMirror>());
                 else
                     die("unsupported material type");
             }

@@ -39,9 +39,14 @@ int main(int argc, const char* argv[])
     auto diffuse_green = std::make_shared<DiffuseBxDF<T>>(green);
     auto diffuse_white = std::make_shared<DiffuseBxDF<T>>(white);
     auto emitter = std::make_shared<AreaEmitter<T>>(emission);
+    std::shared_ptr<BxDF<T>> front = diffuse_white;                                  // render.cpp:39
+    if (args.front == "specular")
+        front = std::make_shared<SpecularBxDF<T>>(white, 30);                        // render.cpp:35
+    else if (args.front == "mirror")
+        front = std::make_shared<MirrorBxDF<T>>();
 
     // shapes
-    Sphere<T> sphere_front(Vector<T, 3>{0., 0., 3.}, 1., diffuse_white);
+    Sphere<T> sphere_front(Vector<T, 3>{0., 0., 3.}, 1., front);
     Sphere<T> sphere_back(Vector<T, 3>{-1., 1., 4.5}, 1., diffuse_white);
     Plane<T> left_plane(Vector<T, 3>{-1., 0., 0.}, -3., diffuse_red);
     Plane<T> right_plane(Vector<T, 3>{1., 0., 0.1}, -3., diffuse_green);

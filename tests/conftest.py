@@ -54,12 +54,12 @@ def case_inputs(pkg, case):
 SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_64x64x8_rr",
                  "g4_specular_64x64x8_d8", "g4b_emissive_wall_48x32x8_adj", "g7_random3_40x30x6",
                  "g8_random8_36x36x6_d5", "g9_mesh6x8_40x30x4", "g10_mesh10x12f5_32x32x4_d4",
-                 "g11_mesh40x40_48x48x4_d5"]
+                 "g11_mesh40x40_48x48x4_d5", "m1_mirror_48x48x6_d6", "m2_mirror_wall_40x32x6_rr_adj"]
 
 
 UNBIASED_GOLDENS = ["u1_unbiased_cornell_40x30x4_rr", "u2_unbiased_cornell_48x48x4_d4",
                     "u3_unbiased_specular_32x32x4_adj", "u4_unbiased_emissive_wall_32x24x4",
-                    "u5_unbiased_mesh10x12_24x24x3"]
+                    "u5_unbiased_mesh10x12_24x24x3", "u6_unbiased_mirror_32x24x4_rr"]
 
 
 @pytest.fixture(scope="session")

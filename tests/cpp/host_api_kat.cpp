@@ -124,6 +124,17 @@ int main()
     MirrorBxDF<double> mirror;
     auto mdir = std::get<0>(mirror.sample(V{0, 1, 0}, V{1, 1, 0}));
     CHECK(mdir[0] == -1 && mdir[1] == 1);
+    // f = 1 / cos on every channel; every BxDF sample advances the stream by two draws, the mirror too
+    CHECK(close(mirror(V{0, 1, 0}, V{1, 1, 0}, V{-0.6, 0.8, 0}).detach()[2], 1.25));
+    random::begin_path(7, 42);
+    (void)mirror.sample(V{0, 1, 0}, V{0, 1, 0});
+    CHECK(close(random::uniform(), drt_rng_u31(7, 42, 2) / 2147483647.0));
+    auto mmirror = std::make_shared<MirrorBxDF<double>>();
+    Sphere<double> s4(V{0, -1, 3}, 0.5, mmirror);
+    Scene<double> scene3{&s1, &s4, &s2};
+    auto flat3 = hip::flatten(scene3);
+    CHECK(flat3.materials.size() == 2 && flat3.materials[1].type == DRT_BXDF_MIRROR && flat3.materials[1].param == -1);
+    CHECK(flat3.requires_grad.size() == 2);              // white and the emission: the mirror adds no parameter
     // mesh extension: brute-force triangles on the host path, flattened for the device
     std::vector<V> mv{V{-1, -1, 2}, V{1, -1, 2}, V{0, 1, 2}, V{0, 0, 4}};
     std::vector<std::array<uint32_t, 3>> mt{{{0, 1, 2}}, {{0, 1, 3}}};

@@ -244,7 +244,8 @@ def test_finite_difference_of_albedo(pkg, hip):
     hip.update_params(base)
 
 
-@pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr"])
+@pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr",
+                                  "m4_mirror_gradimage_white_32x32x6"])
 def test_gradient_image_matches_reference(pkg, hip, name):
     """drt_hip_render_gradient_image against the per-pixel gradients the reference produces."""
     g = load_golden(name)
@@ -352,3 +353,41 @@ def test_malformed_scenes_are_rejected_not_crashed(pkg):
     img, g, _ = r.render(cam, pkg.RenderParams(spp=2, min_bounces=2, absorb=0.5), backward=True)
     assert np.isfinite(img).all() and np.isfinite(g).all()
     r.close()
+
+
+def test_mirror_bxdf_at_scale_and_update_params(pkg, hip, oracle):
+    """MirrorBxDF (bxdf.hpp:126-144 repaired): a larger frame against the oracle in both device modes, a
+    mirror next to more than 4 parameters (general gradient path + the internal constant), and
+    update_params leaving the internal constant alone."""
+    scene = pkg.scene_by_name("cornell_mirror_wall")
+    cam = pkg.cornell_camera(96, 80)
+    rp = pkg.RenderParams(spp=8, min_bounces=3, absorb=0.25, seed=23)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    img, grads, stats = hip.render(cam, rp, backward=True, f64=True)
+    assert stats["segments"] == ref["stats"]["segments"]
+    assert grads.shape == (scene.n_params, 3) and grad_rel_err(grads, ref["grads"]) < 1e-9
+    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    img, grads, stats = hip.render(cam, rp, backward=True)
+    check_f32(img, grads, stats["segments"], ref["image"], ref["grads"], ref["stats"]["segments"])
+    # update_params == re-upload (the internal constant of the mirror must survive the update)
+    newp = np.array(scene.params) * 0.7 + 0.05
+    hip.update_params(newp)
+    a = hip.render(cam, rp, backward=True)
+    scene.params = [tuple(v) for v in newp]
+    hip.upload_scene(scene)
+    b = hip.render(cam, rp, backward=True)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    # a mirror sphere among random spheres with 9+ parameters
+    scene = pkg.random_scene(4)
+    scene.sphere((0.3, -1.2, 2.2), 0.8, scene.mirror())
+    cam = pkg.Camera(48, 40).look_at((0.1, 0.0, -0.2), (0, 0.2, 1))
+    rp = pkg.RenderParams(spp=8, min_bounces=2, absorb=0.35, seed=4)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    img, grads, stats = hip.render(cam, rp, backward=True, f64=True)
+    assert stats["segments"] == ref["stats"]["segments"] and grad_rel_err(grads, ref["grads"]) < 1e-9
+    ref_u = oracle.render(scene, cam, rp, backward=True, unbiased=True, zero_dir_miss=True)
+    img, grads, stats = hip.render(cam, rp, backward=True, f64=True, unbiased=True)
+    assert stats["segments"] == ref_u["stats"]["segments"] and grad_rel_err(grads, ref_u["grads"]) < 1e-9

@@ -86,6 +86,20 @@ def test_cpu_backend_of_the_app_matches_the_oracle(app, pkg, oracle, tmp_path):
     np.testing.assert_array_equal(img[..., :3], ref["image"].astype(np.float32).astype(np.float16).astype(np.float32))
 
 
+@pytest.mark.parametrize("front,scene_name", [("specular", "cornell_specular"), ("mirror", "cornell_mirror")])
+def test_cpu_backend_with_specular_and_mirror_front_sphere(app, pkg, oracle, tmp_path, front, scene_name):
+    """SpecularBxDF and the (repaired) MirrorBxDF of the host API against the oracle, gradients to the
+    printed precision."""
+    out = str(tmp_path / "cpu.exr")
+    r = sh([app, "-o", out, "-x", "32", "-y", "24", "-n", "4", "-b", "2", "-p", "0.3", "--backend", "cpu",
+            "--backward", "--seed", "5", "--front", front])
+    ref = oracle.render(pkg.scene_by_name(scene_name), pkg.cornell_camera(32, 24),
+                        pkg.RenderParams(spp=4, min_bounces=2, absorb=0.3, seed=5), backward=True)
+    np.testing.assert_allclose(parse_grads(r.stdout), ref["grads"], rtol=1e-8)
+    np.testing.assert_array_equal(read_exr_half_rgba(out)[..., :3],
+                                  ref["image"].astype(np.float32).astype(np.float16).astype(np.float32))
+
+
 def test_cli_flags_and_errors(app, tmp_path):
     assert subprocess.run([app], capture_output=True).returncode != 0              # -o is required
     assert subprocess.run([app, "-o", "x", "--bogus"], capture_output=True).returncode != 0
@@ -142,6 +156,15 @@ def test_app_on_the_device_matches_its_cpu_backend(app, tmp_path):
     assert np.abs(ia - ib).max() <= 2e-3 * ib.max()
     c = sh([app, "-o", str(tmp_path / "hip64.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "4", "-p", "1", "--backward", "--f64"])
     np.testing.assert_allclose(parse_grads(c.stdout), gb, rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_app_mirror_front_sphere_on_the_device(app, tmp_path):
+    flags = ["-x", "48", "-y", "40", "-n", "6", "-b", "3", "-p", "0.3", "--backward", "--front", "mirror"]
+    cpu = sh([app, "-o", str(tmp_path / "cpu.exr"), "--backend", "cpu"] + flags)
+    dev = sh([app, "-o", str(tmp_path / "hip.exr"), "--f64"] + flags)
+    np.testing.assert_allclose(parse_grads(dev.stdout), parse_grads(cpu.stdout), rtol=1e-8)
+    np.testing.assert_array_equal(read_exr_half_rgba(str(tmp_path / "hip.exr")), read_exr_half_rgba(str(tmp_path / "cpu.exr")))
 
 
 @pytest.mark.gpu

@@ -7,7 +7,7 @@ import pytest
 from conftest import SMALL_GOLDENS, UNBIASED_GOLDENS, case_inputs, load_golden
 
 
-@pytest.mark.parametrize("name", SMALL_GOLDENS + ["g6_libc_64x64x8_d4"])
+@pytest.mark.parametrize("name", SMALL_GOLDENS + ["g6_libc_64x64x8_d4", "m3_mirror_libc_32x32x4_d4"])
 def test_oracle_bit_exact_vs_reference_golden(pkg, oracle, name):
     g = load_golden(name)
     case = g["case"]
@@ -32,7 +32,8 @@ def test_oracle_bit_exact_vs_reference_golden(pkg, oracle, name):
         assert r2["stats"]["segments"] == int(g["segments"]) and r2["stats"]["zero_dir_segments"] == 0
 
 
-@pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr"])
+@pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr",
+                                  "m4_mirror_gradimage_white_32x32x6"])
 def test_gradient_image_bit_exact(pkg, oracle, name):
     """Per-pixel gradient of one parameter: the reference computes it by zeroing param.grad() before
     each pixel's samples (harness); the restatement must reproduce image, gradient image and totals."""
