@@ -126,6 +126,14 @@ __device__ inline double max_r(double a, double b) { return fmax(a, b); }
 __device__ inline float abs_r(float x) { return fabsf(x); }
 __device__ inline double abs_r(double x) { return fabs(x); }
 __device__ inline float pow_r(float x, float y) { return powf(x, y); }
+// x^y for x <= 1 where only a smooth WEIGHT depends on it (never a direction or a discrete decision):
+// v_exp_f32(y * v_log_f32(x)), ~1e-6 relative for y <= 100
+// (x <= 0 happens when the half vector dips below the surface: keep libm's answer there, e.g. (-x)^30 > 0)
+__device__ inline float pow_weight_r(float x, float y)
+{
+    return x > 0.f ? __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)) : powf(x, y);
+}
+__device__ inline double pow_weight_r(double x, double y) { return pow(x, y); }
 __device__ inline double pow_r(double x, double y) { return pow(x, y); }
 __device__ inline void sincospi_r(float x, float* s, float* c) { sincospif(x, s, c); }
 __device__ inline void sincospi_r(double x, double* s, double* c) { sincospi(x, s, c); }

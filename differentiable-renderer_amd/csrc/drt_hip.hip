@@ -574,7 +574,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                            d_scene, d_params, tape, nv, cs, gpart, grad);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_BACKWARD]++;
-                    hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast, grad);
+                    hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast, grad);
                     st->launches[DRT_K_GRADREDUCE]++;
                     if (chains_done)
                         break;
@@ -591,7 +591,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_BACKWARD]++;
                 if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_gradreduce, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast,
+                hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast,
                                    grad);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_GRADREDUCE]++;

@@ -608,7 +608,7 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
         }
         R s2 = (R(1) - ch) * (R(1) + ch);
         s2 = s2 > R(0) ? s2 : R(0);
-        bs = m.norm * pow_r(ch, m.exponent) * sqrt_r(s2);
+        bs = m.norm * pow_weight_r(ch, m.exponent) * sqrt_r(s2);
     }
 }
 
@@ -1445,24 +1445,24 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
 }
 
 // ---- K7 ---------------------------------------------------------------------------------------
-// grad[p] += sum over blocks of gpart[block][p], blocks in index order (deterministic)
+// grad[p] += sum over blocks of gpart[block][p] in a fixed order (deterministic); one block per row p
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_gradreduce(const double* __restrict__ gpart, int n_blocks, int n_fast, double* __restrict__ grad)
 {
     __shared__ double red[DRT_BLOCK];
-    for (int p = 0; p < n_fast * 3; ++p) {
-        double v = 0;
-        for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
-            v += gpart[(size_t)b * (DRT_FAST_PARAMS * 3) + p];
-        red[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off)
-                red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0)
-            grad[p] += red[0];
+    const int p = blockIdx.x;
+    if (p >= n_fast * 3)
+        return;
+    double v = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
+        v += gpart[(size_t)b * (DRT_FAST_PARAMS * 3) + p];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
+    if (threadIdx.x == 0)
+        grad[p] += red[0];
 }
