@@ -423,18 +423,30 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
         // ---- leaves
         if (active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) {
             const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, count = cur & 7u;
-            for (uint32_t j = first; j < first + count; ++j) {
-                const R4 ta = bvh.tri_a[j], tb = bvh.tri_b[j], tc = bvh.tri_c[j];
-                R t;
-                if (tri_intersect(mk<R>(ta.x, ta.y, ta.z), mk<R>(ta.w, tb.x, tb.y), mk<R>(tb.z, tb.w, tc.x), o, d, t)) {
-                    const uint32_t flat = pid_unpack(tc.z);
-                    if (t < tmin || (t == tmin && flat < best_flat)) {
-                        tmin = t;
-                        prim = n_shapes + (int)pid_unpack(tc.y);
-                        best_flat = flat;
+            // all triangles of the leaf (<= kMaxLeaf = 4) are requested before the first is tested:
+            // one round trip to L2 per leaf instead of one per triangle
+            R4 ta[4], tb[4], tcc[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (j < count) {
+                    ta[j] = bvh.tri_a[first + j];
+                    tb[j] = bvh.tri_b[first + j];
+                    tcc[j] = bvh.tri_c[first + j];
+                }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (j < count) {
+                    R t;
+                    if (tri_intersect(mk<R>(ta[j].x, ta[j].y, ta[j].z), mk<R>(ta[j].w, tb[j].x, tb[j].y),
+                                      mk<R>(tb[j].z, tb[j].w, tcc[j].x), o, d, t)) {
+                        const uint32_t flat = pid_unpack(tcc[j].z);
+                        if (t < tmin || (t == tmin && flat < best_flat)) {
+                            tmin = t;
+                            prim = n_shapes + (int)pid_unpack(tcc[j].y);
+                            best_flat = flat;
+                        }
                     }
                 }
-            }
             cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
         if (active && cur == DRT_BVH_NONE) {
