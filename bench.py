@@ -90,15 +90,32 @@ def main():
     r.upload_scene(scene)
     dev = torch.device("cuda", local_rank)
     out_rgb = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device=dev)
-    grad = torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev)
+    # two gradient buffers: the all-reduce of step i runs on its own stream while step i + 1 renders
+    # into the other buffer (every step's gradient is complete and reduced; only its delivery overlaps
+    # the next step's compute -- "collectives on a separate stream", the usual data-parallel overlap)
+    grads = [torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev) for _ in range(2)]
     ext = torch.cuda.ExternalStream(r.stream, device=dev)
+    comm = torch.cuda.Stream(device=dev) if use_dist else None
+    reduced = [None, None]          # event: the all-reduce that last used this buffer has finished
+    n_step = [0]
 
     def step(timing=False):
+        b = n_step[0] & 1
+        n_step[0] += 1
+        grad = grads[b]
+        if reduced[b] is not None:
+            ext.wait_event(reduced[b])         # step i - 2's all-reduce read this buffer
         st = r.render_device(cam, rp, out_rgb.data_ptr(), grad.data_ptr() if backward else 0,
                              backward=backward, timing=timing, sync=False)
         if use_dist and backward:
-            with torch.cuda.stream(ext):
+            rendered = torch.cuda.Event()
+            rendered.record(ext)
+            comm.wait_event(rendered)
+            with torch.cuda.stream(comm):
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)   # the ONE collective of the path
+                done = torch.cuda.Event()
+                done.record(comm)
+            reduced[b] = done
         return st
 
     def fence():
