@@ -391,3 +391,31 @@ def test_mirror_bxdf_at_scale_and_update_params(pkg, hip, oracle):
     ref_u = oracle.render(scene, cam, rp, backward=True, unbiased=True, zero_dir_miss=True)
     img, grads, stats = hip.render(cam, rp, backward=True, f64=True, unbiased=True)
     assert stats["segments"] == ref_u["stats"]["segments"] and grad_rel_err(grads, ref_u["grads"]) < 1e-9
+
+
+def test_config5_shape_properties_at_scale(pkg, hip):
+    """BASELINE config 5's shape (specular front sphere, depth 16) on a 1024 x 1024 frame, through
+    size-independent properties: linearity in the emission, bitwise determinism, several batches vs
+    one, and the f32 kernels against the device's own flip-free f64 mode (same paths)."""
+    import dataclasses
+    scene = pkg.cornell_box(front_specular=True)
+    cam = pkg.cornell_camera(1024, 1024)
+    rp = pkg.RenderParams(spp=8, min_bounces=16, absorb=1.0, seed=2)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    assert np.isfinite(img).all() and np.isfinite(grads).all()
+    assert st["paths"] == 1024 * 1024 * 8 and st["segments"] > 10 * st["paths"]
+    e = scene.param_names.index("emission")
+    total = img.astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[e] * np.array(scene.params[e]), total, rtol=5e-6)
+    again = hip.render(cam, rp, backward=True)
+    np.testing.assert_array_equal(again[0], img)
+    np.testing.assert_array_equal(again[1], grads)
+    split = hip.render(cam, dataclasses.replace(rp, batch_paths=3_000_000), backward=True)
+    assert split[2]["batches"] > 1 and split[2]["segments"] == st["segments"]
+    np.testing.assert_allclose(split[1], grads, rtol=1e-7)
+    img64, g64, st64 = hip.render(cam, rp, backward=True, f64=True)
+    assert abs(st64["segments"] - st["segments"]) <= 2e-5 * st64["segments"]
+    assert grad_rel_err(grads, g64) < GRAD_TOL
+    m32, m64 = img.astype(np.float64).mean((0, 1)), img64.astype(np.float64).mean((0, 1))
+    assert np.abs(m32 - m64).max() <= MEAN_TOL * m64.max()
