@@ -28,9 +28,13 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# vector-instruction issue: a wave64 VALU op takes 2 cycles of its SIMD; 256 CUs x 4 SIMDs at 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0     # 1228.8 G wave-instructions / s
 # algorithmic bytes per ray segment, f32 queues
-# shade_fused: K2 folded into K3 (analytic scenes): ray 24 + id 8 read; ray 24 + id 8 + tape 8 written
-BYTES_PER_UNIT = {"intersect": 32.0, "shade": 80.0, "shade_fused": 72.0, "backward": 8.0}
+# shade (unfused): ray 24 + id 8 + hit 8 read; ray 24 + id 8 + tape 8 written per segment.
+# Fused shade (K2 folded into K3, several bounces per launch in registers): 8 B of tape per segment + 32 B
+# per ray a launch READS from the queue + 32 B per survivor it WRITES back -- the library counts both.
+BYTES_PER_UNIT = {"intersect": 32.0, "shade": 80.0, "backward": 8.0}
 
 
 def _oracle_shard(args):
@@ -57,6 +61,9 @@ def main():
     ap.add_argument("--unbiased", action="store_true", help="backward with the unbiased integration operator")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming-view", action="store_true",
+                    help="skip the extra one-launch-per-bounce measurement (profiling runs: keeps kernel statistics unmixed)")
+    ap.add_argument("--bounces-per-launch", type=int, default=0, help="0 = automatic (drt_hip.h)")
     ap.add_argument("--cpu-spp", type=int, default=16)
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the oracle on every host core (independent row-band processes)")
@@ -84,7 +91,8 @@ def main():
     backward = not a.forward_only
     rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
                           shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
-                          flags=pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0)
+                          flags=pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0,
+                          bounces_per_launch=a.bounces_per_launch)
 
     r = pkg.HipRenderer(local_rank)          # raises without libdrt_hip.so / a device: no fallback
     r.upload_scene(scene)
@@ -151,6 +159,7 @@ def main():
     fence()
     segments = stats["segments"]
     paths = stats["paths"]
+    queue_rays = stats["queue_rays_read"] + stats["queue_rays_written"]
     if use_dist:
         t = torch.tensor([segments, paths], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -165,7 +174,7 @@ def main():
     units = {"intersect": segments, "shade": segments, "backward": segments,
              "raygen": paths, "film": paths, "gradreduce": 0}
     bpu = {"intersect": BYTES_PER_UNIT["intersect"],
-           "shade": BYTES_PER_UNIT["shade" if kernel_launches["intersect"] else "shade_fused"],
+           "shade": BYTES_PER_UNIT["shade"] if kernel_launches["intersect"] else 8.0 + 32.0 * queue_rays / max(1, segments),
            "backward": BYTES_PER_UNIT["backward"], "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
     per_kernel = {}
     for k in pkg.KERNEL_NAMES:
@@ -174,7 +183,7 @@ def main():
             continue
         gbs = units[k] * bpu[k] / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
         per_kernel[k] = {"ms_per_step": round(ms, 4), "launches_per_step": kernel_launches[k] // n_prof,
-                         "bytes_per_unit": bpu[k], "achieved_GBs": round(gbs, 1),
+                         "bytes_per_unit": round(bpu[k], 3), "achieved_GBs": round(gbs, 1),
                          "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     dominant = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else "shade"
     traffic = None
@@ -195,6 +204,53 @@ def main():
                 "traversal_kernel": dict(per_kernel.get("intersect") or per_kernel.get("shade") or {},
                                          name="k_intersect" if "intersect" in per_kernel else "k_shade<fused>"),
                 "kernels": per_kernel}
+    shade = per_kernel.get("shade")
+    multi_bounce = shade is not None and not kernel_launches["intersect"] and shade["launches_per_step"] < a.depth
+    if multi_bounce:
+        # The fused shade kernel keeps a ray in registers over several bounces: the queue traffic is paid once
+        # per launch, not per segment, and the kernel is bound by vector-instruction issue, not by HBM.  Two
+        # extra views so the HBM fraction above is not read alone:
+        #  (1) the vector-issue utilisation, from the rocprofv3 SQ_INSTS_VALU count of the same kernel;
+        #  (2) the SAME workload with one launch per bounce (bounces_per_launch = 1, the streaming wavefront
+        #      the HBM roofline describes), timed live here.
+        roofline["note"] = (f"k_shade runs {a.depth // max(1, shade['launches_per_step'])} bounces per launch in registers "
+                            f"({shade['bytes_per_unit']} B/segment): VALU-issue-bound; see roofline.valu and roofline.streaming")
+        try:
+            vi = json.load(open(tpath)).get("shade", {}).get("valu_insts_per_launch")
+        except Exception:
+            vi = None
+        if vi:
+            ginst = vi / (shade["ms_per_step"] / shade["launches_per_step"] * 1e-3) * 1e-9
+            roofline["valu"] = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                                "frac": round(ginst / VALU_PEAK_GINST, 4),
+                                "note": "SQ_INSTS_VALU per launch (profiles/traffic.json, rocprofv3 --pmc) / live launch time"}
+    if multi_bounce and not a.no_streaming_view:
+        import dataclasses
+        rp1 = dataclasses.replace(rp, bounces_per_launch=1)
+
+        def step1(timing=False):
+            return r.render_device(cam, rp1, out_rgb.data_ptr(), grads[0].data_ptr() if backward else 0,
+                                   backward=backward, timing=timing, sync=False)
+        for _ in range(2):
+            step1()
+        fence()
+        t4 = time.perf_counter()
+        for _ in range(n_prof):
+            step1()
+        fence()
+        dt4 = (time.perf_counter() - t4) / n_prof
+        ms1, q1 = 0.0, 0
+        for _ in range(n_prof):
+            st1 = step1(timing=True)
+            ms1 += st1["kernels"]["shade"]["ms"]
+            q1 = st1["queue_rays_read"] + st1["queue_rays_written"]
+        fence()
+        ms1 /= n_prof
+        bpu1 = 8.0 + 32.0 * q1 / max(1, segments)
+        gbs1 = segments * bpu1 / (ms1 * 1e-3) * 1e-9 if ms1 > 0 else 0.0
+        roofline["streaming"] = {"bounces_per_launch": 1, "value": round(segments / dt4 * 1e-6, 2), "unit": "Mray/s",
+                                 "ms_per_step": round(dt4 * 1e3, 4), "kernel": "k_shade", "bytes_per_unit": round(bpu1, 3),
+                                 "achieved": round(gbs1, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs1 / HBM_PEAK_GBS, 4)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

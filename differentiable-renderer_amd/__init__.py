@@ -78,17 +78,20 @@ class RenderParamsDesc(C.Structure):
     _fields_ = [("spp", C.c_int32), ("min_bounces", C.c_int32), ("absorb", C.c_double),
                 ("max_depth", C.c_int32), ("seed", C.c_uint32),
                 ("shard", C.c_int32), ("n_shards", C.c_int32), ("band_rows", C.c_int32),
-                ("flags", C.c_uint32), ("batch_paths", C.c_int64)]
+                ("flags", C.c_uint32), ("batch_paths", C.c_int64),
+                ("bounces_per_launch", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HipStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("batches", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double * K_COUNT),
-                ("launches", C.c_uint64 * K_COUNT), ("units", C.c_uint64 * K_COUNT)]
+                ("launches", C.c_uint64 * K_COUNT), ("units", C.c_uint64 * K_COUNT),
+                ("queue_rays_read", C.c_uint64), ("queue_rays_written", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {"paths": int(self.paths), "segments": int(self.segments),
-             "batches": int(self.batches), "ms_total": float(self.ms_total), "kernels": {}}
+             "batches": int(self.batches), "ms_total": float(self.ms_total), "kernels": {},
+             "queue_rays_read": int(self.queue_rays_read), "queue_rays_written": int(self.queue_rays_written)}
         for k, name in enumerate(KERNEL_NAMES):
             d["kernels"][name] = {"ms": float(self.ms_kernel[k]), "launches": int(self.launches[k]),
                                   "units": int(self.units[k])}
@@ -385,10 +388,12 @@ class RenderParams:
     band_rows: int = 16
     flags: int = 0
     batch_paths: int = 0
+    bounces_per_launch: int = 0     # 0 = automatic; 1 = one launch per bounce
 
     def to_desc(self) -> RenderParamsDesc:
         return RenderParamsDesc(self.spp, self.min_bounces, self.absorb, self.max_depth, self.seed,
-                                self.shard, self.n_shards, self.band_rows, self.flags, self.batch_paths)
+                                self.shard, self.n_shards, self.band_rows, self.flags, self.batch_paths,
+                                self.bounces_per_launch, 0)
 
 
 def shard_rows(height: int, band_rows: int, n_shards: int, shard: int) -> np.ndarray:

@@ -257,12 +257,12 @@ int grid_for(const drt_hip_ctx* ctx, uint64_t work)
 int queue_length(drt_hip_ctx* ctx, const uint32_t* counts_row, uint32_t n_regions, unsigned long long* out)
 {
     int rc;
-    if ((rc = ensure(ctx, ctx->probe, sizeof(unsigned long long))) != DRT_OK) return rc;
+    if ((rc = ensure(ctx, ctx->probe, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;
     if (!ctx->h_probe)
         HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_probe, sizeof(unsigned long long)));
     HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_sum_counts, dim3(16), dim3(DRT_BLOCK), 0, ctx->stream, counts_row, n_regions,
-                       (unsigned long long*)ctx->probe.p);
+                       (unsigned long long*)ctx->probe.p, n_regions, 0ull, 0ull);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_probe, ctx->probe.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out = *ctx->h_probe;
@@ -356,8 +356,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     (void)n_batches;
     *n_count_words = cw;
     if ((rc = ensure(ctx, ctx->counts, cw * sizeof(uint32_t))) != DRT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->segtotal, sizeof(unsigned long long))) != DRT_OK) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, sizeof(unsigned long long), ctx->stream));
+    if ((rc = ensure(ctx, ctx->segtotal, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written
+    HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const int bwd_grid = grid_for(ctx, N);
     if (backward)
         if ((rc = ensure(ctx, ctx->gpart, (size_t)bwd_grid * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
@@ -409,6 +409,30 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     // hit is saved as the next chain vertex
     static const bool fuse_env = !(getenv("DRT_HIP_FUSE") && atoi(getenv("DRT_HIP_FUSE")) == 0);
     const bool can_fuse = fuse_env && !ctx->has_mesh;
+    // Bounces per fused launch (at most 8).  Inside a launch the lanes of ended paths idle -- cheap next
+    // to the queue traffic saved, measured: even at absorb = 0.5 four bounces per launch beat one --
+    // so a launch only stops where fewer than ~10 % of its rays are expected to be left: ~7 % end
+    // per bounce on a miss or a light (Cornell-like scenes), the roulette removes `absorb` of them at
+    // every depth >= min_bounces.
+    // DRT_HIP_SHADE_BOUNCES=n forces n (1 = one launch per bounce).
+    static const int shade_nb_env = getenv("DRT_HIP_SHADE_BOUNCES") ? atoi(getenv("DRT_HIP_SHADE_BOUNCES")) : 0;
+    auto bounces_from = [&](int k) -> int {
+        if (!can_fuse)
+            return 1;
+        const int left = D - k;
+        const int forced = shade_nb_env > 0 ? shade_nb_env : (rp->bounces_per_launch > 8 ? 8 : rp->bounces_per_launch);
+        if (forced > 0)
+            return forced < left ? forced : left;
+        double alive = 1.0;
+        int n = 0;
+        while (n < left && n < 8) {
+            alive *= 0.93 * ((k + n + 1) >= rp->min_bounces && (k + n + 1) < D ? 1.0 - rp->absorb : 1.0);
+            ++n;
+            if (alive < 0.1)
+                break;
+        }
+        return n;
+    };
     uint64_t batch = 0;
     for (uint32_t p0 = 0; p0 < n_local_pixels; p0 += Pb) {
         for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += Sb, ++batch) {
@@ -429,9 +453,15 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             st->launches[DRT_K_RAYGEN]++;
             st->units[DRT_K_RAYGEN] += a.n_paths;
 
-            for (int k = 0; k < D; ++k) {
-                const int cur = k & 1, nxt = cur ^ 1;
-                if (D > 2 * DRT_POLL_EVERY && k >= DRT_POLL_EVERY && k % DRT_POLL_EVERY == 0) {
+            // fused launches take every ray through shade_nb bounces in registers (1, 2, 4 or 8)
+            unsigned long long read_rows = 0, written_rows = 0;   // queue rows shade launches start from / end on
+            for (int k = 0, lc = 0, nbk = 1, next_poll = DRT_POLL_EVERY; k < D; k += nbk, ++lc) {
+                const int cur = lc & 1, nxt = cur ^ 1;
+                nbk = bounces_from(k);
+                read_rows |= 1ull << k;
+                if (k + nbk < D) written_rows |= 1ull << (k + nbk);
+                if (D > 2 * DRT_POLL_EVERY && k >= next_poll) {
+                    next_poll = k + DRT_POLL_EVERY;
                     unsigned long long live = 0;
                     if ((rc = queue_length(ctx, counts + (size_t)k * max_regions, max_regions, &live)) != DRT_OK) return rc;
                     if (live == 0)
@@ -465,12 +495,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     static const int shade_bpc = getenv("DRT_HIP_SHADE_BLOCKS_PER_CU") ? atoi(getenv("DRT_HIP_SHADE_BLOCKS_PER_CU")) : 0;
                     if (shade_bpc > 0 && ctx->n_cu * shade_bpc < g)
                         gs = ctx->n_cu * shade_bpc;
-                    const uint32_t* ck = counts + (size_t)k * max_regions;
-                    uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
-#define DRT_LAUNCH_SHADE(SPEC, FUSE, SEG, DBASE)                                                          \
-    hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, d_scene, \
-                       d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, \
-                       ck, cn, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
+                    uint32_t* ck = counts + (size_t)k * max_regions;
+#define DRT_LAUNCH_SHADE(SPEC, FUSE, SEG, DBASE)                                                               \
+    hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk, d_scene, \
+                       d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,      \
+                       ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
                     if (fused) {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, true, 0, (const uint32_t*)nullptr);
@@ -484,7 +513,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             }
 
             hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts,
-                               (uint32_t)((size_t)D * max_regions), (unsigned long long*)ctx->segtotal.p);
+                               (uint32_t)((size_t)D * max_regions), (unsigned long long*)ctx->segtotal.p,
+                               (uint32_t)max_regions, read_rows, written_rows);
             if (backward && D > 0 && gimg_param >= 0) {
                 // gradient image: per-path gradient of one parameter, averaged per pixel by K5
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
@@ -520,16 +550,20 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         if ((rc = queue_length(ctx, counts + (size_t)s * max_regions, max_regions, &live)) != DRT_OK) return rc;
                         chains_done = live == 0;
                     }
-                    for (int k = s; k < D && !chains_done; ++k) {
-                        const int cur = k & 1, nxt = cur ^ 1;
-                        if (D > 2 * DRT_POLL_EVERY && k - s >= DRT_POLL_EVERY && (k - s) % DRT_POLL_EVERY == 0) {
+                    unsigned long long sfx_read = 0, sfx_written = 0;     // rows relative to depth s
+                    for (int k = s, lc = 0, nbk = 1, next_poll = s + DRT_POLL_EVERY; k < D && !chains_done; k += nbk, ++lc) {
+                        const int cur = (s + lc) & 1, nxt = cur ^ 1;     // k_adj_vertex queued the suffix rays in buffer s & 1
+                        nbk = bounces_from(k);
+                        sfx_read |= 1ull << (k - s);
+                        if (k + nbk < D) sfx_written |= 1ull << (k + nbk - s);
+                        if (D > 2 * DRT_POLL_EVERY && k >= next_poll) {
+                            next_poll = k + DRT_POLL_EVERY;
                             unsigned long long live = 0;
                             if ((rc = queue_length(ctx, counts + (size_t)k * max_regions, max_regions, &live)) != DRT_OK) return rc;
                             if (live == 0)
                                 break;
                         }
-                        const uint32_t* ck = counts + (size_t)k * max_regions;
-                        uint32_t* cn = counts + (size_t)(k + 1) * max_regions;
+                        uint32_t* ck = counts + (size_t)k * max_regions;
                         const bool fused = can_fuse;
                         R4* sv_a = k == s && fused ? cs.nx_a : (R4*)nullptr;
                         typename Q2<R>::T* sv_b = k == s && fused ? cs.nx_b : (typename Q2<R>::T*)nullptr;
@@ -559,7 +593,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (s < D)
                         hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream,
                                            counts + (size_t)s * max_regions, (uint32_t)((size_t)(D - s) * max_regions),
-                                           (unsigned long long*)ctx->segtotal.p);
+                                           (unsigned long long*)ctx->segtotal.p, (uint32_t)max_regions, sfx_read, sfx_written);
                     hipLaunchKernelGGL(k_radiance_from<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, s, d_scene,
                                        d_params, tape, nv, cs);
                     if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
@@ -1008,7 +1042,7 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
 
     const bool sync = !dev_out || (rp->flags & DRT_RENDER_SYNC) || timing || stats;
     const size_t img_bytes = npix_all * 3 * sizeof(float), grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
-    const size_t off_grad = 16, off_img = off_grad + ((grad_bytes + 15) & ~(size_t)15), off_gimg = off_img + img_bytes;
+    const size_t off_grad = 32, off_img = off_grad + ((grad_bytes + 15) & ~(size_t)15), off_gimg = off_img + img_bytes;
     {
         const size_t need = off_gimg + img_bytes;
         if (ctx->h_stage_cap < need) {
@@ -1031,11 +1065,14 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     ctx->h_segments = 0;
     const bool want_segments = stats && n_count_words;
     if (want_segments)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     if (sync)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (want_segments)
+    unsigned long long h_queue[2] = {0, 0};
+    if (want_segments) {
         memcpy(&ctx->h_segments, ctx->h_stage, sizeof(unsigned long long));
+        memcpy(h_queue, ctx->h_stage + sizeof(unsigned long long), sizeof h_queue);
+    }
     if (!dev_out) {
         if (out_rgb)
             memcpy(out_rgb, ctx->h_stage + off_img, img_bytes);
@@ -1051,6 +1088,8 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
 
     if (stats) {
         st.segments = ctx->h_segments;
+        st.queue_rays_read = h_queue[0];
+        st.queue_rays_written = h_queue[1];
         st.units[DRT_K_INTERSECT] = st.segments;
         st.units[DRT_K_SHADE] = st.segments;
         st.units[DRT_K_BACKWARD] = backward ? st.segments : 0;

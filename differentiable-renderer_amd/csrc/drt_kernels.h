@@ -647,30 +647,33 @@ __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_
 // segment.  Used whenever nothing else needs the hit records (no mesh, no unbiased chain vertices).
 template <typename R, bool SPEC, bool FUSED>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
-k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
+k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
         const uint2* __restrict__ ray_id, const HitRec<R>* __restrict__ hit,
         typename Q4<R>::T* __restrict__ next_a, typename Q2<R>::T* __restrict__ next_b,
         uint2* __restrict__ next_id,
         TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
-        const uint32_t* __restrict__ counts_k,
-        uint32_t* __restrict__ counts_next, const typename Q4<R>::T* __restrict__ tri_shade,
+        uint32_t* __restrict__ counts_k, uint32_t count_stride,
+        const typename Q4<R>::T* __restrict__ tri_shade,
         int seg_start, const uint32_t* __restrict__ draw_base,
         typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
         HitRec<R>* __restrict__ save_hit)
 {
+    // nb > 1 (FUSED only): the launch takes every ray through nb bounces -- depths k .. k+nb-1 -- in
+    // registers; only the survivors of the LAST one are compacted and written back.  Lanes whose
+    // path ended in between idle (a few per cent per bounce), in exchange the 64 bytes of queue
+    // traffic per ray are paid once per nb segments.  counts_k + j * count_stride is the row of
+    // depth k + j: the rows in between are kept up to date with one non-returning atomic per chunk
+    // (a region is owned by one wave), the row of depth k + nb is written like before.
     typedef typename Q4<R>::T R4;
+    typedef typename Q2<R>::T R2;
     __shared__ SceneLds<R> lds;
     stage_scene(lds, sc, params);
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const R pk = k >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
-    // camera paths start at depth 0 with a closed-form base; re-sampled suffixes (unbiased
-    // backward) start at seg_start with a per-path base
-    const uint32_t n_off = draw_offset(k, seg_start, a.min_bounces) + (draw_base ? 0u : camera_draw_base(a.min_bounces));
-    const bool next_rr = (k + 1) >= a.min_bounces;
-    const bool next_cap = (k + 1) >= a.depth_cap;
+    const size_t N = a.n_paths;
+    uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
     uint32_t cnt;
     uint32_t w = next_live_region(counts_k, grid_wave(), n_waves, a.n_regions, cnt);
@@ -692,86 +695,105 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
         const bool nhave = more && noff + lane < ncnt;
         load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
 
-        bool alive = false;
-        R4 na;
-        typename Q2<R>::T nb;
-        if (have) {
-            const R4 ra = cur.ra;
-            const typename Q2<R>::T rb = cur.rb;
-            HitRec<R> h;
-            if (FUSED) {
-                const R4 ra1[1] = {ra};
-                const typename Q2<R>::T rb1[1] = {rb};
-                HitRec<R> h1[1];
-                closest_hit_n<R, 1>(sc, lds.sc.n_shapes, ra1, rb1, h1);
-                h = h1[0];
-            } else {
-                h = cur.h;
-            }
-            const uint32_t pid = cur.rid.x;
-            if (save_a) {          // unbiased backward: this ray and its hit are the path's next chain vertex
-                save_a[pid] = ra;
-                save_b[pid] = rb;
-                save_hit[pid] = h;
-            }
-            if (h.prim < 0) {
-                nv[pid] = (uint32_t)k;                        // miss: pathtracer.hpp:135
-            } else {
-                const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
-                const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
-                const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
-                V3<R> nrm;
-                int material, emitter;
-                resolve_hit(lds, tri_shade, h.prim, P, nrm, material, emitter);
-                // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
-                uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
-                if (emitter >= 0)
-                    eid = (uint32_t)lds.sc.emitter_param[emitter];
-                if (material < 0) {
-                    // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
-                    // continuation contributes exactly 0, the path ends here
-                    TapeRec<R> tr;
-                    tr.m = R(0);
-                    tr.ids = DRT_ID_NONE | (eid << 16);
-                    tape_k[pid] = tr;
-                    nv[pid] = (uint32_t)k + 1u;
+        bool alive = false, live = have;
+        R4 ra = cur.ra, na;
+        R2 rb = cur.rb, nb2;
+        const uint32_t pid = cur.rid.x, key = cur.rid.y;
+        for (int it = 0;; ++it) {
+            const int kk = k + it;
+            const R pk = kk >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
+            // camera paths start at depth 0 with a closed-form base; re-sampled suffixes (unbiased
+            // backward) start at seg_start with a per-path base
+            const uint32_t n_off = draw_offset(kk, seg_start, a.min_bounces) + (draw_base ? 0u : camera_draw_base(a.min_bounces));
+            const bool next_rr = (kk + 1) >= a.min_bounces;
+            const bool next_cap = (kk + 1) >= a.depth_cap;
+            TapeRec<R>* __restrict__ tape_kk = tape_k + (size_t)it * N;
+            alive = false;
+            if (live) {
+                HitRec<R> h;
+                if (FUSED) {
+                    const R4 ra1[1] = {ra};
+                    const R2 rb1[1] = {rb};
+                    HitRec<R> h1[1];
+                    closest_hit_n<R, 1>(sc, lds.sc.n_shapes, ra1, rb1, h1);
+                    h = h1[0];
                 } else {
-                    const DevMaterial<R>& m = lds.sc.materials[material];
-                    cid = (uint32_t)m.param;
-                    const uint32_t key = cur.rid.y;
-                    const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
-                    V3<R> wo;
-                    R q, bs;
-                    sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
-                    const R c = dot(nrm, wo);                  // pathtracer.hpp:103
-                    const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
+                    h = cur.h;
+                }
+                if (save_a && it == 0) {   // unbiased backward: this ray and its hit are the path's next chain vertex
+                    save_a[pid] = ra;
+                    save_b[pid] = rb;
+                    save_hit[pid] = h;
+                }
+                if (h.prim < 0) {
+                    nv[pid] = (uint32_t)kk;                       // miss: pathtracer.hpp:135
+                } else {
+                    const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+                    const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+                    const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
+                    V3<R> nrm;
+                    int material, emitter;
+                    resolve_hit(lds, tri_shade, h.prim, P, nrm, material, emitter);
+                    // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
+                    uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
+                    if (emitter >= 0)
+                        eid = (uint32_t)lds.sc.emitter_param[emitter];
+                    if (material < 0) {
+                        // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
+                        // continuation contributes exactly 0, the path ends here
+                        TapeRec<R> tr;
+                        tr.m = R(0);
+                        tr.ids = DRT_ID_NONE | (eid << 16);
+                        tape_kk[pid] = tr;
+                        nv[pid] = (uint32_t)kk + 1u;
+                    } else {
+                        const DevMaterial<R>& m = lds.sc.materials[material];
+                        cid = (uint32_t)m.param;
+                        const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
+                        V3<R> wo;
+                        R q, bs;
+                        sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+                        const R c = dot(nrm, wo);                  // pathtracer.hpp:103
+                        const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
 #ifdef DRT_DEBUG_NAN
-                    if (!(mk_ == mk_) || mk_ > R(1e30) || mk_ < R(-1e30))
-                        printf("[k_shade] pid %u k %d type %d: bs %g c %g q %g pk %g | nrm %g %g %g | d %g %g %g | wo %g %g %g | t %g prim %d\n",
-                               pid, k, m.type, (double)bs, (double)c, (double)q, (double)pk, (double)nrm.x, (double)nrm.y,
-                               (double)nrm.z, (double)d.x, (double)d.y, (double)d.z, (double)wo.x, (double)wo.y, (double)wo.z,
-                               (double)h.t, h.prim);
+                        if (!(mk_ == mk_) || mk_ > R(1e30) || mk_ < R(-1e30))
+                            printf("[k_shade] pid %u k %d type %d: bs %g c %g q %g pk %g | nrm %g %g %g | d %g %g %g | wo %g %g %g | t %g prim %d\n",
+                                   pid, kk, m.type, (double)bs, (double)c, (double)q, (double)pk, (double)nrm.x, (double)nrm.y,
+                                   (double)nrm.z, (double)d.x, (double)d.y, (double)d.z, (double)wo.x, (double)wo.y, (double)wo.z,
+                                   (double)h.t, h.prim);
 #endif
-                    // roulette / cap of depth k+1, decided here so dead rays are never queued
-                    alive = !next_cap;
-                    if (alive && next_rr)
-                        alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                    TapeRec<R> tr;
-                    tr.m = mk_;
-                    tr.ids = cid | (eid << 16);
-                    tape_k[pid] = tr;
-                    if (!alive) nv[pid] = (uint32_t)k + 1u;
-                    const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
-                    na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
-                    nb.x = wo.y; nb.y = wo.z;
+                        // roulette / cap of depth kk+1, decided here so dead rays are never queued
+                        alive = !next_cap;
+                        if (alive && next_rr)
+                            alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                        TapeRec<R> tr;
+                        tr.m = mk_;
+                        tr.ids = cid | (eid << 16);
+                        tape_kk[pid] = tr;
+                        if (!alive) nv[pid] = (uint32_t)kk + 1u;
+                        const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
+                        na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
+                        nb2.x = wo.y; nb2.y = wo.z;
+                    }
                 }
             }
+            if (it + 1 >= nb)
+                break;
+            // survivors go straight into the next bounce; the row of the depth in between only counts them
+            const uint32_t n_mid = (uint32_t)__popcll(__ballot(alive));
+            if (n_mid == 0)
+                break;                                             // (alive is false in every lane)
+            if (lane == 0)
+                atomicAdd(counts_k + (size_t)(it + 1) * count_stride + w, n_mid);
+            ra = na;
+            rb = nb2;
+            live = alive;
         }
         uint32_t n_alive;
         const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
         if (alive) {
             next_a[ns] = na;
-            next_b[ns] = nb;
+            next_b[ns] = nb2;
             next_id[ns] = cur.rid;
         }
         running += n_alive;
@@ -792,23 +814,37 @@ k_shade(BatchArgs a, int k, const DevScene<R>* __restrict__ sc, const R* __restr
 
 // segments of one batch = rays queued at depths 0..D-1, summed over regions -> 64-bit total
 __global__ void __launch_bounds__(DRT_BLOCK)
-k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total)
+k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total,
+             uint32_t row_words, unsigned long long read_rows, unsigned long long written_rows)
 {
-    __shared__ unsigned long long red[DRT_BLOCK / DRT_WAVE];
-    unsigned long long v = 0;
-    for (uint32_t i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n_words; i += gridDim.x * DRT_BLOCK)
-        v += counts[i];
-    for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
+    // total[0] += all words (= segments); total[1] += the rows a shade launch STARTED from (rays read from
+    // the queue), total[2] += the rows a launch ended on (survivors written back); row r = bit r of the masks
+    __shared__ unsigned long long red[3][DRT_BLOCK / DRT_WAVE];
+    unsigned long long v = 0, vr = 0, vw = 0;
+    for (uint32_t i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n_words; i += gridDim.x * DRT_BLOCK) {
+        const unsigned long long c = counts[i];
+        const uint32_t row = row_words ? i / row_words : 0u;
+        v += c;
+        if (row < 64u && ((read_rows >> row) & 1ull)) vr += c;
+        if (row < 64u && ((written_rows >> row) & 1ull)) vw += c;
+    }
+    for (int off = DRT_WAVE / 2; off > 0; off >>= 1) {
         v += __shfl_down(v, off);
-    if ((threadIdx.x & (DRT_WAVE - 1)) == 0)
-        red[threadIdx.x / DRT_WAVE] = v;
+        vr += __shfl_down(vr, off);
+        vw += __shfl_down(vw, off);
+    }
+    if ((threadIdx.x & (DRT_WAVE - 1)) == 0) {
+        red[0][threadIdx.x / DRT_WAVE] = v;
+        red[1][threadIdx.x / DRT_WAVE] = vr;
+        red[2][threadIdx.x / DRT_WAVE] = vw;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 3) {
         unsigned long long t = 0;
         for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
-            t += red[w];
+            t += red[threadIdx.x][w];
         if (t)
-            atomicAdd(total, t);   // integer: order-independent
+            atomicAdd(total + threadIdx.x, t);   // integer: order-independent
     }
 }
 

@@ -35,6 +35,7 @@ struct Options {
     int band_rows = 16;
     bool f64 = false;               // verification mode: compute in double on the device
     long long batch_paths = 0;
+    int bounces_per_launch = 0;     // 0 = automatic; 1 = one shade launch per bounce (drt_hip.h)
 };
 
 struct Stats {
@@ -246,6 +247,7 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
             rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
                        (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
             rp.batch_paths = opt.batch_paths;
+            rp.bounces_per_launch = opt.bounces_per_launch;
             ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, frames[d].data(),
                                      opt.backward ? grads[d].data() : nullptr, &stats[d]),
                       "drt_hip_render");

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 2
+#define DRT_HIP_ABI_VERSION 3
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -135,6 +135,11 @@ typedef struct drt_render_params {
                                the bands of `shard`. n_shards <= 1 renders everything. */
     uint32_t flags;         /* DRT_RENDER_* */
     int64_t batch_paths;    /* paths in flight per wavefront batch, <=0 = default */
+    int32_t bounces_per_launch; /* scenes of analytic shapes: bounces a shade launch takes a ray through in
+                               registers before survivors are compacted back into the queue (1 = the
+                               classic one-launch-per-bounce wavefront, HBM-bound; up to 8). <= 0 = automatic:
+                               as many as most rays are expected to survive. Results do not depend on it. */
+    int32_t reserved;
 } drt_render_params;
 
 enum {
@@ -156,6 +161,8 @@ typedef struct drt_hip_stats {
     double ms_kernel[DRT_K_COUNT];  /* summed HIP-event time per kernel (DRT_RENDER_TIMING) */
     uint64_t launches[DRT_K_COUNT];
     uint64_t units[DRT_K_COUNT];    /* segments (K2,K3,K6) or paths (K1,K5) processed */
+    uint64_t queue_rays_read;       /* rays the shade launches read from the queue (a fused launch keeps a ray */
+    uint64_t queue_rays_written;    /* in registers over several bounces) / survivors they wrote back: 32 B each */
 } drt_hip_stats;
 
 typedef struct drt_hip_ctx drt_hip_ctx;

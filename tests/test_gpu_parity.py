@@ -16,6 +16,10 @@ from conftest import SMALL_GOLDENS, case_inputs, load_golden
 pytestmark = pytest.mark.gpu
 
 GRAD_TOL = 1e-4
+# the random scenes (roulette-boosted long paths, exponent-80 lobes, non-unit wall normals) have heavy-tailed
+# per-path weights: the handful of f32-flipped paths of a tiny fixture (13 of 32,450 segments in g7) move
+# its gradient by ~1e-4; DESIGN.md section 6
+GRAD_TOL_HEAVY = 5e-4
 MEAN_TOL = 1e-4
 PIXEL_TOL = 2e-4
 OUTLIER_FRAC = 5e-3
@@ -25,7 +29,7 @@ def grad_rel_err(got, want):
     return float(np.abs(got - want).max() / np.abs(want).max())
 
 
-def check_f32(img, grads, segments, g_img, g_grads, g_segments):
+def check_f32(img, grads, segments, g_img, g_grads, g_segments, grad_tol=GRAD_TOL):
     scale = float(np.abs(g_img).max())
     bad = np.abs(img.astype(np.float64) - g_img).max(-1) > PIXEL_TOL * scale
     assert bad.mean() <= OUTLIER_FRAC, f"{bad.sum()} of {bad.size} pixels outside fp32 tolerance"
@@ -35,7 +39,7 @@ def check_f32(img, grads, segments, g_img, g_grads, g_segments):
     # one path whose fp32 hit/miss decision flips can change the count by its whole length (<= 64)
     assert abs(int(segments) - int(g_segments)) <= max(64, int(2e-4 * g_segments))
     if g_grads is not None:
-        assert grad_rel_err(grads, g_grads) <= GRAD_TOL + 4.0 * bad.sum() / bad.size
+        assert grad_rel_err(grads, g_grads) <= grad_tol + 4.0 * bad.sum() / bad.size
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS)
@@ -44,7 +48,8 @@ def test_f32_matches_reference_golden(pkg, hip, name):
     scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
     hip.upload_scene(scene)
     img, grads, stats = hip.render(cam, rp, backward=True, adjoint=adjoint)
-    check_f32(img, grads, stats["segments"], g["image"], g["grads"], g["segments"])
+    check_f32(img, grads, stats["segments"], g["image"], g["grads"], g["segments"],
+              GRAD_TOL_HEAVY if "random" in name else GRAD_TOL)
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS)
@@ -161,7 +166,7 @@ def test_matches_oracle_on_random_scenes(pkg, hip, oracle):
         assert stats["segments"] == ref["stats"]["segments"]
         assert grad_rel_err(grads, ref["grads"]) < 1e-9
         img, grads, stats = hip.render(cam, rp, backward=True, adjoint=adj)
-        check_f32(img, grads, stats["segments"], ref["image"], ref["grads"], ref["stats"]["segments"])
+        check_f32(img, grads, stats["segments"], ref["image"], ref["grads"], ref["stats"]["segments"], GRAD_TOL_HEAVY)
 
 
 def test_edge_cases(pkg, hip, oracle):

@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-streaming-view $*"
 cd "$PWD"
 # 1) per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"

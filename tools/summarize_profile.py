@@ -88,5 +88,6 @@ for k, t in traffic.items():
         tj[names[k]] = {"GBs": round(t["total_corrected_B"] / (us * 1e-6) * 1e-9, 1),
                         "bytes_per_launch": round(t["total_corrected_B"]), "fetch_raw_bytes": round(t["fetch_raw_B"]),
                         "write_bytes": round(t["write_B"]), "avg_launch_us": round(us, 2),
+                        "valu_insts_per_launch": round(summary[k].get("SQ_INSTS_VALU", 0.0)),
                         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)"}
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
