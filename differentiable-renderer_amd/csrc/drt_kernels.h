@@ -1007,7 +1007,8 @@ struct GradAcc<R, 0> {
 template <typename R, bool SMALL, typename Acc>
 __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds, const R* __restrict__ params,
                                      const TapeRec<R>* __restrict__ tape, size_t N, uint32_t i, int K, V3<R> g,
-                                     R inv_p_rr, Acc& acc, R (*acc_lds)[DRT_BLOCK], double* __restrict__ grad)
+                                     R inv_p_rr, Acc& acc, R (*acc_lds)[DRT_BLOCK], double* __restrict__ grad,
+                                     const TapeRec<R>* first_chunk = nullptr)
 {
     V3<R> Ln = mk<R>(R(0), R(0), R(0));
     for (int c0 = ((K - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
@@ -1020,10 +1021,17 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
         R Tx[DRT_TAPE_CHUNK], Ty[DRT_TAPE_CHUNK], Tz[DRT_TAPE_CHUNK], M[DRT_TAPE_CHUNK];
         uint32_t ID[DRT_TAPE_CHUNK];
         TapeRec<R> trs[DRT_TAPE_CHUNK];
+        if (first_chunk && c0 == 0) {
+            // vertices 0..7 were requested together with the path's vertex count (k_backward)
 #pragma unroll
-        for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
-            if (c0 + j < K)
-                trs[j] = tape[(size_t)(c0 + j) * N + i];   // independent loads, all in flight
+            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+                trs[j] = first_chunk[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+                if (c0 + j < K)
+                    trs[j] = tape[(size_t)(c0 + j) * N + i];   // independent loads, all in flight
+        }
 #pragma unroll
         for (int j = 0; j < DRT_TAPE_CHUNK; ++j) {
             if (c0 + j < K) {
@@ -1069,7 +1077,7 @@ __device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ 
 }
 
 template <typename R, int NP>
-__global__ void __launch_bounds__(DRT_BLOCK)
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : 1)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
            const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad,
@@ -1088,10 +1096,19 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
+        // The first chunk of the tape is requested WITH the vertex count, not after it: one round trip
+        // to memory per path instead of two (records beyond the path's end are read and ignored; the
+        // rows exist for every depth below the cap).  Also prefetching the NEXT path's chunk was
+        // measured slower: 174 VGPRs, 2 waves per SIMD.
         const int K = (int)nv[i];
+        TapeRec<R> first[DRT_TAPE_CHUNK];
+#pragma unroll
+        for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+            if (j < a.depth_cap)
+                first[j] = tape[(size_t)j * N + i];
         V3<R> L0 = mk<R>(R(0), R(0), R(0));
         if (K > 0)
-            L0 = backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, ga, acc, grad);
+            L0 = backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, ga, acc, grad, first);
         if (lacc) {
             R4 o;
             o.x = L0.x; o.y = L0.y; o.z = L0.z; o.w = R(0);

@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 import __graft_entry__ as e
 pkg = e.load_package()
 libs = sys.argv[1:]
-scene = pkg.cornell_box(); cam = pkg.cornell_camera(512, 512)
+scene = pkg.scene_by_name(os.environ.get("AB_SCENE", "cornell")); cam = pkg.cornell_camera(512, 512)
 rp = pkg.RenderParams(spp=64, min_bounces=8, absorb=1.0, seed=1)
 rs = [pkg.HipRenderer(0, lib_path=os.path.abspath(l)) for l in libs]
 for r in rs:
