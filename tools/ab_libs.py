@@ -9,15 +9,16 @@ pkg = e.load_package()
 libs = sys.argv[1:]
 scene = pkg.scene_by_name(os.environ.get("AB_SCENE", "cornell")); cam = pkg.cornell_camera(512, 512)
 rp = pkg.RenderParams(spp=64, min_bounces=8, absorb=1.0, seed=1)
+UNB = bool(os.environ.get("AB_UNBIASED"))
 rs = [pkg.HipRenderer(0, lib_path=os.path.abspath(l)) for l in libs]
 for r in rs:
     r.upload_scene(scene)
     for _ in range(2):
-        r.render(cam, rp, backward=True)
+        r.render(cam, rp, backward=True, unbiased=UNB)
 res = {l: [] for l in libs}
 for rnd in range(7):
     for l, r in zip(libs, rs):
-        _, _, st = r.render(cam, rp, backward=True, timing=True)
+        _, _, st = r.render(cam, rp, backward=True, timing=True, unbiased=UNB)
         res[l].append([st["kernels"][k]["ms"] for k in pkg.KERNEL_NAMES] + [st["ms_total"]])
 print("lib".ljust(44), " ".join(k[:9].rjust(9) for k in pkg.KERNEL_NAMES), "host_ms".rjust(9))
 for l in libs:
