@@ -188,7 +188,10 @@ def main():
     dominant = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else "shade"
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # the committed rocprofv3 counters were taken on the headline workload: only quote them for it
+    pmc_applies = (a.scene == "cornell" and (a.width, a.height, a.spp, a.depth) == (512, 512, 64, 8) and backward
+                   and not a.unbiased and a.bounces_per_launch == 0)
+    if pmc_applies and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath)).get(dominant)
             traffic = tj.get("GBs") if tj else None
@@ -205,7 +208,8 @@ def main():
                                          name="k_intersect" if "intersect" in per_kernel else "k_shade<fused>"),
                 "kernels": per_kernel}
     shade = per_kernel.get("shade")
-    multi_bounce = shade is not None and not kernel_launches["intersect"] and shade["launches_per_step"] < a.depth
+    multi_bounce = (shade is not None and not kernel_launches["intersect"]
+                    and shade["launches_per_step"] < a.depth * max(1, stats["batches"]) and not a.unbiased)
     if multi_bounce:
         # The fused shade kernel keeps a ray in registers over several bounces: the queue traffic is paid once
         # per launch, not per segment, and the kernel is bound by vector-instruction issue, not by HBM.  Two
@@ -213,10 +217,10 @@ def main():
         #  (1) the vector-issue utilisation, from the rocprofv3 SQ_INSTS_VALU count of the same kernel;
         #  (2) the SAME workload with one launch per bounce (bounces_per_launch = 1, the streaming wavefront
         #      the HBM roofline describes), timed live here.
-        roofline["note"] = (f"k_shade runs {a.depth // max(1, shade['launches_per_step'])} bounces per launch in registers "
+        roofline["note"] = (f"k_shade runs {a.depth * max(1, stats['batches']) // max(1, shade['launches_per_step'])} bounces per launch in registers "
                             f"({shade['bytes_per_unit']} B/segment): VALU-issue-bound; see roofline.valu and roofline.streaming")
         try:
-            vi = json.load(open(tpath)).get("shade", {}).get("valu_insts_per_launch")
+            vi = json.load(open(tpath)).get("shade", {}).get("valu_insts_per_launch") if pmc_applies else None
         except Exception:
             vi = None
         if vi:
