@@ -424,3 +424,24 @@ def test_config5_shape_properties_at_scale(pkg, hip):
     assert grad_rel_err(grads, g64) < GRAD_TOL
     m32, m64 = img.astype(np.float64).mean((0, 1)), img64.astype(np.float64).mean((0, 1))
     assert np.abs(m32 - m64).max() <= MEAN_TOL * m64.max()
+
+
+@pytest.mark.parametrize("scene_name,b,p,unbiased", [("cornell", 8, 1.0, False), ("cornell", 1, 0.4, False),
+                                                     ("cornell_specular", 3, 0.2, False), ("cornell_mirror_wall", 5, 1.0, False),
+                                                     ("cornell", 4, 1.0, True), ("cornell_specular", 2, 0.3, True)])
+def test_results_do_not_depend_on_bounces_per_launch(pkg, hip, scene_name, b, p, unbiased):
+    """A shade launch may carry its rays through 1..8 bounces in registers (drt_render_params.
+    bounces_per_launch; 0 = the library's choice): image, gradients and segment count are bitwise the same."""
+    import dataclasses
+    hip.upload_scene(pkg.scene_by_name(scene_name))
+    cam = pkg.cornell_camera(160, 96)
+    rp = pkg.RenderParams(spp=6, min_bounces=b, absorb=p, seed=12, max_depth=24)
+    ref = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, unbiased=unbiased)
+    for nb in (0, 2, 3, 8):
+        got = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=nb), backward=True, unbiased=unbiased)
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+        assert got[2]["segments"] == ref[2]["segments"]
+        if nb == 8 and not unbiased:
+            assert got[2]["kernels"]["shade"]["launches"] < ref[2]["kernels"]["shade"]["launches"]
+            assert got[2]["queue_rays_read"] < ref[2]["queue_rays_read"]
