@@ -33,6 +33,7 @@ struct DevMaterial {
 template <typename R>
 struct DevScene {
     int n_shapes, n_materials, n_emitters, n_params;
+    unsigned long long plane_mask, sphere_mask;   // bit s: the type of shape s, tested on scalar registers
     int flat[DRT_MAX_SHAPES];   // position of shape s in the flattened scene (a mesh counts once per
                                 // triangle): the order that breaks exact ties, pathtracer.hpp:80
     DevShape<R> shapes[DRT_MAX_SHAPES];

@@ -198,6 +198,8 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         for (int j = 0; j < 4; ++j)
             ds.shapes[i].p[j] = (R)s->shapes[i].p[j];
         ds.shapes[i].type = s->shapes[i].type;
+        if (s->shapes[i].type == DRT_SHAPE_PLANE) ds.plane_mask |= 1ull << i;
+        if (s->shapes[i].type == DRT_SHAPE_SPHERE) ds.sphere_mask |= 1ull << i;
         ds.shapes[i].material = s->shapes[i].material;
         ds.shapes[i].emitter = s->shapes[i].emitter;
     }

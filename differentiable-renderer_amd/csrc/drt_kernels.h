@@ -197,25 +197,32 @@ __device__ inline void closest_hit_n(const DevScene<R>* __restrict__ sc, int n_s
         tmin[r] = (R)INFINITY;
         prim[r] = -1;
     }
-    // The record of shape s + 1 is requested (scalar loads) before shape s is tested, so the scalar
-    // cache latency hides behind the arithmetic; the type is wave-uniform, so the plane and the
-    // sphere tests sit behind a real branch (the empty asm keeps the compiler from if-converting
-    // it back into "compute both, select").
-    DevShape<R> sh = sc->shapes[0];
+    // The loop is wave-uniform: its control flow and record fetches run on the CU's one scalar unit,
+    // which all four SIMDs share (the fused shade kernel issues 0.8 scalar-pipe instructions per vector
+    // instruction: tools/pmc_issue.sh).  So it is kept lean in scalar instructions: the type comes
+    // from two 64-bit masks held in scalar registers (a bit test, no load), the record is one 16-byte
+    // scalar load whose latency the other waves hide (software pipelining the fetch cost seven
+    // register moves per shape and was 2-3 % slower), and the plane and the sphere tests sit behind a
+    // real branch (the empty asm keeps the compiler from if-converting it back into "compute both,
+    // select").
+    const unsigned long long planes = sc->plane_mask, spheres = sc->sphere_mask;
     for (int s = 0; s < n_shapes; ++s) {
-        const DevShape<R> nx = sc->shapes[s + 1 < n_shapes ? s + 1 : s];
-        if (sh.type == DRT_SHAPE_PLANE) {
-            const V3<R> n = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
+        const R p0 = sc->shapes[s].p[0], p1 = sc->shapes[s].p[1], p2 = sc->shapes[s].p[2], p3 = sc->shapes[s].p[3];
+        if ((planes >> s) & 1ull) {
+            const V3<R> n = mk<R>(p0, p1, p2);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const R t = div_r(dot(o[r], n) - sh.p[3], -dot(d[r], n));      // shape.hpp:49-59
+                const R t = div_r(dot(o[r], n) - p3, -dot(d[r], n));            // shape.hpp:49-59
                 if (t > R(0) && !(t >= tmin[r])) {                              // pathtracer.hpp:80
                     tmin[r] = t;
                     prim[r] = s;
                 }
             }
-        } else if (sh.type == DRT_SHAPE_SPHERE) {
+        } else if ((spheres >> s) & 1ull) {
             asm volatile("" ::: "memory");
+            DevShape<R> sh;
+            sh.p[0] = p0; sh.p[1] = p1; sh.p[2] = p2; sh.p[3] = p3;
+            sh.type = DRT_SHAPE_SPHERE;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 R t;
@@ -225,7 +232,6 @@ __device__ inline void closest_hit_n(const DevScene<R>* __restrict__ sc, int n_s
                 }
             }
         }                                 // a mesh record: its triangles are k_intersect_mesh's business
-        sh = nx;
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -673,6 +679,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
     const size_t N = a.n_paths;
+    const int n_shapes_u = sc->n_shapes;          // wave-uniform: a scalar load, not the LDS copy
     uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
     uint32_t cnt;
@@ -715,7 +722,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                     const R4 ra1[1] = {ra};
                     const R2 rb1[1] = {rb};
                     HitRec<R> h1[1];
-                    closest_hit_n<R, 1>(sc, lds.sc.n_shapes, ra1, rb1, h1);
+                    closest_hit_n<R, 1>(sc, n_shapes_u, ra1, rb1, h1);
                     h = h1[0];
                 } else {
                     h = cur.h;
