@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_write.err"
 # 3) wave-level counters
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_sq.err"
+rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_sq.err"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2> "$OUT/summary.err"
 cat "$OUT/summary.txt"
 # keep only small files in gpurun_out (it is merged back, <= 64 MiB)
