@@ -34,6 +34,13 @@ template <typename R>
 struct DevScene {
     int n_shapes, n_materials, n_emitters, n_params;
     unsigned long long plane_mask, sphere_mask;   // bit s: the type of shape s, tested on scalar registers
+    // The same shapes as an "intersection program" for the packed f32 test (closest_hit_packed): the
+    // scene order is kept, two ADJACENT planes (or spheres) share one item and are tested with
+    // v_pk_* instructions, two at a time.  item i: 8 values -- a pair interleaved (x0, x1, y0, y1, z0,
+    // z1, w0, w1), a single in the first four -- and one bit in each mask.
+    int n_items, pad_items;
+    unsigned long long item_pair, item_sphere, item_skip;   // skip: a mesh record (one shape index, no test)
+    R items[DRT_MAX_SHAPES][8];
     int flat[DRT_MAX_SHAPES];   // position of shape s in the flattened scene (a mesh counts once per
                                 // triangle): the order that breaks exact ties, pathtracer.hpp:80
     DevShape<R> shapes[DRT_MAX_SHAPES];
@@ -92,6 +99,8 @@ struct DevBvh {
 #ifndef DRT_BVH_DESCEND_MIN
 #define DRT_BVH_DESCEND_MIN 20       // the interior-node loop runs while at least this many lanes descend
 #endif
+
+typedef float drt_f2 __attribute__((ext_vector_type(2)));
 
 // ---- small vector math -----------------------------------------------------------------------
 template <typename R>

@@ -203,6 +203,30 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         ds.shapes[i].material = s->shapes[i].material;
         ds.shapes[i].emitter = s->shapes[i].emitter;
     }
+    // the intersection program of the packed f32 test: scene order, adjacent planes / spheres paired
+    for (int i = 0; i < s->n_shapes;) {
+        const int t = s->shapes[i].type;
+        const int it = ds.n_items++;
+        if (t == DRT_SHAPE_MESH) {
+            ds.item_skip |= 1ull << it;
+            i += 1;
+            continue;
+        }
+        if (t == DRT_SHAPE_SPHERE)
+            ds.item_sphere |= 1ull << it;
+        if (i + 1 < s->n_shapes && s->shapes[i + 1].type == t) {
+            ds.item_pair |= 1ull << it;
+            for (int j = 0; j < 4; ++j) {
+                ds.items[it][2 * j] = (R)s->shapes[i].p[j];
+                ds.items[it][2 * j + 1] = (R)s->shapes[i + 1].p[j];
+            }
+            i += 2;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                ds.items[it][j] = (R)s->shapes[i].p[j];
+            i += 1;
+        }
+    }
     for (int i = 0; i < s->n_materials; ++i) {
         ds.materials[i].type = s->materials[i].type;
         ds.materials[i].param = s->materials[i].type == DRT_BXDF_MIRROR ? s->n_params : s->materials[i].param;

@@ -240,6 +240,100 @@ __device__ inline void closest_hit_n(const DevScene<R>* __restrict__ sc, int n_s
     }
 }
 
+// f32, one ray: the closest hit through the scene's intersection program (DevScene::items).  The fused
+// shade kernel is bound by its vector pipes, where every instruction costs the same 4 cycles per
+// wave and a packed one (v_pk_mul/fma/add_f32) does two lanes' worth: two adjacent planes (spheres)
+// are tested with one packed dot product each way -- 18 instead of 38 (34 instead of 80) vector
+// instructions per pair.  Shapes are visited in scene order and the first of a pair is accepted
+// first, so ties resolve exactly like the sequential loop (pathtracer.hpp:80).
+__device__ inline void hit_accept(float t, int s, float& tmin, int& prim)
+{
+    if (t > 0.f && !(t >= tmin)) {
+        tmin = t;
+        prim = s;
+    }
+}
+
+__device__ inline HitRec<float> closest_hit_packed(const DevScene<float>* __restrict__ sc, float4 ra, float2 rb)
+{
+    const V3<float> o = mk<float>(ra.x, ra.y, ra.z), d = mk<float>(ra.w, rb.x, rb.y);
+    const drt_f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const drt_f2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    float tmin = INFINITY;
+    int prim = -1;
+    const int n_items = sc->n_items;
+    const unsigned long long pairs = sc->item_pair, spheres = sc->item_sphere, skips = sc->item_skip;
+    int s = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const float* __restrict__ rec = sc->items[i];
+        const bool pair = (pairs >> i) & 1ull;
+        if ((skips >> i) & 1ull) {
+            s += 1;
+        } else if (!((spheres >> i) & 1ull)) {
+            if (pair) {
+                asm volatile("" ::: "memory");
+                const drt_f2 nx = {rec[0], rec[1]}, ny = {rec[2], rec[3]}, nz = {rec[4], rec[5]}, off = {rec[6], rec[7]};
+                drt_f2 h = ox * nx;
+                h = __builtin_elementwise_fma(oy, ny, h);
+                h = __builtin_elementwise_fma(oz, nz, h);
+                h = h - off;
+                drt_f2 den = dx * nx;
+                den = __builtin_elementwise_fma(dy, ny, den);
+                den = __builtin_elementwise_fma(dz, nz, den);
+                hit_accept(h.x * __builtin_amdgcn_rcpf(-den.x), s, tmin, prim);       // shape.hpp:49-59
+                hit_accept(h.y * __builtin_amdgcn_rcpf(-den.y), s + 1, tmin, prim);
+            } else {
+                asm volatile("" ::: "memory");
+                const V3<float> n = mk<float>(rec[0], rec[1], rec[2]);
+                hit_accept(div_r(dot(o, n) - rec[3], -dot(d, n)), s, tmin, prim);
+            }
+            s += pair ? 2 : 1;
+        } else {
+            if (pair) {
+                asm volatile("" ::: "memory");
+                const drt_f2 cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]}, rr = {rec[6], rec[7]};
+                const drt_f2 ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+                drt_f2 bd = ocx * dx;                                         // shape.hpp:78-103, two spheres
+                bd = __builtin_elementwise_fma(ocy, dy, bd);
+                bd = __builtin_elementwise_fma(ocz, dz, bd);
+                drt_f2 cc = ocx * ocx;
+                cc = __builtin_elementwise_fma(ocy, ocy, cc);
+                cc = __builtin_elementwise_fma(ocz, ocz, cc);
+                cc = cc - rr * rr;
+                const drt_f2 b = bd * drt_f2{2.f, 2.f};
+                const drt_f2 disc = __builtin_elementwise_fma(b, b, cc * drt_f2{-4.f, -4.f});
+                const drt_f2 sq = {sqrt_r(disc.x > 0.f ? disc.x : 0.f), sqrt_r(disc.y > 0.f ? disc.y : 0.f)};
+                const drt_f2 t1 = (-b - sq) * drt_f2{0.5f, 0.5f}, t2 = (sq - b) * drt_f2{0.5f, 0.5f};
+                const float ta = t1.x > 0.f ? t1.x : t2.x, tb = t1.y > 0.f ? t1.y : t2.y;
+                if (disc.x >= 0.f) hit_accept(ta, s, tmin, prim);
+                if (disc.y >= 0.f) hit_accept(tb, s + 1, tmin, prim);
+            } else {
+                asm volatile("" ::: "memory");
+                DevShape<float> sh;
+                sh.p[0] = rec[0]; sh.p[1] = rec[1]; sh.p[2] = rec[2]; sh.p[3] = rec[3];
+                sh.type = DRT_SHAPE_SPHERE;
+                float t;
+                if (shape_intersect(sh, o, d, t))
+                    hit_accept(t, s, tmin, prim);
+            }
+            s += pair ? 2 : 1;
+        }
+    }
+    HitRec<float> h;
+    h.t = tmin;
+    h.prim = prim;
+    return h;
+}
+
+__device__ inline HitRec<double> closest_hit_packed(const DevScene<double>* __restrict__ sc, double4 ra, double2 rb)
+{
+    const double4 ra1[1] = {ra};
+    const double2 rb1[1] = {rb};
+    HitRec<double> h1[1];
+    closest_hit_n<double, 1>(sc, sc->n_shapes, ra1, rb1, h1);      // the f64 verification mode keeps the literal loop
+    return h1[0];
+}
+
 // slot of this lane in chunk c, or 0xFFFFFFFF when the lane has no live ray there
 __device__ inline uint32_t chunk_slot(const BatchArgs& a, const uint32_t* __restrict__ counts_k,
                                       uint32_t c, uint32_t n_chunks, uint32_t lane)
@@ -679,7 +773,6 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
     const size_t N = a.n_paths;
-    const int n_shapes_u = sc->n_shapes;          // wave-uniform: a scalar load, not the LDS copy
     uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
     uint32_t cnt;
@@ -719,11 +812,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
             if (live) {
                 HitRec<R> h;
                 if (FUSED) {
-                    const R4 ra1[1] = {ra};
-                    const R2 rb1[1] = {rb};
-                    HitRec<R> h1[1];
-                    closest_hit_n<R, 1>(sc, n_shapes_u, ra1, rb1, h1);
-                    h = h1[0];
+                    h = closest_hit_packed(sc, ra, rb);
                 } else {
                     h = cur.h;
                 }
@@ -943,7 +1032,6 @@ struct GradAcc {
 // f32, parameters in registers: one-hot weights and packed FMAs (v_pk_fma_f32) -- xy of every
 // parameter as one pair, the z components of two parameters as another: 14 VALU per add for NP = 4
 // instead of a compare + three selects + three adds per parameter.
-typedef float drt_f2 __attribute__((ext_vector_type(2)));
 template <int NP>
 struct GradAccF32 {
     static_assert(NP % 2 == 0, "z components are paired");
