@@ -225,12 +225,11 @@ def main():
             tsh = {}
         if tsh.get("valu_insts_per_launch"):
             ginst = tsh["valu_insts_per_launch"] / (shade["ms_per_step"] / shade["launches_per_step"] * 1e-3) * 1e-9
-            roofline["valu"] = {"busy_frac": tsh.get("valu_busy_frac"),
-                                "busy_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x profiled launch time x 2.4 GHz): ~1 = the vector "
-                                             "pipes are saturated (profiles/traffic.json)",
-                                "issued": round(ginst, 1), "unit": "G wave-instr/s",
-                                "issue_peak_2_cycles_per_instr": VALU_PEAK_GINST,
-                                "note": "SQ_INSTS_VALU per launch (profiles/traffic.json) / live launch time"}
+            roofline["valu"] = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                                "frac": round(ginst / VALU_PEAK_GINST, 4),
+                                "note": "SQ_INSTS_VALU per launch (profiles/traffic.json, rocprofv3 --pmc) / live launch time; peak = one "
+                                        "VALU op per 2 cycles per SIMD (two interleaved waves); the CU's one scalar unit is about as busy "
+                                        "(DESIGN.md section 3)"}
     if multi_bounce and not a.no_streaming_view:
         import dataclasses
         rp1 = dataclasses.replace(rp, bounces_per_launch=1)

@@ -89,9 +89,8 @@ for k, t in traffic.items():
                         "bytes_per_launch": round(t["total_corrected_B"]), "fetch_raw_bytes": round(t["fetch_raw_B"]),
                         "write_bytes": round(t["write_B"]), "avg_launch_us": round(us, 2),
                         "valu_insts_per_launch": round(summary[k].get("SQ_INSTS_VALU", 0.0)),
-                        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md): the share
-                        # of the launch during which a SIMD's vector pipe was executing, at the 2.4 GHz peak clock (uncapped: ~1 =
-                        # saturated; the real clock under load is lower and in-flight instructions of two waves overlap)
-                        "valu_busy_frac": round(summary[k].get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (256 * 4 * us * 1e-6 * 2.4e9), 4),
+                        # SQ_ACTIVE_INST_VALU counts quad-cycles per WAVE (a wave issues a VALU op every 4 cycles, two waves
+                        # interleave on a SIMD at one per 2): wave-activity / (SIMDs x time) -- 2.0 would be a saturated pipe
+                        "valu_wave_activity": round(summary[k].get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (256 * 4 * us * 1e-6 * 2.4e9), 4),
                         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)"}
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
