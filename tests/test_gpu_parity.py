@@ -8,6 +8,8 @@ Stated tolerances (north star: fp32 forward tolerance, gradients within 1e-4 rel
     per pixel |d| <= 2e-4 * max(image) except for an outlier budget of 0.5 % of the pixels
     (a discrete hit/miss decision flipped by fp32 rounding changes one of the spp samples).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -442,6 +444,7 @@ def test_results_do_not_depend_on_bounces_per_launch(pkg, hip, scene_name, b, p,
         np.testing.assert_array_equal(got[0], ref[0])
         np.testing.assert_array_equal(got[1], ref[1])
         assert got[2]["segments"] == ref[2]["segments"]
-        if nb == 8 and not unbiased:
+        overridden = os.environ.get("DRT_HIP_SHADE_BOUNCES") or os.environ.get("DRT_HIP_FUSE") == "0"   # debug knobs win
+        if nb == 8 and not unbiased and not overridden:
             assert got[2]["kernels"]["shade"]["launches"] < ref[2]["kernels"]["shade"]["launches"]
             assert got[2]["queue_rays_read"] < ref[2]["queue_rays_read"]
