@@ -630,11 +630,11 @@ __device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, b
 }
 
 // what was hit: position, normal (as the reference's Shape::normal returns it), material, emitter
-template <typename R>
+template <typename R, bool MESHES = true>
 __device__ inline void resolve_hit(const SceneLds<R>& lds, const typename Q4<R>::T* __restrict__ tri_shade,
                                    int prim, V3<R> P, V3<R>& nrm, int& material, int& emitter)
 {
-    if (prim < lds.sc.n_shapes) {
+    if (!MESHES || prim < lds.sc.n_shapes) {
         const DevShape<R>& sh = lds.sc.shapes[prim];
         nrm = shape_normal(sh, P);
         material = sh.material;
@@ -822,30 +822,27 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                     save_b[pid] = rb;
                     save_hit[pid] = h;
                 }
-                if (h.prim < 0) {
-                    nv[pid] = (uint32_t)kk;                       // miss: pathtracer.hpp:135
-                } else {
+                // what this vertex writes: at most one tape record and, when the path ends here, its length
+                TapeRec<R> tr;
+                bool write_tape = false, ended = true;
+                uint32_t n_vertices = (uint32_t)kk;                // miss: pathtracer.hpp:135
+                if (h.prim >= 0) {
                     const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
                     const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
                     const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
                     V3<R> nrm;
                     int material, emitter;
-                    resolve_hit(lds, tri_shade, h.prim, P, nrm, material, emitter);
+                    resolve_hit<R, !FUSED>(lds, tri_shade, h.prim, P, nrm, material, emitter);
                     // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
-                    uint32_t eid = DRT_ID_NONE, cid = DRT_ID_NONE;
-                    if (emitter >= 0)
-                        eid = (uint32_t)lds.sc.emitter_param[emitter];
-                    if (material < 0) {
-                        // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
-                        // continuation contributes exactly 0, the path ends here
-                        TapeRec<R> tr;
-                        tr.m = R(0);
-                        tr.ids = DRT_ID_NONE | (eid << 16);
-                        tape_kk[pid] = tr;
-                        nv[pid] = (uint32_t)kk + 1u;
-                    } else {
+                    const uint32_t eid = emitter >= 0 ? (uint32_t)lds.sc.emitter_param[emitter] : DRT_ID_NONE;
+                    write_tape = true;
+                    n_vertices = (uint32_t)kk + 1u;
+                    // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
+                    // continuation contributes exactly 0, the path ends here
+                    tr.m = R(0);
+                    tr.ids = DRT_ID_NONE | (eid << 16);
+                    if (material >= 0) {
                         const DevMaterial<R>& m = lds.sc.materials[material];
-                        cid = (uint32_t)m.param;
                         const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
                         V3<R> wo;
                         R q, bs;
@@ -863,16 +860,18 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                         alive = !next_cap;
                         if (alive && next_rr)
                             alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                        TapeRec<R> tr;
                         tr.m = mk_;
-                        tr.ids = cid | (eid << 16);
-                        tape_kk[pid] = tr;
-                        if (!alive) nv[pid] = (uint32_t)kk + 1u;
+                        tr.ids = (uint32_t)m.param | (eid << 16);
+                        ended = !alive;
                         const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
                         na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
                         nb2.x = wo.y; nb2.y = wo.z;
                     }
                 }
+                if (write_tape)
+                    tape_kk[pid] = tr;
+                if (ended)
+                    nv[pid] = n_vertices;
             }
             if (it + 1 >= nb)
                 break;
