@@ -254,6 +254,8 @@ def main():
         ms1 /= n_prof
         bpu1 = 8.0 + 32.0 * q1 / max(1, segments)
         gbs1 = segments * bpu1 / (ms1 * 1e-3) * 1e-9 if ms1 > 0 else 0.0
+        roofline["traversal_kernel"]["one_launch_per_bounce"] = {"ms_per_step": round(ms1, 4), "achieved_GBs": round(gbs1, 1),
+                                                                 "frac_hbm_peak": round(gbs1 / HBM_PEAK_GBS, 4)}
         roofline["streaming"] = {"bounces_per_launch": 1, "value": round(segments / dt4 * 1e-6, 2), "unit": "Mray/s",
                                  "ms_per_step": round(dt4 * 1e3, 4), "kernel": "k_shade", "bytes_per_unit": round(bpu1, 3),
                                  "achieved": round(gbs1, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs1 / HBM_PEAK_GBS, 4)}
