@@ -472,19 +472,26 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             const int g = (int)((a.n_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
             const int gp = grid_for(ctx, a.n_paths);   // per-path kernels (K6): persistent grid
 
-            if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
-            hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
-                               rid[0], nv, counts);
-            if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
-            st->launches[DRT_K_RAYGEN]++;
-            st->units[DRT_K_RAYGEN] += a.n_paths;
+            // K1 folded into the first shade launch when it is a fused one and every path is alive at depth 0
+            static const bool cam_env = !(getenv("DRT_HIP_FUSE_CAMERA") && atoi(getenv("DRT_HIP_FUSE_CAMERA")) == 0);
+            // (only when that launch carries its rays through several bounces: with one launch per bounce the
+            // depth-0 launch is the largest, and the camera's f64 math no longer hides behind K1's own writes)
+            const bool camera_fused = cam_env && can_fuse && D > 0 && a.min_bounces > 0 && bounces_from(0) > 1;
+            if (!camera_fused) {
+                if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
+                                   rid[0], nv, counts);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_RAYGEN]++;
+                st->units[DRT_K_RAYGEN] += a.n_paths;
+            }
 
             // fused launches take every ray through shade_nb bounces in registers (1, 2, 4 or 8)
             unsigned long long read_rows = 0, written_rows = 0;   // queue rows shade launches start from / end on
             for (int k = 0, lc = 0, nbk = 1, next_poll = DRT_POLL_EVERY; k < D; k += nbk, ++lc) {
                 const int cur = lc & 1, nxt = cur ^ 1;
                 nbk = bounces_from(k);
-                read_rows |= 1ull << k;
+                if (!(camera_fused && k == 0)) read_rows |= 1ull << k;      // the camera launch generates its rays
                 if (k + nbk < D) written_rows |= 1ull << (k + nbk);
                 if (D > 2 * DRT_POLL_EVERY && k >= next_poll) {
                     next_poll = k + DRT_POLL_EVERY;
@@ -526,7 +533,18 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk, d_scene, \
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,      \
                        ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
-                    if (fused) {
+                    if (fused && camera_fused && k == 0) {
+                        if (ctx->has_specular)
+                            hipLaunchKernelGGL((k_shade<R, true, true, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,
+                                               d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt],
+                                               tape_k, nv, ck, (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr,
+                                               sv_a, sv_b, sv_hit);
+                        else
+                            hipLaunchKernelGGL((k_shade<R, false, true, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,
+                                               d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt],
+                                               tape_k, nv, ck, (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr,
+                                               sv_a, sv_b, sv_hit);
+                    } else if (fused) {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, true, 0, (const uint32_t*)nullptr);
                     } else {

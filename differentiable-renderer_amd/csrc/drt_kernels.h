@@ -106,6 +106,33 @@ __device__ inline uint32_t draw_offset(int k, int s, int min_bounces)
 }
 __device__ inline uint32_t camera_draw_base(int min_bounces) { return 2u + (min_bounces <= 0 ? 1u : 0u); }
 
+// Camera ray of batch-local path i (camera.hpp:51-60, in double like the reference: the pixel
+// jitter decides which surface a path starts on) and the RNG key of its path.
+template <typename R>
+__device__ inline void camera_ray(const BatchArgs& a, uint32_t i, typename Q4<R>::T& ra, typename Q2<R>::T& rb,
+                                  uint32_t& key)
+{
+    const uint32_t sl = i / a.Pb, pl = i - sl * a.Pb;
+    const uint32_t gpix = global_pixel(a, a.p0 + pl);
+    const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
+    key = drt_rng_path_key(a.seed, path);
+    const uint32_t y = gpix / (uint32_t)a.W, x = gpix - y * (uint32_t)a.W;
+    // camera.hpp:53-58
+    const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
+    const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
+    const double s = ((double)x + u1) / (double)a.W;
+    const double t = ((double)y + u2) / (double)a.H;
+    const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
+    const double ct = (2. * t - 1.) * a.tan_half;
+    double dx = a.fwd[0] + cs * a.right[0] - ct * a.up[0];
+    double dy = a.fwd[1] + cs * a.right[1] - ct * a.up[1];
+    double dz = a.fwd[2] + cs * a.right[2] - ct * a.up[2];
+    const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dx;
+    rb.x = (R)dy; rb.y = (R)dz;
+}
+
 // ---- K1 ---------------------------------------------------------------------------------------
 // One wave per queue region: generates the camera rays of its region's paths and compacts the
 // ones that survive the depth-0 roulette to the front of the region.
@@ -129,30 +156,13 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* 
         typename Q2<R>::T rb;
         uint2 rid;
         if (alive) {
-            const uint32_t sl = i / a.Pb, pl = i - sl * a.Pb;
-            const uint32_t gpix = global_pixel(a, a.p0 + pl);
-            const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
-            const uint32_t key = drt_rng_path_key(a.seed, path);
-            const uint32_t y = gpix / (uint32_t)a.W, x = gpix - y * (uint32_t)a.W;
-            // camera.hpp:53-58
-            const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
-            const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
-            const double s = ((double)x + u1) / (double)a.W;
-            const double t = ((double)y + u2) / (double)a.H;
-            const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
-            const double ct = (2. * t - 1.) * a.tan_half;
-            double dx = a.fwd[0] + cs * a.right[0] - ct * a.up[0];
-            double dy = a.fwd[1] + cs * a.right[1] - ct * a.up[1];
-            double dz = a.fwd[2] + cs * a.right[2] - ct * a.up[2];
-            const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
-            dx *= inv; dy *= inv; dz *= inv;
+            uint32_t key;
+            camera_ray<R>(a, i, ra, rb, key);
             // pathtracer.hpp:128 at depth 0
             if (a.depth_cap <= 0)
                 alive = false;
             else if (a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold)
                 alive = false;
-            ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dx;
-            rb.x = (R)dy; rb.y = (R)dz;
             rid.x = i; rid.y = key;
             if (!alive)
                 nv[i] = 0;
@@ -739,6 +749,18 @@ __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_
     return w;
 }
 
+// next region >= w this wave shades; CAM: depth 0, region w holds its share of the batch's paths
+template <bool CAM>
+__device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __restrict__ counts_k, uint32_t w,
+                                       uint32_t n_waves, uint32_t& cnt)
+{
+    if (!CAM)
+        return next_live_region(counts_k, w, n_waves, a.n_regions, cnt);
+    const uint32_t begin = w << a.region_shift;
+    cnt = w < a.n_regions ? (a.n_paths - begin < a.region_size ? a.n_paths - begin : a.region_size) : 0u;
+    return w;
+}
+
 // Persistent blocks; every wave walks the regions w, w + n_waves, ... it owns in this launch and
 // shades them chunk by chunk.  The loads of the NEXT chunk (same region or the next live one) are
 // issued before the current chunk is shaded, so a wave always has one chunk of loads in flight.
@@ -746,7 +768,9 @@ __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_
 // FUSED = true: the closest hit over the analytic shapes is computed HERE from the ray just loaded
 // (K2 folded into K3): no hit lane, no second read of the ray -- 72 instead of 120 bytes per
 // segment.  Used whenever nothing else needs the hit records (no mesh, no unbiased chain vertices).
-template <typename R, bool SPEC, bool FUSED>
+// CAM (fused launches that start at depth 0, every path alive there): the camera ray is generated in
+// place -- K1 folded in too: nothing is read from the queue, the row of depth 0 is written here.
+template <typename R, bool SPEC, bool FUSED, bool CAM = false>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
@@ -777,24 +801,31 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
     uint32_t cnt;
-    uint32_t w = next_live_region(counts_k, grid_wave(), n_waves, a.n_regions, cnt);
+    uint32_t w = next_region<CAM>(a, counts_k, grid_wave(), n_waves, cnt);
     if (w >= a.n_regions)
         return;
     uint32_t off = 0, running = 0;
     ShadeIn<R> cur, nxt;
     bool have = lane < cnt;
-    load_shade_in(cur, (w << a.region_shift) + lane, have, !FUSED, ray_a, ray_b, ray_id, hit);
+    if (!CAM)
+        load_shade_in(cur, (w << a.region_shift) + lane, have, !FUSED, ray_a, ray_b, ray_id, hit);
 
     for (;;) {
         // where the next chunk is, and its loads
         uint32_t nw = w, noff = off + DRT_WAVE, ncnt = cnt;
         if (noff >= cnt) {
             noff = 0;
-            nw = next_live_region(counts_k, w + n_waves, n_waves, a.n_regions, ncnt);
+            nw = next_region<CAM>(a, counts_k, w + n_waves, n_waves, ncnt);
         }
         const bool more = nw < a.n_regions;
         const bool nhave = more && noff + lane < ncnt;
-        load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
+        if (!CAM)
+            load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
+        if (CAM && have) {
+            const uint32_t i = (w << a.region_shift) + off + lane;      // all alive at depth 0: slot == path
+            cur.rid.x = i;
+            camera_ray<R>(a, i, cur.ra, cur.rb, cur.rid.y);
+        }
 
         bool alive = false, live = have;
         R4 ra = cur.ra, na;
@@ -894,8 +925,11 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         }
         running += n_alive;
         if (nw != w) {                                         // region finished
-            if (lane == 0)
+            if (lane == 0) {
                 counts_next[w] = running;
+                if (CAM)
+                    counts_k[w] = cnt;                         // depth 0: every path of the region
+            }
             running = 0;
         }
         if (!more)
