@@ -64,6 +64,10 @@ def main():
     ap.add_argument("--no-streaming-view", action="store_true",
                     help="skip the extra one-launch-per-bounce measurement (profiling runs: keeps kernel statistics unmixed)")
     ap.add_argument("--bounces-per-launch", type=int, default=0, help="0 = automatic (drt_hip.h)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, the real thing) | gloo: lets two ranks share ONE GPU to exercise the N > 1 path "
+                         "on a single-GPU box (with --same-gpu); the numbers of such a run mean nothing")
+    ap.add_argument("--same-gpu", action="store_true", help="every rank uses device 0 (testing only)")
     ap.add_argument("--cpu-spp", type=int, default=16)
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the oracle on every host core (independent row-band processes)")
@@ -80,10 +84,15 @@ def main():
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     # launched by torch.distributed.run (also with one rank: exercises the RCCL path on one GPU)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if a.same_gpu:
+        local_rank = 0
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.dist_backend)
 
     pkg = entry.load_package()
     scene = pkg.scene_by_name(a.scene)
