@@ -183,7 +183,11 @@ def main():
     units = {"intersect": segments, "shade": segments, "backward": segments,
              "raygen": paths, "film": paths, "gradreduce": 0}
     bpu = {"intersect": BYTES_PER_UNIT["intersect"],
-           "shade": BYTES_PER_UNIT["shade"] if kernel_launches["intersect"] else 8.0 + 32.0 * queue_rays / max(1, segments),
+           # fused shade: tape 8 B/segment + queued rays; when it also walks the tape in place (forward-only, one launch
+           # from the eye to the path's end: no K6 / k_radiance launch) the tape stays in LDS and 16 B of radiance
+           # per path is all it writes
+           "shade": BYTES_PER_UNIT["shade"] if kernel_launches["intersect"] else
+                    (8.0 if kernel_launches["backward"] else 16.0 * paths / max(1, segments)) + 32.0 * queue_rays / max(1, segments),
            "backward": BYTES_PER_UNIT["backward"], "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
     per_kernel = {}
     for k in pkg.KERNEL_NAMES:

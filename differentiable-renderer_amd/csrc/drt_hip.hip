@@ -385,8 +385,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if ((rc = ensure(ctx, ctx->segtotal, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written
     HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const int bwd_grid = grid_for(ctx, N);
-    if (backward)
-        if ((rc = ensure(ctx, ctx->gpart, (size_t)bwd_grid * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
+    if (backward) {   // per-block partial sums: K6's persistent grid, or the shade kernel's one block per 4 regions
+        const size_t shade_blocks = (max_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE);
+        const size_t blocks = shade_blocks > (size_t)bwd_grid ? shade_blocks : (size_t)bwd_grid;
+        if ((rc = ensure(ctx, ctx->gpart, blocks * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
+    }
 
     BatchArgs a;
     memset(&a, 0, sizeof a);
@@ -487,6 +490,21 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             }
 
             // fused launches take every ray through shade_nb bounces in registers (1, 2, 4 or 8)
+            // The tape walk in place: the first launch takes every path from the eye to its end (depth cap <= one
+            // tape chunk), so each lane walks its own path's records out of LDS -- no tape, no K6 / k_radiance.
+            // Forward-only renders do (their walk is light: 1.70 -> 1.54 ms on config 2).  The gradient walk in place
+            // works too but needs 168 VGPRs (3 waves per SIMD instead of 5) and loses to the separate K6
+            // (1.97 vs 1.71 ms): DRT_HIP_INLINE_WALK=2 opts in, =0 switches both off.
+            static const int walk_env = getenv("DRT_HIP_INLINE_WALK") ? atoi(getenv("DRT_HIP_INLINE_WALK")) : 1;
+            int walk = DRT_WALK_NONE;
+            if (walk_env > 0 && camera_fused && bounces_from(0) == D && D <= DRT_TAPE_CHUNK && !unbiased && gimg_param < 0 &&
+                !getenv("DRT_HIP_DUMP_PATH")) {
+                if (backward && ctx->n_params <= 4 && walk_env >= 2)
+                    walk = DRT_WALK_GRADIENTS;
+                else if (!backward && film)
+                    walk = DRT_WALK_RADIANCE;
+            }
+            int walk_blocks = 0;
             unsigned long long read_rows = 0, written_rows = 0;   // queue rows shade launches start from / end on
             for (int k = 0, lc = 0, nbk = 1, next_poll = DRT_POLL_EVERY; k < D; k += nbk, ++lc) {
                 const int cur = lc & 1, nxt = cur ^ 1;
@@ -534,16 +552,23 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,      \
                        ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
                     if (fused && camera_fused && k == 0) {
-                        if (ctx->has_specular)
-                            hipLaunchKernelGGL((k_shade<R, true, true, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,
-                                               d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt],
-                                               tape_k, nv, ck, (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr,
-                                               sv_a, sv_b, sv_hit);
-                        else
-                            hipLaunchKernelGGL((k_shade<R, false, true, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,
-                                               d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt],
-                                               tape_k, nv, ck, (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr,
-                                               sv_a, sv_b, sv_hit);
+#define DRT_LAUNCH_CAMERA(SPEC, WALK)                                                                                    \
+    hipLaunchKernelGGL((k_shade<R, SPEC, true, true, WALK>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,        \
+                       d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, ck,    \
+                       (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit, d_adjoint, \
+                       gpart, film ? lacc : (R4*)nullptr)
+                        walk_blocks = gs;
+                        if (walk == DRT_WALK_GRADIENTS) {
+                            if (ctx->has_specular) DRT_LAUNCH_CAMERA(true, DRT_WALK_GRADIENTS);
+                            else DRT_LAUNCH_CAMERA(false, DRT_WALK_GRADIENTS);
+                        } else if (walk == DRT_WALK_RADIANCE) {
+                            if (ctx->has_specular) DRT_LAUNCH_CAMERA(true, DRT_WALK_RADIANCE);
+                            else DRT_LAUNCH_CAMERA(false, DRT_WALK_RADIANCE);
+                        } else {
+                            if (ctx->has_specular) DRT_LAUNCH_CAMERA(true, DRT_WALK_NONE);
+                            else DRT_LAUNCH_CAMERA(false, DRT_WALK_NONE);
+                        }
+#undef DRT_LAUNCH_CAMERA
                     } else if (fused) {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, true, 0, (const uint32_t*)nullptr);
@@ -657,6 +682,14 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (chains_done)
                         break;
                 }
+            } else if (backward && D > 0 && walk == DRT_WALK_GRADIENTS) {
+                // the shade launch has walked every tape in place: only its per-block partial sums are left
+                if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
+                hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart,
+                                   walk_blocks, n_fast, grad);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_GRADREDUCE]++;
+                st->units[DRT_K_GRADREDUCE] += (uint64_t)walk_blocks;
             } else if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
 #define DRT_LAUNCH_BWD(NP)                                                                              \
@@ -675,7 +708,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->launches[DRT_K_GRADREDUCE]++;
                 st->units[DRT_K_GRADREDUCE] += (uint64_t)gp;
             }
-            else if (D > 0 && film) {
+            else if (D > 0 && film && walk != DRT_WALK_RADIANCE) {
                 // forward only: radiance of every path from its tape
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                 hipLaunchKernelGGL(k_radiance<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params,

@@ -749,267 +749,6 @@ __device__ inline uint32_t next_live_region(const uint32_t* __restrict__ counts_
     return w;
 }
 
-// next region >= w this wave shades; CAM: depth 0, region w holds its share of the batch's paths
-template <bool CAM>
-__device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __restrict__ counts_k, uint32_t w,
-                                       uint32_t n_waves, uint32_t& cnt)
-{
-    if (!CAM)
-        return next_live_region(counts_k, w, n_waves, a.n_regions, cnt);
-    const uint32_t begin = w << a.region_shift;
-    cnt = w < a.n_regions ? (a.n_paths - begin < a.region_size ? a.n_paths - begin : a.region_size) : 0u;
-    return w;
-}
-
-// Persistent blocks; every wave walks the regions w, w + n_waves, ... it owns in this launch and
-// shades them chunk by chunk.  The loads of the NEXT chunk (same region or the next live one) are
-// issued before the current chunk is shaded, so a wave always has one chunk of loads in flight.
-// SPEC = false instantiations carry no specular code (and fewer registers) for all-diffuse scenes.
-// FUSED = true: the closest hit over the analytic shapes is computed HERE from the ray just loaded
-// (K2 folded into K3): no hit lane, no second read of the ray -- 72 instead of 120 bytes per
-// segment.  Used whenever nothing else needs the hit records (no mesh, no unbiased chain vertices).
-// CAM (fused launches that start at depth 0, every path alive there): the camera ray is generated in
-// place -- K1 folded in too: nothing is read from the queue, the row of depth 0 is written here.
-template <typename R, bool SPEC, bool FUSED, bool CAM = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
-k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
-        const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
-        const uint2* __restrict__ ray_id, const HitRec<R>* __restrict__ hit,
-        typename Q4<R>::T* __restrict__ next_a, typename Q2<R>::T* __restrict__ next_b,
-        uint2* __restrict__ next_id,
-        TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
-        uint32_t* __restrict__ counts_k, uint32_t count_stride,
-        const typename Q4<R>::T* __restrict__ tri_shade,
-        int seg_start, const uint32_t* __restrict__ draw_base,
-        typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
-        HitRec<R>* __restrict__ save_hit)
-{
-    // nb > 1 (FUSED only): the launch takes every ray through nb bounces -- depths k .. k+nb-1 -- in
-    // registers; only the survivors of the LAST one are compacted and written back.  Lanes whose
-    // path ended in between idle (a few per cent per bounce), in exchange the 64 bytes of queue
-    // traffic per ray are paid once per nb segments.  counts_k + j * count_stride is the row of
-    // depth k + j: the rows in between are kept up to date with one non-returning atomic per chunk
-    // (a region is owned by one wave), the row of depth k + nb is written like before.
-    typedef typename Q4<R>::T R4;
-    typedef typename Q2<R>::T R2;
-    __shared__ SceneLds<R> lds;
-    stage_scene(lds, sc, params);
-
-    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
-    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const size_t N = a.n_paths;
-    uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
-
-    uint32_t cnt;
-    uint32_t w = next_region<CAM>(a, counts_k, grid_wave(), n_waves, cnt);
-    if (w >= a.n_regions)
-        return;
-    uint32_t off = 0, running = 0;
-    ShadeIn<R> cur, nxt;
-    bool have = lane < cnt;
-    if (!CAM)
-        load_shade_in(cur, (w << a.region_shift) + lane, have, !FUSED, ray_a, ray_b, ray_id, hit);
-
-    for (;;) {
-        // where the next chunk is, and its loads
-        uint32_t nw = w, noff = off + DRT_WAVE, ncnt = cnt;
-        if (noff >= cnt) {
-            noff = 0;
-            nw = next_region<CAM>(a, counts_k, w + n_waves, n_waves, ncnt);
-        }
-        const bool more = nw < a.n_regions;
-        const bool nhave = more && noff + lane < ncnt;
-        if (!CAM)
-            load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
-        if (CAM && have) {
-            const uint32_t i = (w << a.region_shift) + off + lane;      // all alive at depth 0: slot == path
-            cur.rid.x = i;
-            camera_ray<R>(a, i, cur.ra, cur.rb, cur.rid.y);
-        }
-
-        bool alive = false, live = have;
-        R4 ra = cur.ra, na;
-        R2 rb = cur.rb, nb2;
-        const uint32_t pid = cur.rid.x, key = cur.rid.y;
-        for (int it = 0;; ++it) {
-            const int kk = k + it;
-            const R pk = kk >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
-            // camera paths start at depth 0 with a closed-form base; re-sampled suffixes (unbiased
-            // backward) start at seg_start with a per-path base
-            const uint32_t n_off = draw_offset(kk, seg_start, a.min_bounces) + (draw_base ? 0u : camera_draw_base(a.min_bounces));
-            const bool next_rr = (kk + 1) >= a.min_bounces;
-            const bool next_cap = (kk + 1) >= a.depth_cap;
-            TapeRec<R>* __restrict__ tape_kk = tape_k + (size_t)it * N;
-            alive = false;
-            if (live) {
-                HitRec<R> h;
-                if (FUSED) {
-                    h = closest_hit_packed(sc, ra, rb);
-                } else {
-                    h = cur.h;
-                }
-                if (save_a && it == 0) {   // unbiased backward: this ray and its hit are the path's next chain vertex
-                    save_a[pid] = ra;
-                    save_b[pid] = rb;
-                    save_hit[pid] = h;
-                }
-                // what this vertex writes: at most one tape record and, when the path ends here, its length
-                TapeRec<R> tr;
-                bool write_tape = false, ended = true;
-                uint32_t n_vertices = (uint32_t)kk;                // miss: pathtracer.hpp:135
-                if (h.prim >= 0) {
-                    const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
-                    const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
-                    const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
-                    V3<R> nrm;
-                    int material, emitter;
-                    resolve_hit<R, !FUSED>(lds, tri_shade, h.prim, P, nrm, material, emitter);
-                    // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
-                    const uint32_t eid = emitter >= 0 ? (uint32_t)lds.sc.emitter_param[emitter] : DRT_ID_NONE;
-                    write_tape = true;
-                    n_vertices = (uint32_t)kk + 1u;
-                    // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
-                    // continuation contributes exactly 0, the path ends here
-                    tr.m = R(0);
-                    tr.ids = DRT_ID_NONE | (eid << 16);
-                    if (material >= 0) {
-                        const DevMaterial<R>& m = lds.sc.materials[material];
-                        const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
-                        V3<R> wo;
-                        R q, bs;
-                        sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
-                        const R c = dot(nrm, wo);                  // pathtracer.hpp:103
-                        const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
-#ifdef DRT_DEBUG_NAN
-                        if (!(mk_ == mk_) || mk_ > R(1e30) || mk_ < R(-1e30))
-                            printf("[k_shade] pid %u k %d type %d: bs %g c %g q %g pk %g | nrm %g %g %g | d %g %g %g | wo %g %g %g | t %g prim %d\n",
-                                   pid, kk, m.type, (double)bs, (double)c, (double)q, (double)pk, (double)nrm.x, (double)nrm.y,
-                                   (double)nrm.z, (double)d.x, (double)d.y, (double)d.z, (double)wo.x, (double)wo.y, (double)wo.z,
-                                   (double)h.t, h.prim);
-#endif
-                        // roulette / cap of depth kk+1, decided here so dead rays are never queued
-                        alive = !next_cap;
-                        if (alive && next_rr)
-                            alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                        tr.m = mk_;
-                        tr.ids = (uint32_t)m.param | (eid << 16);
-                        ended = !alive;
-                        const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
-                        na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
-                        nb2.x = wo.y; nb2.y = wo.z;
-                    }
-                }
-                if (write_tape)
-                    tape_kk[pid] = tr;
-                if (ended)
-                    nv[pid] = n_vertices;
-            }
-            if (it + 1 >= nb)
-                break;
-            // survivors go straight into the next bounce; the row of the depth in between only counts them
-            const uint32_t n_mid = (uint32_t)__popcll(__ballot(alive));
-            if (n_mid == 0)
-                break;                                             // (alive is false in every lane)
-            if (lane == 0)
-                atomicAdd(counts_k + (size_t)(it + 1) * count_stride + w, n_mid);
-            ra = na;
-            rb = nb2;
-            live = alive;
-        }
-        uint32_t n_alive;
-        const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
-        if (alive) {
-            next_a[ns] = na;
-            next_b[ns] = nb2;
-            next_id[ns] = cur.rid;
-        }
-        running += n_alive;
-        if (nw != w) {                                         // region finished
-            if (lane == 0) {
-                counts_next[w] = running;
-                if (CAM)
-                    counts_k[w] = cnt;                         // depth 0: every path of the region
-            }
-            running = 0;
-        }
-        if (!more)
-            break;
-        cur = nxt;
-        have = nhave;
-        w = nw;
-        off = noff;
-        cnt = ncnt;
-    }
-}
-
-// segments of one batch = rays queued at depths 0..D-1, summed over regions -> 64-bit total
-__global__ void __launch_bounds__(DRT_BLOCK)
-k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total,
-             uint32_t row_words, unsigned long long read_rows, unsigned long long written_rows)
-{
-    // total[0] += all words (= segments); total[1] += the rows a shade launch STARTED from (rays read from
-    // the queue), total[2] += the rows a launch ended on (survivors written back); row r = bit r of the masks
-    __shared__ unsigned long long red[3][DRT_BLOCK / DRT_WAVE];
-    unsigned long long v = 0, vr = 0, vw = 0;
-    for (uint32_t i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n_words; i += gridDim.x * DRT_BLOCK) {
-        const unsigned long long c = counts[i];
-        const uint32_t row = row_words ? i / row_words : 0u;
-        v += c;
-        if (row < 64u && ((read_rows >> row) & 1ull)) vr += c;
-        if (row < 64u && ((written_rows >> row) & 1ull)) vw += c;
-    }
-    for (int off = DRT_WAVE / 2; off > 0; off >>= 1) {
-        v += __shfl_down(v, off);
-        vr += __shfl_down(vr, off);
-        vw += __shfl_down(vw, off);
-    }
-    if ((threadIdx.x & (DRT_WAVE - 1)) == 0) {
-        red[0][threadIdx.x / DRT_WAVE] = v;
-        red[1][threadIdx.x / DRT_WAVE] = vr;
-        red[2][threadIdx.x / DRT_WAVE] = vw;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        unsigned long long t = 0;
-        for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
-            t += red[threadIdx.x][w];
-        if (t)
-            atomicAdd(total + threadIdx.x, t);   // integer: order-independent
-    }
-}
-
-// ---- K5 ---------------------------------------------------------------------------------------
-template <typename R>
-__global__ void __launch_bounds__(DRT_BLOCK)
-k_film(BatchArgs a, const typename Q4<R>::T* __restrict__ lacc, double* __restrict__ film)
-{
-    typedef typename Q4<R>::T R4;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.Pb; j += stride) {
-        double r = 0, g = 0, b = 0;
-        for (uint32_t s = 0; s < a.Sb; ++s) {
-            const R4 L = lacc[(size_t)s * a.Pb + j];
-            r += (double)L.x; g += (double)L.y; b += (double)L.z;
-        }
-        double* f = film + (size_t)(a.p0 + j) * 3;
-        f[0] += r; f[1] += g; f[2] += b;
-    }
-}
-
-// film (sums, shard-local) -> out_rgb (means, global row-major float)
-__global__ void __launch_bounds__(DRT_BLOCK)
-k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float* __restrict__ out)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const double inv = 1.0 / (double)a.spp;
-    for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < n_pixels; lp += stride) {
-        const uint32_t gp = global_pixel(a, lp);
-        out[(size_t)gp * 3 + 0] = (float)(film[(size_t)lp * 3 + 0] * inv);
-        out[(size_t)gp * 3 + 1] = (float)(film[(size_t)lp * 3 + 1] * inv);
-        out[(size_t)gp * 3 + 2] = (float)(film[(size_t)lp * 3 + 2] * inv);
-    }
-}
-
 // ---- K6 ---------------------------------------------------------------------------------------
 // One thread per path.  The tape holds 8 bytes per vertex (m_k, parameter ids); the prefix
 // throughputs T_k are rebuilt in registers with the very expression K3 used
@@ -1205,6 +944,358 @@ __device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ 
     return mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1], (R)adjoint[(size_t)gp * 3 + 2]);
 }
 
+// Forward-only: the radiance of a path of at most DRT_TAPE_CHUNK vertices from its records, deepest
+// vertex first (the walk of k_radiance on one chunk).
+template <typename R>
+__device__ inline V3<R> radiance_of_chunk(const BatchArgs& a, const SceneLds<R>& lds, const R* __restrict__ params,
+                                         const TapeRec<R>* trs, int K, R inv_p_rr)
+{
+    V3<R> L = mk<R>(R(0), R(0), R(0));
+#pragma unroll
+    for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
+        if (j < K) {
+            const uint32_t cid = trs[j].ids & 0xFFFFu, eid = trs[j].ids >> 16;
+            const R inv_pk = j >= a.min_bounces ? inv_p_rr : R(1);
+            V3<R> Lk = mk<R>(R(0), R(0), R(0));
+            if (eid != DRT_ID_NONE)
+                Lk = load_param(lds, params, (int)eid) * inv_pk;
+            if (cid != DRT_ID_NONE)
+                Lk = Lk + load_param(lds, params, (int)cid) * (L * trs[j].m);
+            L = Lk;
+        }
+    }
+    return L;
+}
+
+// next region >= w this wave shades; CAM: depth 0, region w holds its share of the batch's paths
+template <bool CAM>
+__device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __restrict__ counts_k, uint32_t w,
+                                       uint32_t n_waves, uint32_t& cnt)
+{
+    if (!CAM)
+        return next_live_region(counts_k, w, n_waves, a.n_regions, cnt);
+    const uint32_t begin = w << a.region_shift;
+    cnt = w < a.n_regions ? (a.n_paths - begin < a.region_size ? a.n_paths - begin : a.region_size) : 0u;
+    return w;
+}
+
+// Persistent blocks; every wave walks the regions w, w + n_waves, ... it owns in this launch and
+// shades them chunk by chunk.  The loads of the NEXT chunk (same region or the next live one) are
+// issued before the current chunk is shaded, so a wave always has one chunk of loads in flight.
+// SPEC = false instantiations carry no specular code (and fewer registers) for all-diffuse scenes.
+// FUSED = true: the closest hit over the analytic shapes is computed HERE from the ray just loaded
+// (K2 folded into K3): no hit lane, no second read of the ray -- 72 instead of 120 bytes per
+// segment.  Used whenever nothing else needs the hit records (no mesh, no unbiased chain vertices).
+// CAM (fused launches that start at depth 0, every path alive there): the camera ray is generated in
+// place -- K1 folded in too: nothing is read from the queue, the row of depth 0 is written here.
+// WALK (camera launches that take every path from the eye to its end, depth cap <= DRT_TAPE_CHUNK): the
+// tape never leaves the CU -- each lane keeps its path's records in an LDS column and walks them as
+// soon as the path has ended: DRT_WALK_RADIANCE = the radiance of the path (forward-only renders),
+// DRT_WALK_GRADIENTS = K6 in place (<= 4 parameters: register accumulators, the block reduction of
+// k_backward at the end of the kernel).  No tape, no vertex counts, no K6 / k_radiance launch.
+#define DRT_WALK_NONE 0
+#define DRT_WALK_RADIANCE 1
+#define DRT_WALK_GRADIENTS 2
+template <typename R, bool SPEC, bool FUSED, bool CAM = false, int WALK = DRT_WALK_NONE>
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
+k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
+        const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
+        const uint2* __restrict__ ray_id, const HitRec<R>* __restrict__ hit,
+        typename Q4<R>::T* __restrict__ next_a, typename Q2<R>::T* __restrict__ next_b,
+        uint2* __restrict__ next_id,
+        TapeRec<R>* __restrict__ tape_k, uint32_t* __restrict__ nv,
+        uint32_t* __restrict__ counts_k, uint32_t count_stride,
+        const typename Q4<R>::T* __restrict__ tri_shade,
+        int seg_start, const uint32_t* __restrict__ draw_base,
+        typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
+        HitRec<R>* __restrict__ save_hit,
+        const float* __restrict__ adjoint = nullptr, double* __restrict__ gpart = nullptr,
+        typename Q4<R>::T* __restrict__ lacc = nullptr)
+{
+    // nb > 1 (FUSED only): the launch takes every ray through nb bounces -- depths k .. k+nb-1 -- in
+    // registers; only the survivors of the LAST one are compacted and written back.  Lanes whose
+    // path ended in between idle (a few per cent per bounce), in exchange the 64 bytes of queue
+    // traffic per ray are paid once per nb segments.  counts_k + j * count_stride is the row of
+    // depth k + j: the rows in between are kept up to date with one non-returning atomic per chunk
+    // (a region is owned by one wave), the row of depth k + nb is written like before.
+    typedef typename Q4<R>::T R4;
+    typedef typename Q2<R>::T R2;
+    __shared__ SceneLds<R> lds;
+    __shared__ TapeRec<R> s_tape[WALK ? DRT_TAPE_CHUNK : 1][WALK ? DRT_BLOCK : 1];
+    __shared__ double s_red[WALK == DRT_WALK_GRADIENTS ? DRT_BLOCK / DRT_WAVE : 1][DRT_FAST_PARAMS * 3];
+    GradAcc<R, 4> ga;
+    if (WALK == DRT_WALK_GRADIENTS)
+        ga.init(nullptr);
+    stage_scene(lds, sc, params);
+
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
+    const size_t N = a.n_paths;
+    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
+    uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
+
+    uint32_t cnt;
+    uint32_t w = next_region<CAM>(a, counts_k, grid_wave(), n_waves, cnt);
+    if (!WALK && w >= a.n_regions)
+        return;
+    if (w < a.n_regions) {              // (a WALK launch ends with a block-wide reduction: no early exit)
+    uint32_t off = 0, running = 0;
+    ShadeIn<R> cur, nxt;
+    bool have = lane < cnt;
+    if (!CAM)
+        load_shade_in(cur, (w << a.region_shift) + lane, have, !FUSED, ray_a, ray_b, ray_id, hit);
+
+    for (;;) {
+        // where the next chunk is, and its loads
+        uint32_t nw = w, noff = off + DRT_WAVE, ncnt = cnt;
+        if (noff >= cnt) {
+            noff = 0;
+            nw = next_region<CAM>(a, counts_k, w + n_waves, n_waves, ncnt);
+        }
+        const bool more = nw < a.n_regions;
+        const bool nhave = more && noff + lane < ncnt;
+        if (!CAM)
+            load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
+        if (CAM && have) {
+            const uint32_t i = (w << a.region_shift) + off + lane;      // all alive at depth 0: slot == path
+            cur.rid.x = i;
+            camera_ray<R>(a, i, cur.ra, cur.rb, cur.rid.y);
+        }
+
+        bool alive = false, live = have;
+        int k_lane = 0;                                        // WALK: vertices of this lane's path
+        R4 ra = cur.ra, na;
+        R2 rb = cur.rb, nb2;
+        const uint32_t pid = cur.rid.x, key = cur.rid.y;
+        for (int it = 0;; ++it) {
+            const int kk = k + it;
+            const R pk = kk >= a.min_bounces ? (R)(1.0 - a.absorb) : R(1);   // pathtracer.hpp:130
+            // camera paths start at depth 0 with a closed-form base; re-sampled suffixes (unbiased
+            // backward) start at seg_start with a per-path base
+            const uint32_t n_off = draw_offset(kk, seg_start, a.min_bounces) + (draw_base ? 0u : camera_draw_base(a.min_bounces));
+            const bool next_rr = (kk + 1) >= a.min_bounces;
+            const bool next_cap = (kk + 1) >= a.depth_cap;
+            TapeRec<R>* __restrict__ tape_kk = tape_k + (size_t)it * N;
+            alive = false;
+            if (live) {
+                HitRec<R> h;
+                if (FUSED) {
+                    h = closest_hit_packed(sc, ra, rb);
+                } else {
+                    h = cur.h;
+                }
+                if (save_a && it == 0) {   // unbiased backward: this ray and its hit are the path's next chain vertex
+                    save_a[pid] = ra;
+                    save_b[pid] = rb;
+                    save_hit[pid] = h;
+                }
+                // what this vertex writes: at most one tape record and, when the path ends here, its length
+                TapeRec<R> tr;
+                bool write_tape = false, ended = true;
+                uint32_t n_vertices = (uint32_t)kk;                // miss: pathtracer.hpp:135
+                if (h.prim >= 0) {
+                    const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+                    const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+                    const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
+                    V3<R> nrm;
+                    int material, emitter;
+                    resolve_hit<R, !FUSED>(lds, tri_shade, h.prim, P, nrm, material, emitter);
+                    // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
+                    const uint32_t eid = emitter >= 0 ? (uint32_t)lds.sc.emitter_param[emitter] : DRT_ID_NONE;
+                    write_tape = true;
+                    n_vertices = (uint32_t)kk + 1u;
+                    // no BxDF: f = 0 (pathtracer.hpp:38-39); the reference's zero-direction
+                    // continuation contributes exactly 0, the path ends here
+                    tr.m = R(0);
+                    tr.ids = DRT_ID_NONE | (eid << 16);
+                    if (material >= 0) {
+                        const DevMaterial<R>& m = lds.sc.materials[material];
+                        const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
+                        V3<R> wo;
+                        R q, bs;
+                        sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+                        const R c = dot(nrm, wo);                  // pathtracer.hpp:103
+                        const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
+#ifdef DRT_DEBUG_NAN
+                        if (!(mk_ == mk_) || mk_ > R(1e30) || mk_ < R(-1e30))
+                            printf("[k_shade] pid %u k %d type %d: bs %g c %g q %g pk %g | nrm %g %g %g | d %g %g %g | wo %g %g %g | t %g prim %d\n",
+                                   pid, kk, m.type, (double)bs, (double)c, (double)q, (double)pk, (double)nrm.x, (double)nrm.y,
+                                   (double)nrm.z, (double)d.x, (double)d.y, (double)d.z, (double)wo.x, (double)wo.y, (double)wo.z,
+                                   (double)h.t, h.prim);
+#endif
+                        // roulette / cap of depth kk+1, decided here so dead rays are never queued
+                        alive = !next_cap;
+                        if (alive && next_rr)
+                            alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                        tr.m = mk_;
+                        tr.ids = (uint32_t)m.param | (eid << 16);
+                        ended = !alive;
+                        const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
+                        na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
+                        nb2.x = wo.y; nb2.y = wo.z;
+                    }
+                }
+                if (WALK) {
+                    if (write_tape)
+                        s_tape[it][threadIdx.x] = tr;          // own column: written and read by this lane only
+                    if (ended)
+                        k_lane = (int)n_vertices;
+                } else {
+                    if (write_tape)
+                        tape_kk[pid] = tr;
+                    if (ended)
+                        nv[pid] = n_vertices;
+                }
+            }
+            if (it + 1 >= nb)
+                break;
+            // survivors go straight into the next bounce; the row of the depth in between only counts them
+            const uint32_t n_mid = (uint32_t)__popcll(__ballot(alive));
+            if (n_mid == 0)
+                break;                                             // (alive is false in every lane)
+            if (lane == 0)
+                atomicAdd(counts_k + (size_t)(it + 1) * count_stride + w, n_mid);
+            ra = na;
+            rb = nb2;
+            live = alive;
+        }
+        if (WALK && have) {
+            // the path has ended inside this launch: walk its records now
+            TapeRec<R> first[DRT_TAPE_CHUNK];
+#pragma unroll
+            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+                first[j] = s_tape[j][threadIdx.x];
+            V3<R> L0 = mk<R>(R(0), R(0), R(0));
+            if (k_lane > 0) {
+                if (WALK == DRT_WALK_GRADIENTS)
+                    L0 = backward_path<R, true>(a, lds, params, (const TapeRec<R>*)nullptr, N, pid, k_lane,
+                                               path_seed<R>(a, adjoint, pid), inv_p_rr, ga, nullptr, nullptr, first);
+                else
+                    L0 = radiance_of_chunk<R>(a, lds, params, first, k_lane, inv_p_rr);
+            }
+            if (lacc) {
+                R4 o4;
+                o4.x = L0.x; o4.y = L0.y; o4.z = L0.z; o4.w = R(0);
+                lacc[pid] = o4;
+            }
+        }
+        uint32_t n_alive;
+        const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
+        if (alive) {
+            next_a[ns] = na;
+            next_b[ns] = nb2;
+            next_id[ns] = cur.rid;
+        }
+        running += n_alive;
+        if (nw != w) {                                         // region finished
+            if (lane == 0) {
+                counts_next[w] = running;
+                if (CAM)
+                    counts_k[w] = cnt;                         // depth 0: every path of the region
+            }
+            running = 0;
+        }
+        if (!more)
+            break;
+        cur = nxt;
+        have = nhave;
+        w = nw;
+        off = noff;
+        cnt = ncnt;
+    }
+    }
+    if (WALK == DRT_WALK_GRADIENTS) {
+        // block reduction in fp64, as in k_backward: thread -> wave (shuffles) -> block (LDS), fixed order
+        const int wv = threadIdx.x / DRT_WAVE;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            double v = ga.get(nullptr, r);
+#pragma unroll
+            for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)
+                v += __shfl_down(v, o2);
+            if (lane == 0)
+                s_red[wv][r] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < DRT_FAST_PARAMS * 3) {
+            double v = 0;
+            if (threadIdx.x < 12)
+                for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
+                    v += s_red[ww][threadIdx.x];
+            gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
+        }
+    }
+}
+
+// segments of one batch = rays queued at depths 0..D-1, summed over regions -> 64-bit total
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total,
+             uint32_t row_words, unsigned long long read_rows, unsigned long long written_rows)
+{
+    // total[0] += all words (= segments); total[1] += the rows a shade launch STARTED from (rays read from
+    // the queue), total[2] += the rows a launch ended on (survivors written back); row r = bit r of the masks
+    __shared__ unsigned long long red[3][DRT_BLOCK / DRT_WAVE];
+    unsigned long long v = 0, vr = 0, vw = 0;
+    for (uint32_t i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n_words; i += gridDim.x * DRT_BLOCK) {
+        const unsigned long long c = counts[i];
+        const uint32_t row = row_words ? i / row_words : 0u;
+        v += c;
+        if (row < 64u && ((read_rows >> row) & 1ull)) vr += c;
+        if (row < 64u && ((written_rows >> row) & 1ull)) vw += c;
+    }
+    for (int off = DRT_WAVE / 2; off > 0; off >>= 1) {
+        v += __shfl_down(v, off);
+        vr += __shfl_down(vr, off);
+        vw += __shfl_down(vw, off);
+    }
+    if ((threadIdx.x & (DRT_WAVE - 1)) == 0) {
+        red[0][threadIdx.x / DRT_WAVE] = v;
+        red[1][threadIdx.x / DRT_WAVE] = vr;
+        red[2][threadIdx.x / DRT_WAVE] = vw;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long t = 0;
+        for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
+            t += red[threadIdx.x][w];
+        if (t)
+            atomicAdd(total + threadIdx.x, t);   // integer: order-independent
+    }
+}
+
+// ---- K5 ---------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_film(BatchArgs a, const typename Q4<R>::T* __restrict__ lacc, double* __restrict__ film)
+{
+    typedef typename Q4<R>::T R4;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < a.Pb; j += stride) {
+        double r = 0, g = 0, b = 0;
+        for (uint32_t s = 0; s < a.Sb; ++s) {
+            const R4 L = lacc[(size_t)s * a.Pb + j];
+            r += (double)L.x; g += (double)L.y; b += (double)L.z;
+        }
+        double* f = film + (size_t)(a.p0 + j) * 3;
+        f[0] += r; f[1] += g; f[2] += b;
+    }
+}
+
+// film (sums, shard-local) -> out_rgb (means, global row-major float)
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float* __restrict__ out)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const double inv = 1.0 / (double)a.spp;
+    for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < n_pixels; lp += stride) {
+        const uint32_t gp = global_pixel(a, lp);
+        out[(size_t)gp * 3 + 0] = (float)(film[(size_t)lp * 3 + 0] * inv);
+        out[(size_t)gp * 3 + 1] = (float)(film[(size_t)lp * 3 + 1] * inv);
+        out[(size_t)gp * 3 + 2] = (float)(film[(size_t)lp * 3 + 2] * inv);
+    }
+}
+
+// ---- K6 (kernel; the tape walk and the accumulators it uses are defined before K3, which can run them in place) ----
 template <typename R, int NP>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : 1)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
