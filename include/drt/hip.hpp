@@ -14,6 +14,8 @@
 
 #include <cstdint>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -36,6 +38,7 @@ struct Options {
     bool f64 = false;               // verification mode: compute in double on the device
     long long batch_paths = 0;
     int bounces_per_launch = 0;     // 0 = automatic; 1 = one shade launch per bounce (drt_hip.h)
+    bool reuse_context = true;      // keep the device context (and its gigabytes of queues) between calls
 };
 
 struct Stats {
@@ -200,10 +203,49 @@ public:
         if (rc != DRT_OK)
             throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + drt_hip_last_error(m_ctx));
     }
+    std::mutex& mutex() { return m_mutex; }
 
 private:
     drt_hip_ctx* m_ctx = nullptr;
+    std::mutex m_mutex;        // a context is not thread-safe: pooled ones are locked for the duration of a call
 };
+
+// Contexts are kept between calls: creating one (HIP module load, stream) and growing its queues
+// (gigabytes of hipMalloc for a 512 x 512 x 64 frame) costs ~0.3 s, a render 2 ms -- an optimisation
+// loop around drt::hip::render must not pay that per iteration.  One context per (device, slot); slot
+// distinguishes several entries of Options::devices that name the same device.  They live until
+// release_contexts() or process exit (deliberately not destroyed by static destructors: the HIP
+// runtime may be gone by then).
+namespace detail {
+struct ContextPool {
+    std::mutex m;
+    std::map<std::pair<int, int>, Context*> contexts;
+};
+inline ContextPool& pool()
+{
+    static ContextPool* p = new ContextPool();
+    return *p;
+}
+} // namespace detail
+
+inline Context& pooled_context(int device, int slot = 0)
+{
+    detail::ContextPool& p = detail::pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    Context*& c = p.contexts[std::make_pair(device, slot)];
+    if (!c)
+        c = new Context(device);
+    return *c;
+}
+
+inline void release_contexts()
+{
+    detail::ContextPool& p = detail::pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    for (auto& kv : p.contexts)
+        delete kv.second;
+    p.contexts.clear();
+}
 
 // img: width*height row-major (render.cpp:66,82); adjoint: optional per-pixel seed, same layout.
 template <typename T>
@@ -233,7 +275,14 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
 
     auto work = [&](int d) {
         try {
-            Context ctx(opt.devices[d]);
+            int slot = 0;                                      // how many earlier entries name the same device
+            for (int e = 0; e < d; ++e)
+                slot += opt.devices[e] == opt.devices[d] ? 1 : 0;
+            std::unique_ptr<Context> own;
+            if (!opt.reuse_context)
+                own.reset(new Context(opt.devices[d]));
+            Context& ctx = own ? *own : pooled_context(opt.devices[d], slot);
+            std::lock_guard<std::mutex> lock(ctx.mutex());
             ctx.check(drt_hip_upload_scene(ctx.get(), &sd), "drt_hip_upload_scene");
             drt_render_params rp{};
             rp.spp = (int32_t)spp;
@@ -315,7 +364,11 @@ inline Stats render_gradient_image(const Scene<T>& scene, const Camera<T>& cam, 
     const drt_camera_desc cd = describe(cam);
     const std::size_t npix = cam.width() * cam.height();
     std::vector<float> rgb(npix * 3, 0.f), grad(npix * 3, 0.f);
-    Context ctx(opt.devices.empty() ? 0 : opt.devices[0]);
+    std::unique_ptr<Context> own;
+    if (!opt.reuse_context)
+        own.reset(new Context(opt.devices.empty() ? 0 : opt.devices[0]));
+    Context& ctx = own ? *own : pooled_context(opt.devices.empty() ? 0 : opt.devices[0]);
+    std::lock_guard<std::mutex> lock(ctx.mutex());
     ctx.check(drt_hip_upload_scene(ctx.get(), &sd), "drt_hip_upload_scene");
     drt_render_params rp{};
     rp.spp = (int32_t)spp;

@@ -31,6 +31,7 @@ struct Args {
     int max_depth = 0;
     std::vector<int> devices = {0};
     bool f64 = false;
+    int repeat = 1;                   // --repeat N: render N times (an optimisation loop's cost per iteration)
     std::string front = "diffuse";   // BxDF of sphere_front: diffuse (render.cpp:39) | specular (render.cpp:35's) | mirror
 };
 
@@ -47,7 +48,7 @@ inline bool parse_args(int argc, const char* const* argv, Args* args)
         std::fprintf(f,
             "USAGE: %s -o <string> [-x <integer>] [-y <integer>] [-n <integer>] [-b <integer>] [-p <number>]\n"
             "       [--backend cpu|hip] [--backward] [--unbiased] [--seed <integer>] [--max-depth <integer>]\n"
-            "       [--devices a,b,...] [--f64] [--front diffuse|specular|mirror] [--version] [-h]\n\n"
+            "       [--devices a,b,...] [--f64] [--front diffuse|specular|mirror] [--repeat <integer>] [--version] [-h]\n\n"
             "A simple differentiable path tracer\n"
             "  -x, --width        Output image width (640)\n"
             "  -y, --height       Output image height (480)\n"
@@ -75,6 +76,7 @@ inline bool parse_args(int argc, const char* const* argv, Args* args)
         else if (a == "--f64") { args->f64 = true; }
         else if (a == "--seed") { if (!value(v)) return false; args->seed = (unsigned)std::strtoul(v, &end, 10); if (*end) return false; }
         else if (a == "--max-depth") { if (!value(v)) return false; args->max_depth = (int)std::strtol(v, &end, 10); if (*end) return false; }
+        else if (a == "--repeat") { if (!value(v)) return false; args->repeat = (int)std::strtol(v, &end, 10); if (*end || args->repeat < 1) return false; }
         else if (a == "--front") { if (!value(v)) return false; args->front = v; if (args->front != "diffuse" && args->front != "specular" && args->front != "mirror") return false; }
         else if (a == "--devices") {
             if (!value(v)) return false;

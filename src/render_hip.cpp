@@ -75,8 +75,20 @@ int main(int argc, const char* argv[])
         opt.max_depth = args.max_depth;
         opt.devices = args.devices;
         opt.f64 = args.f64;
-        const hip::Stats st = hip::render(scene, cam, tracer, args.samples, img.data(), opt);
-        segments = st.segments;
+        // --repeat N: what an optimisation loop pays per iteration (the device context and its queues are
+        // kept between calls; gradients accumulate like the reference's autograd, so they are zeroed in between)
+        for (int it = 0; it < args.repeat; ++it) {
+            if (it > 0) {
+                for (Vector<T, 3, true>* p : {&red, &green, &white, &emission})
+                    p->grad() = Vector<T, 3>(0.);
+            }
+            const auto ti = std::chrono::steady_clock::now();
+            const hip::Stats st = hip::render(scene, cam, tracer, args.samples, img.data(), opt);
+            segments = st.segments;
+            if (args.repeat > 1)
+                std::printf("call %d: %.3f ms\n", it,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count());
+        }
     } else {
         // the reference's loop on the host API, drawing the same per-path RNG streams
         for (std::size_t y = 0; y < cam.height(); ++y) {
