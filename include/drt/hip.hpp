@@ -75,6 +75,42 @@ struct FlatScene {
         d.meshes = meshes.data();
         return d;
     }
+
+    // Everything but the parameter VALUES (FNV-1a over the records and the mesh data): two scenes with the
+    // same key differ at most in their parameters, which drt_hip_update_params replaces without
+    // re-uploading the geometry or rebuilding the BVH.
+    uint64_t topology_key() const
+    {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void* p, std::size_t n) {
+            const unsigned char* b = static_cast<const unsigned char*>(p);
+            for (std::size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+        };
+        auto mix_n = [&](uint64_t v) { mix(&v, sizeof v); };
+        mix_n(shapes.size());
+        for (const drt_shape_desc& sh : shapes) {       // field by field: the records have padding
+            mix(&sh.type, sizeof sh.type); mix(&sh.material, sizeof sh.material); mix(&sh.emitter, sizeof sh.emitter);
+            mix(&sh.mesh, sizeof sh.mesh); mix(sh.p, sizeof sh.p);
+        }
+        mix_n(materials.size());
+        for (const drt_material_desc& m : materials) {
+            mix(&m.type, sizeof m.type); mix(&m.param, sizeof m.param); mix(&m.exponent, sizeof m.exponent);
+        }
+        mix_n(emitters.size());
+        for (const drt_emitter_desc& e : emitters)
+            mix(&e.param, sizeof e.param);
+        mix_n(requires_grad.size());
+        mix(requires_grad.data(), requires_grad.size());
+        mix_n(meshes.size());
+        for (std::size_t i = 0; i < meshes.size(); ++i) {
+            mix(mesh_vertices[i].data(), mesh_vertices[i].size() * sizeof(double));
+            mix(mesh_indices[i].data(), mesh_indices[i].size() * sizeof(uint32_t));
+            mix_n(meshes[i].face_material ? 1 : 0);
+            if (meshes[i].face_material)
+                mix(meshes[i].face_material, (std::size_t)meshes[i].n_triangles * sizeof(int32_t));
+        }
+        return h;
+    }
 };
 
 template <typename T>
@@ -205,8 +241,26 @@ public:
     }
     std::mutex& mutex() { return m_mutex; }
 
+    // upload the scene, or -- when only parameter values changed since this context's last upload -- just them
+    template <typename T>
+    void set_scene(const FlatScene<T>& flat)
+    {
+        const uint64_t key = flat.topology_key();
+        if (m_has_scene && key == m_scene_key) {
+            check(drt_hip_update_params(m_ctx, flat.params.data()), "drt_hip_update_params");
+            return;
+        }
+        const drt_scene_desc sd = flat.desc();
+        m_has_scene = false;
+        check(drt_hip_upload_scene(m_ctx, &sd), "drt_hip_upload_scene");
+        m_scene_key = key;
+        m_has_scene = true;
+    }
+
 private:
     drt_hip_ctx* m_ctx = nullptr;
+    uint64_t m_scene_key = 0;
+    bool m_has_scene = false;
     std::mutex m_mutex;        // a context is not thread-safe: pooled ones are locked for the duration of a call
 };
 
@@ -253,7 +307,6 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
                     Vector<T, 3>* img, const Options& opt = Options(), const Vector<T, 3>* adjoint = nullptr)
 {
     FlatScene<T> flat = flatten(scene);
-    const drt_scene_desc sd = flat.desc();
     const drt_camera_desc cd = describe(cam);
     const std::size_t npix = cam.width() * cam.height();
     const int n_dev = (int)opt.devices.size();
@@ -283,7 +336,7 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
                 own.reset(new Context(opt.devices[d]));
             Context& ctx = own ? *own : pooled_context(opt.devices[d], slot);
             std::lock_guard<std::mutex> lock(ctx.mutex());
-            ctx.check(drt_hip_upload_scene(ctx.get(), &sd), "drt_hip_upload_scene");
+            ctx.set_scene(flat);
             drt_render_params rp{};
             rp.spp = (int32_t)spp;
             rp.min_bounces = (int32_t)tracer.min_bounces();
@@ -360,7 +413,6 @@ inline Stats render_gradient_image(const Scene<T>& scene, const Camera<T>& cam, 
             index = (int)p;
     if (index < 0)
         throw std::runtime_error("drt::hip::render_gradient_image: the parameter is not used by the scene");
-    const drt_scene_desc sd = flat.desc();
     const drt_camera_desc cd = describe(cam);
     const std::size_t npix = cam.width() * cam.height();
     std::vector<float> rgb(npix * 3, 0.f), grad(npix * 3, 0.f);
@@ -369,7 +421,7 @@ inline Stats render_gradient_image(const Scene<T>& scene, const Camera<T>& cam, 
         own.reset(new Context(opt.devices.empty() ? 0 : opt.devices[0]));
     Context& ctx = own ? *own : pooled_context(opt.devices.empty() ? 0 : opt.devices[0]);
     std::lock_guard<std::mutex> lock(ctx.mutex());
-    ctx.check(drt_hip_upload_scene(ctx.get(), &sd), "drt_hip_upload_scene");
+    ctx.set_scene(flat);
     drt_render_params rp{};
     rp.spp = (int32_t)spp;
     rp.min_bounces = (int32_t)tracer.min_bounces();
