@@ -68,7 +68,7 @@ def main():
                     help="nccl (= RCCL, the real thing) | gloo: lets two ranks share ONE GPU to exercise the N > 1 path "
                          "on a single-GPU box (with --same-gpu); the numbers of such a run mean nothing")
     ap.add_argument("--same-gpu", action="store_true", help="every rank uses device 0 (testing only)")
-    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-spp", type=int, default=48)
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the oracle on every host core (independent row-band processes)")
     a = ap.parse_args()
