@@ -448,3 +448,17 @@ def test_results_do_not_depend_on_bounces_per_launch(pkg, hip, scene_name, b, p,
         if nb == 8 and not unbiased and not overridden:
             assert got[2]["kernels"]["shade"]["launches"] < ref[2]["kernels"]["shade"]["launches"]
             assert got[2]["queue_rays_read"] < ref[2]["queue_rays_read"]
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_forward_only_image_equals_the_image_of_a_gradient_render(pkg, hip, f64):
+    """Forward-only renders take their own route (for depth caps <= 8 the shade launch walks every path's
+    tape in place, without a tape in HBM): the image must be the one a forward + backward render returns."""
+    for scene_name, b, p in (("cornell", 8, 1.0), ("cornell_specular", 5, 1.0), ("cornell", 2, 0.3), ("mesh10x12", 4, 1.0)):
+        hip.upload_scene(pkg.scene_by_name(scene_name))
+        cam = pkg.cornell_camera(144, 100)
+        rp = pkg.RenderParams(spp=5, min_bounces=b, absorb=p, seed=31)
+        fwd, g0, st0 = hip.render(cam, rp, backward=False, f64=f64)
+        both, g1, st1 = hip.render(cam, rp, backward=True, f64=f64)
+        assert g0 is None and st0["segments"] == st1["segments"]
+        np.testing.assert_array_equal(fwd, both)
