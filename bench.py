@@ -3,42 +3,73 @@
 
 Metric: Mray/s (fwd+bwd) on the Cornell box of /root/reference/src/render.cpp:26-59,
 512x512, 64 spp, depth 8 (`-b 8 -p 1`), gradients w.r.t. the material albedos + emission
-(BASELINE config 3).  A "step" is one full render call: every path of the frame traced forward
-through the wavefront pipeline, the tape swept backward, gradients reduced.  ray = one raycast
-(camera ray included), exactly what the reference's Pathtracer::raycast counts.
+(BASELINE config 3).  A "step" is one full render call: every path of the frame traced from the
+eye to its end, gradients accumulated and reduced.  ray = one raycast (camera ray included),
+exactly what the reference's Pathtracer::raycast counts.
 
-  python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|5]
 
-Multi-GPU: one process per GPU; the frame's rows are dealt to the ranks in interleaved bands
-and spp is multiplied by N, so every rank traces the same 512*512*64 paths whatever N is (weak
-scaling); the only collective is one RCCL all-reduce of the P x 3 gradient vector per step.
-Prints ONE JSON line (rank 0).
+--gpus N > 1 without torchrun's environment: this process starts N ranks itself (a fresh
+`python -m torch.distributed.run` child, one rank per GPU) and relays rank 0's JSON line.  Under
+torchrun (RANK set) it is one of the ranks.  The frame's rows are dealt to the ranks in
+interleaved 16-row bands and spp is multiplied by N, so every rank traces the same number of
+paths whatever N is (weak scaling); the only collective is ONE ncclAllReduce of the P x 3 f64
+gradient vector per step, enqueued by libdrt_hip.so itself on the context's stream
+(drt_hip_comm_init_rank + DRT_RENDER_ALLREDUCE).  Prints ONE JSON line (rank 0).
+
+--config selects a BASELINE.json configuration; per GPU it is that configuration's 1/8 share
+(configs 4 and 5 are quoted on 8 GPUs), so `--config 4 --gpus 8` is exactly config 4.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6200.0        # measured float4 copy on the pool's boxes (profiles/r01_microbench_stream_roofs.txt; guide: 6.29)
 # vector-instruction issue: a wave64 VALU op takes 2 cycles of its SIMD; 256 CUs x 4 SIMDs at 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0     # 1228.8 G wave-instructions / s
-# algorithmic bytes per ray segment, f32 queues (DESIGN.md section 4)
-# shade (unfused): ray 24 + id 8 + hit 8 read; ray 24 + id 8 + tape 8 written per segment.
-# Fused shade (K2 folded into K3, several bounces per launch in registers): 8 B of tape per segment + 32 B
-# per ray a launch READS from the queue + 32 B per survivor it WRITES back -- the library counts both.
-BYTES_PER_UNIT = {"intersect": 32.0, "shade": 80.0, "backward": 8.0}
+
+# BASELINE.json configs -> workload per GPU (configs 4, 5: the 1/8 share of one of the 8 GPUs they are quoted on)
+CONFIGS = {
+    2: dict(width=512, height=512, spp=64, depth=8, scene="cornell", forward_only=True,
+            name="config 2: Cornell 512x512, 64 spp, depth 8, diffuse+emissive, fwd only"),
+    3: dict(width=512, height=512, spp=64, depth=8, scene="cornell", forward_only=False,
+            name="config 3: Cornell 512x512, 64 spp, depth 8, fwd + radiative backprop w.r.t. the albedos"),
+    4: dict(width=1024, height=1024, spp=32, depth=8, scene="mesh160x160", forward_only=False,
+            name="config 4: 1024x1024, 256 spp over 8 GPUs (32 spp per GPU), 50,880-triangle mesh in the box, fwd+bwd"),
+    5: dict(width=2048, height=2048, spp=128, depth=16, scene="cornell_specular", forward_only=False,
+            name="config 5: 2048x2048, 1024 spp over 8 GPUs (128 spp per GPU), depth 16, diffuse + specular, fwd+bwd"),
+}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start N ranks as a CHILD process tree (never an exec of this process:
+    under rocprofv3 the GPU is initialised before main() runs) and pass rank 0's line through."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _oracle_shard(args):
     """Worker of the all-cores CPU figure: one row-band shard of the sample, in its own process."""
+    import __graft_entry__ as entry
     scene_name, w, h, spp, depth, backward, shard, n_shards = args
     pkg = entry.load_package()
     oracle = entry.load_oracle()
@@ -47,42 +78,64 @@ def _oracle_shard(args):
     return r["stats"]["segments"]
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--scene", default="cornell", help="cornell (headline) | cornell_specular | mesh<lat>x<lon>[f<n>] | random<seed>")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configuration (per-GPU share)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel PER GPU")
+    ap.add_argument("--depth", type=int, default=0)
+    ap.add_argument("--scene", default="", help="cornell | cornell_specular | mesh<lat>x<lon>[f<n>] | random<seed>")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--unbiased", action="store_true", help="backward with the unbiased integration operator")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-streaming-view", action="store_true",
-                    help="skip the extra one-launch-per-bounce measurement (profiling runs: keeps kernel statistics unmixed)")
+    ap.add_argument("--no-extra-views", action="store_true",
+                    help="skip the extra measurements (one launch per bounce, f64, forward-only, host buffers): profiling "
+                         "runs keep their kernel statistics unmixed")
     ap.add_argument("--bounces-per-launch", type=int, default=0, help="0 = automatic (drt_hip.h)")
     ap.add_argument("--dist-backend", default="nccl",
-                    help="nccl (= RCCL, the real thing) | gloo: lets two ranks share ONE GPU to exercise the N > 1 path "
-                         "on a single-GPU box (with --same-gpu); the numbers of such a run mean nothing")
+                    help="nccl (= RCCL, the real thing) | gloo: rendezvous only, lets ranks share ONE GPU to exercise the "
+                         "N > 1 path on a single-GPU box (with --same-gpu); the numbers of such a run mean nothing")
     ap.add_argument("--same-gpu", action="store_true", help="every rank uses device 0 (testing only)")
-    ap.add_argument("--cpu-spp", type=int, default=48)
+    ap.add_argument("--reduce", default="library", choices=["library", "torch"],
+                    help="where the gradient all-reduce runs: inside libdrt_hip.so (RCCL, default) or torch.distributed")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the oracle on every host core (independent row-band processes)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    cfg = CONFIGS[a.config]
+    a.width = a.width or cfg["width"]
+    a.height = a.height or cfg["height"]
+    a.spp = a.spp or cfg["spp"]
+    a.depth = a.depth or cfg["depth"]
+    a.scene = a.scene or cfg["scene"]
+    a.forward_only = a.forward_only or cfg["forward_only"]
+    a.is_config = all(getattr(a, k) == v for k, v in cfg.items() if k != "name")
+    a.config_name = cfg["name"] if a.is_config else "custom"
+    return a
 
+
+def main():
+    argv = sys.argv[1:]
+    a = parse_args(argv)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus, argv))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
+    import __graft_entry__ as entry
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(1, a.gpus):
-        if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    # launched by torch.distributed.run (also with one rank: exercises the RCCL path on one GPU)
+    if world != max(1, a.gpus) and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # launched by torch.distributed.run (also with one rank: exercises the in-library RCCL path on one GPU)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if a.same_gpu:
         local_rank = 0
@@ -98,38 +151,58 @@ def main():
     scene = pkg.scene_by_name(a.scene)
     cam = pkg.cornell_camera(a.width, a.height)
     backward = not a.forward_only
-    rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
-                          shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
-                          flags=pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0,
-                          bounces_per_launch=a.bounces_per_launch)
-
     r = pkg.HipRenderer(local_rank)          # raises without libdrt_hip.so / a device: no fallback
     r.upload_scene(scene)
     dev = torch.device("cuda", local_rank)
+
+    # the ONE collective of the path lives behind the C ABI: rank 0 makes the id, the launcher's rendezvous
+    # (torch.distributed here) hands it to the other ranks, every rank joins with its own context
+    reduce_mode = None
+    if use_dist and backward:
+        reduce_mode = a.reduce
+        if reduce_mode == "library":
+            uid = [pkg.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            try:
+                r.comm_init(uid[0], rank, world)
+            except pkg.DrtHipError as e:            # e.g. --same-gpu: RCCL refuses two ranks on one device
+                if rank == 0:
+                    print(f"bench.py: in-library communicator unavailable ({e}); reducing with torch.distributed", file=sys.stderr)
+                reduce_mode = "torch"
+            ok = torch.tensor([1 if reduce_mode == "library" else 0], device=dev if a.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if reduce_mode == "library":
+                    r.comm_destroy()
+                reduce_mode = "torch"
+    flags = (pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0) | (pkg.RENDER_ALLREDUCE if reduce_mode == "library" else 0)
+    rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
+                          shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
+                          flags=flags, bounces_per_launch=a.bounces_per_launch)
+
     out_rgb = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device=dev)
-    # two gradient buffers: the all-reduce of step i runs on its own stream while step i + 1 renders
-    # into the other buffer (every step's gradient is complete and reduced; only its delivery overlaps
-    # the next step's compute -- "collectives on a separate stream", the usual data-parallel overlap)
     grads = [torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-    ext = torch.cuda.ExternalStream(r.stream, device=dev)
-    comm = torch.cuda.Stream(device=dev) if use_dist else None
-    reduced = [None, None]          # event: the all-reduce that last used this buffer has finished
+    # reduce_mode == "torch" (testing / A-B): the all-reduce of step i runs on its own stream while step i + 1
+    # renders into the other gradient buffer
+    ext = torch.cuda.ExternalStream(r.stream, device=dev) if reduce_mode == "torch" else None
+    comm = torch.cuda.Stream(device=dev) if reduce_mode == "torch" else None
+    reduced = [None, None]
     n_step = [0]
 
-    def step(timing=False):
+    def step(timing=False, params=None):
         b = n_step[0] & 1
         n_step[0] += 1
         grad = grads[b]
         if reduced[b] is not None:
             ext.wait_event(reduced[b])         # step i - 2's all-reduce read this buffer
-        st = r.render_device(cam, rp, out_rgb.data_ptr(), grad.data_ptr() if backward else 0,
+        st = r.render_device(cam, params or rp, out_rgb.data_ptr(), grad.data_ptr() if backward else 0,
                              backward=backward, timing=timing, sync=False)
-        if use_dist and backward:
+        if reduce_mode == "torch":
             rendered = torch.cuda.Event()
             rendered.record(ext)
             comm.wait_event(rendered)
             with torch.cuda.stream(comm):
-                dist.all_reduce(grad, op=dist.ReduceOp.SUM)   # the ONE collective of the path
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
                 done = torch.cuda.Event()
                 done.record(comm)
             reduced[b] = done
@@ -169,26 +242,34 @@ def main():
     segments = stats["segments"]
     paths = stats["paths"]
     queue_rays = stats["queue_rays_read"] + stats["queue_rays_written"]
+    devices = None
     if use_dist:
         t = torch.tensor([segments, paths], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_segments, total_paths = float(t[0].item()), float(t[1].item())
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = f"rank {rank}: cuda:{local_rank} {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
     else:
         total_segments, total_paths = float(segments), float(paths)
 
     ms_per_step = elapsed / a.steps * 1e3
     value = total_segments * a.steps / elapsed * 1e-6   # Mray/s, whole job
 
-    # dominant kernel and its roofline (rank 0's device; every rank runs the same work)
-    units = {"intersect": segments, "shade": segments, "backward": segments,
+    # ---- per-kernel algorithmic bytes and the roofline of the dominant kernel ----------
+    units = {"intersect": segments, "intersect_mesh": segments, "shade": segments, "backward": segments, "path": segments,
              "raygen": paths, "film": paths, "gradreduce": 0}
-    bpu = {"intersect": BYTES_PER_UNIT["intersect"],
-           # fused shade: tape 8 B/segment + queued rays; when it also walks the tape in place (forward-only, one launch
-           # from the eye to the path's end: no K6 / k_radiance launch) the tape stays in LDS and 16 B of radiance
-           # per path is all it writes
-           "shade": BYTES_PER_UNIT["shade"] if kernel_launches["intersect"] else
-                    (8.0 if kernel_launches["backward"] else 16.0 * paths / max(1, segments)) + 32.0 * queue_rays / max(1, segments),
-           "backward": BYTES_PER_UNIT["backward"], "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
+    # fused shade: tape 8 B/segment + 32 B per ray read from / written to the queue (the library counts both);
+    # unfused (mesh scenes): ray 24 + id 8 + hit 8 read, ray 24 + id 8 + tape 8 written;
+    # k_path: a path lives in registers from the eye to its end: 16 B of radiance per PATH is all it moves;
+    # k_intersect_mesh: ray 24 + hit 8 read, hit 8 written (the BVH itself is L2 / Infinity-Cache resident)
+    seg = max(1, segments)
+    bpu = {"intersect": 32.0, "intersect_mesh": 40.0,
+           "shade": 80.0 if kernel_launches["intersect"] else
+                    (8.0 if kernel_launches["backward"] else 16.0 * paths / seg) + 32.0 * queue_rays / seg,
+           "path": 16.0 * paths / seg,
+           "backward": 8.0, "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
     per_kernel = {}
     for k in pkg.KERNEL_NAMES:
         ms = kernel_ms[k] / n_prof
@@ -199,97 +280,131 @@ def main():
                          "bytes_per_unit": round(bpu[k], 3), "achieved_GBs": round(gbs, 1),
                          "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     dominant = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else "shade"
-    traffic = None
+    # rocprofv3 PMC figures of the dominant kernel (profiles/traffic.json, written by tools/profile.sh on the
+    # workload named in it): quoted only for that very workload
+    pmc = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    # the committed rocprofv3 counters were taken on the headline workload: only quote them for it
-    pmc_applies = (a.scene == "cornell" and (a.width, a.height, a.spp, a.depth) == (512, 512, 64, 8) and backward
-                   and not a.unbiased and a.bounces_per_launch == 0)
-    if pmc_applies and os.path.exists(tpath):
+    workload_key = f"{a.scene}:{a.width}x{a.height}x{a.spp}:d{a.depth}:{'fwd' if a.forward_only else 'fwdbwd'}"
+    if os.path.exists(tpath) and not a.unbiased and a.bounces_per_launch == 0:
         try:
-            tj = json.load(open(tpath)).get(dominant)
-            traffic = tj.get("GBs") if tj else None
+            tj = json.load(open(tpath))
+            if tj.get("workload") == workload_key:
+                pmc = tj.get(dominant) or {}
         except Exception:
-            traffic = None
+            pmc = {}
     dk = per_kernel.get(dominant, {"achieved_GBs": 0.0, "launches_per_step": 1, "ms_per_step": 0.0})
-    roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": dk["achieved_GBs"],
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json) over the profiled launch time" if traffic else None,
-                "avg_launch_ms": round(dk["ms_per_step"] / max(1, dk["launches_per_step"]), 4),
-                # the kernel that finds the closest hit: k_intersect(+mesh), or k_shade when K2 is folded into it
-                "traversal_kernel": dict(per_kernel.get("intersect") or per_kernel.get("shade") or {},
-                                         name="k_intersect" if "intersect" in per_kernel else "k_shade<fused>"),
+    launch_ms = dk["ms_per_step"] / max(1, dk["launches_per_step"])
+    register_resident = dominant == "path" or (dominant == "shade" and not kernel_launches["intersect"]
+                                               and dk["launches_per_step"] < a.depth * max(1, stats["batches"]) and not a.unbiased)
+    traffic = round(pmc["bytes_per_launch"] / (launch_ms * 1e-3) * 1e-9, 1) if pmc.get("bytes_per_launch") and launch_ms > 0 else None
+    roofline = {"bound": "valu-issue (paths are register-resident: the kernel moves almost no bytes)" if register_resident
+                         else ("latency (divergent BVH walk out of L2)" if dominant == "intersect_mesh" else "hbm"),
+                "kernel": "k_" + dominant, "achieved": dk["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy_roof": round(dk["achieved_GBs"] / HBM_COPY_GBS, 4),
+                "traffic": traffic,
+                "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json, rocprofv3 --pmc, FETCH_SIZE "
+                                "doubled per the gfx950 correction) over the live launch time" if traffic else None,
+                "avg_launch_ms": round(launch_ms, 4),
                 "kernels": per_kernel}
-    shade = per_kernel.get("shade")
-    multi_bounce = (shade is not None and not kernel_launches["intersect"]
-                    and shade["launches_per_step"] < a.depth * max(1, stats["batches"]) and not a.unbiased)
-    if multi_bounce:
-        # The fused shade kernel keeps a ray in registers over several bounces: the queue traffic is paid once
-        # per launch, not per segment, and the kernel is bound by vector-instruction issue, not by HBM.  Two
-        # extra views so the HBM fraction above is not read alone:
-        #  (1) the vector-issue utilisation, from the rocprofv3 SQ_INSTS_VALU count of the same kernel;
-        #  (2) the SAME workload with one launch per bounce (bounces_per_launch = 1, the streaming wavefront
-        #      the HBM roofline describes), timed live here.
-        roofline["note"] = (f"k_shade runs {a.depth * max(1, stats['batches']) // max(1, shade['launches_per_step'])} bounces per launch in registers "
-                            f"({shade['bytes_per_unit']} B/segment): VALU-issue-bound; see roofline.valu and roofline.streaming")
-        try:
-            tsh = json.load(open(tpath)).get("shade", {}) if pmc_applies else {}
-        except Exception:
-            tsh = {}
-        if tsh.get("valu_insts_per_launch"):
-            ginst = tsh["valu_insts_per_launch"] / (shade["ms_per_step"] / shade["launches_per_step"] * 1e-3) * 1e-9
-            roofline["valu"] = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
-                                "frac": round(ginst / VALU_PEAK_GINST, 4),
-                                "note": "SQ_INSTS_VALU per launch (profiles/traffic.json, rocprofv3 --pmc) / live launch time; peak = one "
-                                        "VALU op per 2 cycles per SIMD (two interleaved waves); the CU's one scalar unit is about as busy "
-                                        "(DESIGN.md section 3)"}
-    if multi_bounce and not a.no_streaming_view:
-        import dataclasses
-        rp1 = dataclasses.replace(rp, bounces_per_launch=1)
+    if pmc.get("valu_insts_per_launch") and launch_ms > 0:
+        ginst = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3) * 1e-9
+        roofline["valu"] = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                            "frac": round(ginst / VALU_PEAK_GINST, 4),
+                            "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
+                            "note": "SQ_INSTS_VALU per launch (profiles/traffic.json) / live launch time; peak = one VALU op "
+                                    "per 2 cycles per SIMD"}
 
-        def step1(timing=False):
-            return r.render_device(cam, rp1, out_rgb.data_ptr(), grads[0].data_ptr() if backward else 0,
-                                   backward=backward, timing=timing, sync=False)
+    extra = rank == 0 and world == 1 and not a.no_extra_views
+    import dataclasses
+    if extra and register_resident and not a.unbiased:
+        # The HBM roofline describes the STREAMING wavefront: the same workload with one shade launch per bounce
+        # (rays through the queue in HBM after every bounce), timed live.
+        rp1 = dataclasses.replace(rp, bounces_per_launch=1)
         for _ in range(2):
-            step1()
+            step(params=rp1)
         fence()
         t4 = time.perf_counter()
         for _ in range(n_prof):
-            step1()
+            step(params=rp1)
         fence()
         dt4 = (time.perf_counter() - t4) / n_prof
         ms1, q1 = 0.0, 0
         for _ in range(n_prof):
-            st1 = step1(timing=True)
+            st1 = step(timing=True, params=rp1)
             ms1 += st1["kernels"]["shade"]["ms"]
             q1 = st1["queue_rays_read"] + st1["queue_rays_written"]
         fence()
         ms1 /= n_prof
-        bpu1 = 8.0 + 32.0 * q1 / max(1, segments)
+        bpu1 = 8.0 + 32.0 * q1 / seg
         gbs1 = segments * bpu1 / (ms1 * 1e-3) * 1e-9 if ms1 > 0 else 0.0
-        roofline["traversal_kernel"]["one_launch_per_bounce"] = {"ms_per_step": round(ms1, 4), "achieved_GBs": round(gbs1, 1),
-                                                                 "frac_hbm_peak": round(gbs1 / HBM_PEAK_GBS, 4)}
         roofline["streaming"] = {"bounces_per_launch": 1, "value": round(segments / dt4 * 1e-6, 2), "unit": "Mray/s",
-                                 "ms_per_step": round(dt4 * 1e3, 4), "kernel": "k_shade", "bytes_per_unit": round(bpu1, 3),
-                                 "achieved": round(gbs1, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs1 / HBM_PEAK_GBS, 4)}
+                                 "ms_per_step": round(dt4 * 1e3, 4), "kernel": "k_shade", "shade_ms_per_step": round(ms1, 4),
+                                 "bytes_per_unit": round(bpu1, 3), "achieved": round(gbs1, 1), "peak": HBM_PEAK_GBS,
+                                 "frac": round(gbs1 / HBM_PEAK_GBS, 4),
+                                 "frac_of_measured_copy_roof": round(gbs1 / HBM_COPY_GBS, 4)}
+
+    def timed_variant(**kw):
+        """Mray/s of a variant of the headline call (device buffers, same frame), a few steps."""
+        bw = kw.pop("backward", backward)
+        f64 = kw.pop("f64", False)
+        rpv = dataclasses.replace(rp, flags=(rp.flags | (pkg.RENDER_F64 if f64 else 0)))
+
+        def one(timing=False):
+            return r.render_device(cam, rpv, out_rgb.data_ptr(), grads[0].data_ptr() if bw else 0, backward=bw,
+                                   timing=timing, sync=False)
+        one()
+        fence()
+        n = 2 if f64 else n_prof
+        t5 = time.perf_counter()
+        for _ in range(n):
+            one()
+        fence()
+        dt5 = (time.perf_counter() - t5) / n
+        segs = one(timing=True)["segments"]
+        fence()
+        return {"value": round(segs / dt5 * 1e-6, 2), "unit": "Mray/s", "ms_per_step": round(dt5 * 1e3, 4)}
+
+    f64_view = fwd_view = None
+    if extra and not a.unbiased:
+        f64_view = dict(timed_variant(f64=True), note="the same call with DRT_RENDER_F64: every kernel computes and stores in "
+                                                      "double, the reference's precision (render.cpp:22)")
+        if backward:
+            fwd_view = dict(timed_variant(backward=False), note="forward only (BASELINE config 2 when the headline is config 3)")
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         oracle = entry.load_oracle()
-        crp = pkg.RenderParams(spp=a.cpu_spp, min_bounces=a.depth, absorb=1.0, seed=1)
+        # a bounded sample of the same workload: a pilot measures the oracle's rate on a small frame of the same
+        # scene and depth, then the sample is sized for ~cpu_seconds (mesh scenes are brute force on the CPU:
+        # their sample is a handful of pixels)
+        pw, ph, ps = 32, 32, 1
         t1 = time.perf_counter()
-        ref = oracle.render(scene, cam, crp, backward=backward)
+        pilot = oracle.render(scene, pkg.cornell_camera(pw, ph), pkg.RenderParams(spp=ps, min_bounces=a.depth, absorb=1.0, seed=1),
+                              backward=backward)
+        rate = pilot["stats"]["segments"] / max(1e-6, time.perf_counter() - t1)      # rays / s
+        per_path = pilot["stats"]["segments"] / (pw * ph * ps)
+        budget_paths = max(1.0, a.cpu_seconds * rate / per_path)
+        cw, ch, cs = a.width, a.height, a.spp
+        if budget_paths >= cw * ch:
+            cs = int(max(1, min(a.spp, budget_paths // (cw * ch))))
+        else:                               # not even one sample per pixel: shrink the frame (same aspect)
+            f = (budget_paths / (cw * ch)) ** 0.5
+            cw, ch, cs = max(8, int(cw * f)), max(8, int(ch * f)), 1
+        ccam = pkg.cornell_camera(cw, ch)
+        crp = pkg.RenderParams(spp=cs, min_bounces=a.depth, absorb=1.0, seed=1)
+        t1 = time.perf_counter()
+        ref = oracle.render(scene, ccam, crp, backward=backward)
         dt = time.perf_counter() - t1
         cpu_baseline = {"value": round(ref["stats"]["segments"] / dt * 1e-6, 3), "unit": "Mray/s",
                         "cores": 1, "kind": "port",
-                        "sample": f"same scene and frame {a.width}x{a.height}, {a.cpu_spp} of the {a.spp} spp, "
+                        "sample": f"same scene, frame {cw}x{ch} of {a.width}x{a.height}, {cs} of the {a.spp} spp, "
                                   f"depth {a.depth}, {'fwd+bwd' if backward else 'fwd'}: "
                                   f"{ref['stats']['segments']} rays in {dt:.1f} s (fp64 C restatement, 1 thread)"}
-        # parity of this very workload's gradients against the CPU restatement (same RNG keys):
-        # the first cpu_spp samples of every pixel are the same paths on both sides only when
-        # spp matches, so run the device once more at the sample's spp
+        # parity of this very workload's gradients against the CPU restatement (same RNG keys): run the
+        # device once more on the sample's frame and spp
         if backward:
-            img_d, g_d, _ = r.render(cam, crp, backward=True)
+            img_d, g_d, _ = r.render(ccam, crp, backward=True)
             gerr = float(np.abs(g_d - ref["grads"]).max() / np.abs(ref["grads"]).max())
             cpu_baseline["grad_max_rel_err_vs_cpu"] = gerr
         if a.cpu_all_cores:
@@ -297,7 +412,7 @@ def main():
             # processes, each rendering its interleaved row bands of the same sample
             import multiprocessing as mp
             n = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
-            jobs = [(a.scene, a.width, a.height, a.cpu_spp, a.depth, backward, i, n) for i in range(n)]
+            jobs = [(a.scene, cw, ch, cs, a.depth, backward, i, n) for i in range(n)]
             with mp.get_context("spawn").Pool(n) as pool:
                 # start the workers and load the checker in each of them before the clock starts
                 pool.map(_oracle_shard, [(a.scene, 16, 16, 1, 1, False, 0, 1)] * n, chunksize=1)
@@ -310,7 +425,7 @@ def main():
     # the same call through the host-buffer entry point (synchronous, image and gradients copied to
     # pageable host memory over PCIe): reported beside `value`, never as `value`
     host_buffers = None
-    if rank == 0 and world == 1:
+    if extra:
         hrp = pkg.RenderParams(spp=a.spp, min_bounces=a.depth, absorb=1.0, seed=1, batch_paths=a.batch_paths)
         n_host = max(1, min(a.steps, 5))
         r.render(cam, hrp, backward=backward, unbiased=a.unbiased and backward)
@@ -323,20 +438,31 @@ def main():
                         "note": "drt_hip_render with host out_rgb / out_param_grad (synchronous, PCIe D2H of the image included)"}
 
     if rank == 0:
+        what = "fwd+bwd" if backward else "fwd"
+        if world > 1:
+            par = (f"{dist.get_world_size()} ranks x 1 GPU ({'; '.join(devices)}): interleaved 16-row bands, ONE "
+                   f"{'ncclAllReduce(sum, f64, P x 3) inside libdrt_hip.so' if reduce_mode == 'library' else 'torch.distributed all_reduce'}"
+                   f" per step" + (" [ranks share device 0: plumbing test, numbers meaningless]" if a.same_gpu else ""))
+        elif use_dist:
+            par = f"1 rank, 1 GPU ({devices[0]}); gradient through the {reduce_mode or 'no'} all-reduce of a 1-rank communicator"
+        else:
+            par = "1 GPU"
         line = {
-            "metric": f"Mray/s ({'fwd+bwd' if backward else 'fwd'}), Cornell {a.width}x{a.height} @{a.spp}spp depth {a.depth}",
+            "metric": f"Mray/s ({what}), {'Cornell' if a.scene.startswith('cornell') else a.scene} {a.width}x{a.height} @{a.spp}spp depth {a.depth}",
             "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("" if a.scene == "cornell" else f"[scene {a.scene}] ") + f"cornell box (render.cpp:26-59) {a.width}x{a.height}, "
+            "config": {"workload": f"{a.config_name}; scene '{a.scene}' (cornell box of render.cpp:26-59"
+                                   f"{' + procedural mesh' if a.scene.startswith('mesh') else ''}) {a.width}x{a.height}, "
                                    f"{a.spp} spp per GPU, depth {a.depth} (-b {a.depth} -p 1), "
-                                   f"{'fwd + radiative-backprop grads of 4 params' if backward else 'fwd only'}",
+                                   f"{'fwd + radiative-backprop gradients of ' + str(scene.n_params) + ' parameters' if backward else 'fwd only'}",
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
-                       "parallelism": f"pixel-row bands x{world}, 1 grad all-reduce" if world > 1 else "1 GPU",
-                       "batches_per_step": stats["batches"]},
+                       "parallelism": par, "batches_per_step": stats["batches"],
+                       "capped_paths_per_step": stats["capped_paths"]},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
+            "f64": f64_view, "fwd_only": fwd_view,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,11 +33,15 @@ RENDER_SYNC = 0x4
 RENDER_TIMING = 0x8
 RENDER_F64 = 0x10
 RENDER_UNBIASED = 0x20
-K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 8
-KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce"]
+RENDER_ALLREDUCE = 0x40
+MAX_DEPTH = 64
+K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
+KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]
+ABI_VERSION = 4
+UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3: "DRT_ERR_HIP",
-                -4: "DRT_ERR_NO_SCENE", -5: "DRT_ERR_OOM", -6: "DRT_ERR_UNSUPPORTED"}
+                -4: "DRT_ERR_NO_SCENE", -5: "DRT_ERR_OOM", -6: "DRT_ERR_UNSUPPORTED", -7: "DRT_ERR_COMM"}
 
 
 class ShapeDesc(C.Structure):
@@ -86,12 +90,14 @@ class HipStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("batches", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double * K_COUNT),
                 ("launches", C.c_uint64 * K_COUNT), ("units", C.c_uint64 * K_COUNT),
-                ("queue_rays_read", C.c_uint64), ("queue_rays_written", C.c_uint64)]
+                ("queue_rays_read", C.c_uint64), ("queue_rays_written", C.c_uint64),
+                ("capped_paths", C.c_uint64), ("bvh_bytes", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {"paths": int(self.paths), "segments": int(self.segments),
              "batches": int(self.batches), "ms_total": float(self.ms_total), "kernels": {},
-             "queue_rays_read": int(self.queue_rays_read), "queue_rays_written": int(self.queue_rays_written)}
+             "queue_rays_read": int(self.queue_rays_read), "queue_rays_written": int(self.queue_rays_written),
+             "capped_paths": int(self.capped_paths), "bvh_bytes": int(self.bvh_bytes)}
         for k, name in enumerate(KERNEL_NAMES):
             d["kernels"][name] = {"ms": float(self.ms_kernel[k]), "launches": int(self.launches[k]),
                                   "units": int(self.units[k])}
@@ -416,7 +422,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + srcs
+           "-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + srcs + ["-lrccl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -427,7 +433,9 @@ class DrtHipError(RuntimeError):
     pass
 
 
-_ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_destroy",
+_ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_create_group",
+                "drt_hip_group_size", "drt_hip_destroy",
+                "drt_hip_comm_unique_id", "drt_hip_comm_init_rank", "drt_hip_comm_size", "drt_hip_comm_destroy",
                 "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render",
                 "drt_hip_render_gradient_image", "drt_hip_stream",
                 "drt_hip_synchronize", "drt_hip_last_error", "drt_hip_kernel_name"]
@@ -445,6 +453,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.drt_hip_abi_version.restype = C.c_int
     lib.drt_hip_device_count.restype = C.c_int
     lib.drt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.drt_hip_create_group.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    lib.drt_hip_group_size.argtypes = [C.c_void_p]
+    lib.drt_hip_comm_unique_id.argtypes = [C.c_void_p]
+    lib.drt_hip_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.drt_hip_comm_size.argtypes = [C.c_void_p]
+    lib.drt_hip_comm_destroy.argtypes = [C.c_void_p]
     lib.drt_hip_destroy.argtypes = [C.c_void_p]
     lib.drt_hip_destroy.restype = None
     lib.drt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
@@ -463,17 +477,52 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-class HipRenderer:
-    """One context = one MI355X device + one stream (drt_hip_ctx)."""
+def comm_unique_id(lib_path: Optional[str] = None) -> bytes:
+    """drt_hip_comm_unique_id: 128 bytes rank 0 hands to the other ranks out of band."""
+    lib = load_library(lib_path)
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = lib.drt_hip_comm_unique_id(buf)
+    if rc != 0:
+        raise DrtHipError(f"drt_hip_comm_unique_id failed: {STATUS_NAMES.get(rc, rc)}")
+    return buf.raw
 
-    def __init__(self, device: int = 0, lib_path: Optional[str] = None):
+
+class HipRenderer:
+    """One context = one MI355X device + one stream (drt_hip_ctx); or, with a LIST of devices, a group
+    context: one process driving several GPUs, gradients reduced inside the library (drt_hip_create_group)."""
+
+    def __init__(self, device=0, lib_path: Optional[str] = None):
         self.lib = load_library(lib_path)
         self.ctx = C.c_void_p()
-        rc = self.lib.drt_hip_create(device, C.byref(self.ctx))
-        if rc != 0:
-            raise DrtHipError(f"drt_hip_create(device={device}) failed: {STATUS_NAMES.get(rc, rc)}")
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*device)
+            rc = self.lib.drt_hip_create_group(ids, len(device), C.byref(self.ctx))
+            if rc != 0:
+                raise DrtHipError(f"drt_hip_create_group(devices={list(device)}) failed: {STATUS_NAMES.get(rc, rc)}")
+        else:
+            rc = self.lib.drt_hip_create(device, C.byref(self.ctx))
+            if rc != 0:
+                raise DrtHipError(f"drt_hip_create(device={device}) failed: {STATUS_NAMES.get(rc, rc)}")
         self.device = device
         self.scene: Optional[Scene] = None
+
+    @property
+    def group_size(self) -> int:
+        return int(self.lib.drt_hip_group_size(self.ctx))
+
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        """Join the communicator of a one-process-per-GPU job (collective). Afterwards renders with
+        RENDER_ALLREDUCE return gradients summed over all ranks."""
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        self._check(self.lib.drt_hip_comm_init_rank(self.ctx, buf, rank, n_ranks), "drt_hip_comm_init_rank")
+
+    @property
+    def comm_size(self) -> int:
+        return int(self.lib.drt_hip_comm_size(self.ctx))
+
+    def comm_destroy(self):
+        self._check(self.lib.drt_hip_comm_destroy(self.ctx), "drt_hip_comm_destroy")
 
     def _check(self, rc: int, what: str):
         if rc != 0:

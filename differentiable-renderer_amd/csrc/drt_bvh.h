@@ -34,14 +34,22 @@ struct Node {
 
 constexpr uint32_t kLeaf = 0x80000000u;
 constexpr int kMaxLeaf = 4;
-constexpr int kMaxDepth = 20;     // binary depth <= 20 => 4-wide depth <= 10 => at most 3 * 10 pushes:
-                                  // the device's 32-entry per-lane stack cannot overflow
+constexpr int kMaxDepth = 20;     // bound of the binary build's depth.  The collapse below splits the child with the
+                                  // LARGEST box, so a child that is never re-split advances one binary level per wide
+                                  // level: the wide depth is NOT kMaxDepth / 2 in general.  What the device needs is
+                                  // Built::stack_need <= its per-lane stack (DRT_BVH_STACK); build() measures it on the
+                                  // finished tree and rebuilds with a smaller depth bound until it holds.
+constexpr int kStackEntries = 32; // = DRT_BVH_STACK (drt_device.h; static_assert in drt_hip.hip)
 
 struct Built {
     std::vector<Node> nodes;      // final order, root = 0
     std::vector<uint32_t> order;  // triangle indices (into the input) in leaf order
     uint32_t top = 0;             // nodes [0, top) are the breadth-first top of the tree
-    int depth = 0;
+    int depth = 0;                // binary depth of the SAH tree
+    int wide_depth = 0;           // levels of 4-wide nodes
+    int stack_need = 0;           // worst number of entries the ordered walk can hold at once: along a root-to-leaf
+                                  // path every node pushes at most (children - 1) links before descending
+    int sah_splits = 0, median_splits = 0;   // how the interior nodes were split (diagnostics / tests)
 };
 
 namespace detail {
@@ -89,6 +97,8 @@ struct Builder {
     }
 
     int max_depth_seen = 0;
+    int depth_bound = kMaxDepth;
+    int sah_splits = 0, median_splits = 0;
 
     int build(uint32_t first, uint32_t count, int depth = 0)
     {
@@ -109,7 +119,7 @@ struct Builder {
         // depth bound: once the remaining levels are only enough for a balanced tree, split by median
         int need = 0;
         while ((1u << need) * (uint32_t)kMaxLeaf < count) ++need;
-        const bool force_median = depth + need + 1 >= kMaxDepth;
+        const bool force_median = depth + need + 1 >= depth_bound;
         // binned SAH over the widest centroid axis first, then the others
         constexpr int B = 16;
         double best = INFINITY;
@@ -133,8 +143,10 @@ struct Builder {
             uint32_t rc[B];
             double alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
             uint32_t acc = 0;
+            // (an empty bin holds the inverted box (+inf, -inf): growing by its corners would blow the running box
+            // up to (-inf, +inf), make every cost infinite and silently turn the whole build into median splits)
             for (int b = B - 1; b >= 0; --b) {
-                grow(alo, ahi, lo[b]); grow(alo, ahi, hi[b]);
+                if (cnt[b]) { grow(alo, ahi, lo[b]); grow(alo, ahi, hi[b]); }
                 acc += cnt[b];
                 std::memcpy(rlo[b], alo, sizeof alo); std::memcpy(rhi[b], ahi, sizeof ahi);
                 rc[b] = acc;
@@ -142,7 +154,7 @@ struct Builder {
             double llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
             uint32_t lc = 0;
             for (int b = 0; b < B - 1; ++b) {
-                grow(llo, lhi, lo[b]); grow(llo, lhi, hi[b]);
+                if (cnt[b]) { grow(llo, lhi, lo[b]); grow(llo, lhi, hi[b]); }
                 lc += cnt[b];
                 if (lc == 0 || rc[b + 1] == 0)
                     continue;
@@ -154,6 +166,7 @@ struct Builder {
         if (count <= (uint32_t)kMaxLeaf && (best_axis < 0 || best >= leaf_cost))
             return me;
         uint32_t mid;
+        (best_axis >= 0 ? sah_splits : median_splits)++;
         if (best_axis >= 0) {
             const double ext = chi[best_axis] - clo[best_axis];
             auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t t) {
@@ -186,15 +199,18 @@ struct Builder {
 
 // pad: boxes are grown by this much on every side (absorbs f32 rounding of boxes, rays and the
 // traversal arithmetic; the closest hit is still exact, the box test only has to be conservative)
-inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
+inline Built build_bounded(const std::vector<Tri>& tris, uint32_t max_top, double pad, int depth_bound)
 {
     Built out;
     if (tris.empty())
         return out;
     detail::Builder b(tris);
+    b.depth_bound = depth_bound;
     b.tmp.reserve(tris.size() * 2);
     b.build(0, (uint32_t)tris.size());
     out.depth = b.max_depth_seen;
+    out.sah_splits = b.sah_splits;
+    out.median_splits = b.median_splits;
     const std::vector<detail::Tmp>& t = b.tmp;
     out.order = b.idx;
     auto leaf_link = [&](int u) { return kLeaf | (t[u].first << 3) | t[u].count; };
@@ -236,6 +252,8 @@ inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
             set_empty(nd, sde);
         out.nodes.push_back(nd);
         out.top = 1;
+        out.wide_depth = 1;
+        out.stack_need = 0;
         return out;
     }
     // wide nodes = the binary nodes that survive the collapse; physical order: breadth-first prefix
@@ -281,7 +299,45 @@ inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad)
                 set_empty(out.nodes[i], c);
         }
     }
+    // Worst stack occupancy of the device's ordered walk and the depth in wide levels, on the finished tree.
+    // Children come after their parent in `at` (breadth-first prefix, then depth-first), so one backward
+    // sweep sees every child before its parent.
+    {
+        std::vector<int> need(out.nodes.size(), 0), levels(out.nodes.size(), 1);
+        for (size_t i = out.nodes.size(); i-- > 0;) {
+            int nc = 0, deepest = 0, lv = 0;
+            for (int c = 0; c < kWidth; ++c) {
+                const uint32_t link = out.nodes[i].child[c];
+                if (link == kLeaf)
+                    continue;
+                ++nc;
+                if (!(link & kLeaf)) {
+                    deepest = std::max(deepest, need[link]);
+                    lv = std::max(lv, levels[link]);
+                }
+            }
+            need[i] = (nc > 0 ? nc - 1 : 0) + deepest;
+            levels[i] = 1 + lv;
+        }
+        out.stack_need = need[0];
+        out.wide_depth = levels[0];
+    }
     return out;
+}
+
+// The tree the device walks: binned SAH under the default depth bound; if the collapsed tree could hold more
+// than `stack_entries` links on the walk's stack (deep, unbalanced trees: nested scales, long slivers), rebuild
+// with a tighter bound -- more of the tree becomes balanced median splits -- until it fits.  A bound of
+// ceil(log2(n / kMaxLeaf)) + 1 is a fully balanced tree; stack_entries >= 3 * that / 2 always terminates the loop.
+inline Built build(const std::vector<Tri>& tris, uint32_t max_top, double pad, int stack_entries = kStackEntries)
+{
+    int bound = kMaxDepth;
+    for (;;) {
+        Built b = build_bounded(tris, max_top, pad, bound);
+        if (b.stack_need <= stack_entries || bound <= 2)
+            return b;
+        --bound;
+    }
 }
 
 // ---- device encoding: one 4-wide node in 64 bytes ---------------------------------------------

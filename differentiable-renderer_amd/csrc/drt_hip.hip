@@ -5,6 +5,8 @@
 #include "drt_kernels.h"
 #include "drt_bvh.h"
 
+#include <rccl/rccl.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -23,6 +25,30 @@ struct DevBuf {
 struct TimedLaunch {
     int kernel;
     hipEvent_t e0, e1;
+};
+
+// One render call between its phases: launch (everything enqueued, gradients in ctx->grad) -> reduce (the
+// cross-device sum) -> collect (results on their way to the caller) -> finish (wait, hand over, statistics).
+// A plain context runs them back to back; a group context runs each phase on ALL members before the next,
+// so the devices work concurrently under one host thread.
+struct RenderJob {
+    drt_camera_desc cam;
+    drt_render_params rp;
+    const float* adjoint_rgb = nullptr;
+    float* out_rgb = nullptr;
+    double* out_param_grad = nullptr;
+    float* out_gimg = nullptr;
+    drt_hip_stats* stats = nullptr;
+    int gimg_param = -1;
+    bool backward = false, dev_out = false, timing = false, want_segments = false, sync = true;
+    int n_shards = 1, shard = 0, band = 1;
+    uint32_t n_local_pixels = 0;
+    size_t n_count_words = 0;
+    float* d_out = nullptr;
+    float* d_gimg = nullptr;
+    size_t off_grad = 0, off_img = 0, off_gimg = 0, img_bytes = 0, grad_bytes = 0;
+    drt_hip_stats st;
+    std::chrono::steady_clock::time_point t0;
 };
 
 } // namespace
@@ -62,6 +88,18 @@ struct drt_hip_ctx {
     uint8_t* h_stage = nullptr;
     size_t h_stage_cap = 0;
     DevBuf probe;
+    uint64_t bvh_bytes = 0;
+    RenderJob job;
+    // multi-GPU.  A plain context may join a communicator (one process per GPU, drt_hip_comm_init_rank).  A GROUP
+    // context (drt_hip_create_group) owns one plain member per listed device and nothing else; members that share a
+    // device are summed on it, the first member of every distinct device (its "leader") holds that device's rank
+    // in the group's communicator.
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
+    std::vector<drt_hip_ctx*> members;
+    std::vector<int> leader;          // member i -> index of the first member on the same device
+    hipEvent_t ev_done = nullptr;     // member: "my gradient is complete" (waited for by its leader's stream)
+    bool is_member = false;
 };
 
 namespace {
@@ -288,7 +326,7 @@ int queue_length(drt_hip_ctx* ctx, const uint32_t* counts_row, uint32_t n_region
         HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_probe, sizeof(unsigned long long)));
     HIPCHK(ctx, hipMemsetAsync(ctx->probe.p, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_sum_counts, dim3(16), dim3(DRT_BLOCK), 0, ctx->stream, counts_row, n_regions,
-                       (unsigned long long*)ctx->probe.p, n_regions, 0ull, 0ull);
+                       (unsigned long long*)ctx->probe.p, n_regions, 0ull, 0ull, 0xFFFFFFFFu);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_probe, ctx->probe.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *out = *ctx->h_probe;
@@ -529,11 +567,15 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                        ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
-                    if (ctx->has_mesh)   // continues from the analytic hit: (t, primitive) refined by the BVH walk
-                        hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                           bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_INTERSECT]++;
+                    if (ctx->has_mesh) {   // continues from the analytic hit: (t, primitive) refined by the BVH walk
+                        if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT_MESH)) != DRT_OK) return rc;
+                        hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                           bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                        if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                        st->launches[DRT_K_INTERSECT_MESH]++;
+                    }
                 }
                 if (save_here && !fused)
                     hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur], rb[cur],
@@ -582,8 +624,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             }
 
             hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts,
-                               (uint32_t)((size_t)D * max_regions), (unsigned long long*)ctx->segtotal.p,
-                               (uint32_t)max_regions, read_rows, written_rows);
+                               (uint32_t)((size_t)(D + 1) * max_regions), (unsigned long long*)ctx->segtotal.p,
+                               (uint32_t)max_regions, read_rows, written_rows, (uint32_t)D);
             if (backward && D > 0 && gimg_param >= 0) {
                 // gradient image: per-path gradient of one parameter, averaged per pixel by K5
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
@@ -662,7 +704,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (s < D)
                         hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream,
                                            counts + (size_t)s * max_regions, (uint32_t)((size_t)(D - s) * max_regions),
-                                           (unsigned long long*)ctx->segtotal.p, (uint32_t)max_regions, sfx_read, sfx_written);
+                                           (unsigned long long*)ctx->segtotal.p, (uint32_t)max_regions, sfx_read, sfx_written, 0xFFFFFFFFu);
                     hipLaunchKernelGGL(k_radiance_from<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, s, d_scene,
                                        d_params, tape, nv, cs);
                     if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
@@ -801,9 +843,19 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
 {
     if (!ctx)
         return;
+    if (!ctx->members.empty() || !ctx->stream) {          // a group context owns members, nothing else
+        for (drt_hip_ctx* m : ctx->members)
+            drt_hip_destroy(m);
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm)
+        (void)ncclCommDestroy(ctx->comm);
+    if (ctx->ev_done)
+        (void)hipEventDestroy(ctx->ev_done);
     DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
@@ -827,7 +879,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     delete ctx;
 }
 
-int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
+static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
 {
     if (!ctx)
         return DRT_ERR_INVALID;
@@ -935,10 +987,14 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
                 return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: more than 2^28 triangles");
             const double diag = sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
                                      (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            static_assert(drt_bvh::kStackEntries == DRT_BVH_STACK, "builder and traversal kernel disagree on the stack size");
             const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES, 1e-5 * (diag > 0 ? diag : 1.0));
+            if (built.stack_need > DRT_BVH_STACK)      // not even a balanced tree fits (> ~2 M triangles)
+                return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: the BVH of this mesh needs a deeper traversal stack than the device kernel has");
             if ((rc = upload_bvh<float>(ctx, built, tris, &ctx->bvh_f)) != DRT_OK) return rc;
             if ((rc = upload_bvh<double>(ctx, built, tris, &ctx->bvh_d)) != DRT_OK) return rc;
             ctx->has_mesh = true;
+            ctx->bvh_bytes = (uint64_t)built.nodes.size() * 64 + (uint64_t)tris.size() * 48;   // f32 image: nodes + three 16-byte triangle lanes
         }
     }
     ctx->n_user_params = s->n_params;
@@ -965,7 +1021,7 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     return DRT_OK;
 }
 
-int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
+static int update_params_one(drt_hip_ctx* ctx, const double* params)
 {
     if (!ctx)
         return DRT_ERR_INVALID;
@@ -983,9 +1039,357 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
     return DRT_OK;
 }
 
+} // extern "C"
+
+// ---- one render call in phases (see RenderJob) ---------------------------------------------------
+
+// rows [y0, y1) of the bands that `shard` owns
+template <typename F>
+static void for_each_band(int height, int band, int n_shards, int shard, F&& fn)
+{
+    if (n_shards <= 1) {
+        fn(0, height);
+        return;
+    }
+    for (int y0 = shard * band; y0 < height; y0 += n_shards * band)
+        fn(y0, y0 + band < height ? y0 + band : height);
+}
+
+// phase 1: validate, set up, enqueue the whole pipeline; the gradient of THIS context's shard ends up in ctx->grad
+static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                         const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
+                         int gimg_param, float* out_gimg)
+{
+    if (!ctx->has_scene)
+        return fail(ctx, DRT_ERR_NO_SCENE, "render before upload_scene");
+    if (!cam || !rp || cam->width <= 0 || cam->height <= 0 || rp->spp <= 0 || rp->min_bounces < 0 ||
+        !(rp->absorb >= 0.0 && rp->absorb <= 1.0))
+        return fail(ctx, DRT_ERR_INVALID, "render: bad camera or render parameters");
+    if ((uint64_t)cam->width * (uint64_t)cam->height >= 0xFFFFFFFFull)
+        return fail(ctx, DRT_ERR_INVALID, "render: image too large");
+    if (rp->max_depth > DRT_MAX_DEPTH)
+        return fail(ctx, DRT_ERR_INVALID, "render: max_depth above DRT_MAX_DEPTH (64)");
+    if (rp->absorb >= 1.0 && rp->max_depth <= 0 && rp->min_bounces > DRT_MAX_DEPTH)
+        return fail(ctx, DRT_ERR_INVALID, "render: absorb == 1 ends every path at min_bounces, which is above DRT_MAX_DEPTH (64)");
+    const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;
+    const int band = rp->band_rows > 0 ? rp->band_rows : 1;
+    if (n_shards > 1 && (rp->shard < 0 || rp->shard >= n_shards))
+        return fail(ctx, DRT_ERR_INVALID, "render: shard out of range");
+    RenderJob& j = ctx->job;
+    j = RenderJob();
+    j.cam = *cam;
+    j.rp = *rp;
+    j.adjoint_rgb = adjoint_rgb; j.out_rgb = out_rgb; j.out_param_grad = out_param_grad; j.out_gimg = out_gimg;
+    j.stats = stats;
+    j.gimg_param = gimg_param;
+    j.n_shards = n_shards; j.shard = n_shards > 1 ? rp->shard : 0; j.band = band;
+    j.backward = (rp->flags & DRT_RENDER_BACKWARD) != 0;
+    j.dev_out = (rp->flags & DRT_RENDER_DEVICE_OUT) != 0;
+    j.timing = (rp->flags & DRT_RENDER_TIMING) != 0;
+    const bool f64 = (rp->flags & DRT_RENDER_F64) != 0;
+    if (j.backward && !out_param_grad && gimg_param < 0 && !ctx->is_member)
+        return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
+    if ((rp->flags & DRT_RENDER_ALLREDUCE) && j.backward && !ctx->comm && !ctx->is_member)
+        return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_ALLREDUCE on a context without a communicator (drt_hip_comm_init_rank)");
+
+    j.t0 = std::chrono::steady_clock::now();
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    // rows owned by this shard
+    uint32_t local_rows = 0;
+    for_each_band(cam->height, band, n_shards, j.shard, [&](int y0, int y1) { local_rows += (uint32_t)(y1 - y0); });
+    j.n_local_pixels = local_rows * (uint32_t)cam->width;
+
+    // deepest vertex a path can reach: absorb == 1 kills every path at depth min_bounces
+    int depth_cap = rp->max_depth > 0 ? rp->max_depth : DRT_MAX_DEPTH;
+    if (rp->absorb >= 1.0 && rp->min_bounces < depth_cap)
+        depth_cap = rp->min_bounces;
+
+    memset(&j.st, 0, sizeof j.st);
+    ctx->events_used = 0;
+    ctx->timed.clear();
+
+    int rc;
+    const size_t npix_all = (size_t)cam->width * cam->height;
+    const float* d_adj = nullptr;
+    if (out_rgb) {
+        if ((rc = ensure(ctx, ctx->film, (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->film.p, 0, (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double), ctx->stream));
+        if (j.dev_out) {
+            j.d_out = out_rgb;
+        } else {
+            if ((rc = ensure(ctx, ctx->out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+            j.d_out = (float*)ctx->out.p;       // only this shard's rows are written, and only they are copied back
+        }
+    }
+    if (j.backward) {
+        if ((rc = ensure(ctx, ctx->grad, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double), ctx->stream));
+        if (adjoint_rgb) {
+            if (j.dev_out) {
+                d_adj = adjoint_rgb;
+            } else {
+                if ((rc = ensure(ctx, ctx->adjoint, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->adjoint.p, adjoint_rgb, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                d_adj = (const float*)ctx->adjoint.p;
+            }
+        }
+    }
+    if (gimg_param >= 0) {
+        const size_t fb = (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double);
+        if ((rc = ensure(ctx, ctx->gfilm, fb)) != DRT_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->gfilm.p, 0, fb, ctx->stream));
+        if (j.dev_out) {
+            j.d_gimg = out_gimg;
+        } else {
+            if ((rc = ensure(ctx, ctx->gimg_out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+            j.d_gimg = (float*)ctx->gimg_out.p;
+        }
+    }
+    double* d_film = out_rgb ? (double*)ctx->film.p : nullptr;   // no image requested: skip K5
+    rc = DRT_OK;
+    if (j.n_local_pixels > 0) {
+        if (f64)
+            rc = render_impl<double>(ctx, cam, rp, d_adj, j.d_out, j.backward, j.timing, &j.st, j.n_local_pixels,
+                                     depth_cap, &j.n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, j.d_gimg);
+        else
+            rc = render_impl<float>(ctx, cam, rp, d_adj, j.d_out, j.backward, j.timing, &j.st, j.n_local_pixels,
+                                    depth_cap, &j.n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, j.d_gimg);
+    }
+    return rc;
+}
+
+// phase 2 (one process per GPU): THE collective of the path -- the P x 3 gradient accumulator summed over the ranks
+static int render_reduce(drt_hip_ctx* ctx)
+{
+    RenderJob& j = ctx->job;
+    if (!(j.backward && (j.rp.flags & DRT_RENDER_ALLREDUCE) && ctx->comm && j.gimg_param < 0))
+        return DRT_OK;
+    const ncclResult_t r = ncclAllReduce(ctx->grad.p, ctx->grad.p, (size_t)ctx->n_user_params * 3, ncclDouble, ncclSum,
+                                         ctx->comm, ctx->stream);
+    if (r != ncclSuccess) {
+        ctx->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
+        return DRT_ERR_COMM;
+    }
+    return DRT_OK;
+}
+
+// phase 3: results on their way to the caller (device pointers: a copy on the stream; host buffers: DMA into the
+// context's pinned staging block -- only the rows of this shard)
+static int render_collect(drt_hip_ctx* ctx, bool with_grad = true)
+{
+    RenderJob& j = ctx->job;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t npix_all = (size_t)j.cam.width * j.cam.height;
+    // parameters that do not require grad keep a zero gradient (vector.hpp:156-162)
+    if (j.backward && j.dev_out && j.out_param_grad && with_grad) {
+        for (int p = 0; p < ctx->n_user_params; ++p)
+            if (!ctx->requires_grad[p])
+                HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)p * 3, 0, 3 * sizeof(double), ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(j.out_param_grad, ctx->grad.p, (size_t)ctx->n_user_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    j.sync = !j.dev_out || (j.rp.flags & DRT_RENDER_SYNC) || j.timing || j.stats;
+    j.img_bytes = npix_all * 3 * sizeof(float);
+    j.grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
+    j.off_grad = 64;
+    j.off_img = j.off_grad + ((j.grad_bytes + 15) & ~(size_t)15);
+    j.off_gimg = j.off_img + j.img_bytes;
+    {
+        const size_t need = j.off_gimg + j.img_bytes;
+        if (ctx->h_stage_cap < need) {
+            if (ctx->h_stage)
+                (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr;
+            ctx->h_stage_cap = 0;
+            HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage, need));
+            ctx->h_stage_cap = need;
+        }
+    }
+    if (!j.dev_out) {
+        const size_t row_bytes = (size_t)j.cam.width * 3 * sizeof(float);
+        hipError_t e = hipSuccess;
+        auto rows_to_stage = [&](const float* d_src, size_t off) {
+            for_each_band(j.cam.height, j.band, j.n_shards, j.shard, [&](int y0, int y1) {
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(ctx->h_stage + off + (size_t)y0 * row_bytes, (const uint8_t*)d_src + (size_t)y0 * row_bytes,
+                                       (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            });
+        };
+        if (j.out_rgb && j.n_local_pixels)
+            rows_to_stage(j.d_out, j.off_img);
+        if (j.gimg_param >= 0 && j.out_gimg && j.n_local_pixels)
+            rows_to_stage(j.d_gimg, j.off_gimg);
+        HIPCHK(ctx, e);
+        if (j.backward && j.out_param_grad && with_grad)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + j.off_grad, ctx->grad.p, j.grad_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->h_segments = 0;
+    j.want_segments = j.stats && j.n_count_words;
+    if (j.want_segments)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    return DRT_OK;
+}
+
+// phase 4: wait (unless the caller asked for an asynchronous device-pointer render), hand over, statistics
+static int render_finish(drt_hip_ctx* ctx, bool with_grad = true)
+{
+    RenderJob& j = ctx->job;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (j.sync)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h_tot[4] = {0, 0, 0, 0};
+    if (j.want_segments)
+        memcpy(h_tot, ctx->h_stage, sizeof h_tot);
+    ctx->h_segments = h_tot[0];
+    if (!j.dev_out) {
+        const size_t row_bytes = (size_t)j.cam.width * 3 * sizeof(float);
+        auto rows_to_caller = [&](float* dst, size_t off) {
+            for_each_band(j.cam.height, j.band, j.n_shards, j.shard, [&](int y0, int y1) {
+                memcpy((uint8_t*)dst + (size_t)y0 * row_bytes, ctx->h_stage + off + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes);
+            });
+        };
+        if (j.out_rgb && j.n_local_pixels)
+            rows_to_caller(j.out_rgb, j.off_img);
+        if (j.gimg_param >= 0 && j.out_gimg && j.n_local_pixels)
+            rows_to_caller(j.out_gimg, j.off_gimg);
+        if (j.backward && j.out_param_grad && with_grad) {
+            memcpy(j.out_param_grad, ctx->h_stage + j.off_grad, j.grad_bytes);
+            for (int p = 0; p < ctx->n_user_params; ++p)
+                if (!ctx->requires_grad[p])
+                    j.out_param_grad[p * 3] = j.out_param_grad[p * 3 + 1] = j.out_param_grad[p * 3 + 2] = 0.0;
+        }
+    }
+    if (j.stats) {
+        drt_hip_stats& st = j.st;
+        st.segments = h_tot[0];
+        st.queue_rays_read = h_tot[1];
+        st.queue_rays_written = h_tot[2];
+        st.capped_paths = h_tot[3];
+        st.bvh_bytes = ctx->has_mesh ? ctx->bvh_bytes : 0;
+        st.units[DRT_K_INTERSECT] = st.launches[DRT_K_INTERSECT] ? st.segments : 0;
+        st.units[DRT_K_INTERSECT_MESH] = st.launches[DRT_K_INTERSECT_MESH] ? st.segments : 0;
+        st.units[DRT_K_SHADE] = st.launches[DRT_K_SHADE] ? st.segments : 0;
+        st.units[DRT_K_PATH] = st.launches[DRT_K_PATH] ? st.segments : 0;
+        st.units[DRT_K_BACKWARD] = j.backward && st.launches[DRT_K_BACKWARD] ? st.segments : 0;
+        if (j.timing) {
+            for (const TimedLaunch& t : ctx->timed) {
+                float ms = 0;
+                HIPCHK(ctx, hipEventElapsedTime(&ms, t.e0, t.e1));
+                st.ms_kernel[t.kernel] += (double)ms;
+            }
+        }
+        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j.t0).count();
+        *j.stats = st;
+    }
+    return DRT_OK;
+}
+
+__global__ void __launch_bounds__(DRT_BLOCK) k_add_f64(double* __restrict__ dst, const double* __restrict__ src, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] += src[i];
+}
+
+// A group context: every phase on ALL members before the next one, so n devices run concurrently under this one
+// host thread.  The gradient: members that share a device are added to their leader on that device (stream-ordered
+// through events), then ONE ncclAllReduce over the leaders -- the single collective of the path.
+static int render_group(drt_hip_ctx* g, const drt_camera_desc* cam, const drt_render_params* rp, const float* adjoint_rgb,
+                        float* out_rgb, double* out_param_grad, drt_hip_stats* stats, int gimg_param, float* out_gimg)
+{
+    if (!cam || !rp)
+        return fail(g, DRT_ERR_INVALID, "render: bad camera or render parameters");
+    if (rp->flags & DRT_RENDER_DEVICE_OUT)
+        return fail(g, DRT_ERR_UNSUPPORTED, "render: a group context returns through host buffers (no DRT_RENDER_DEVICE_OUT)");
+    const bool backward = (rp->flags & DRT_RENDER_BACKWARD) != 0;
+    if (backward && !out_param_grad && gimg_param < 0)
+        return fail(g, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int n = (int)g->members.size();
+    const int outer = rp->n_shards > 1 ? rp->n_shards : 1, outer_shard = rp->n_shards > 1 ? rp->shard : 0;
+    if (outer_shard < 0 || outer_shard >= outer)
+        return fail(g, DRT_ERR_INVALID, "render: shard out of range");
+    std::vector<drt_hip_stats> mstats((size_t)n);
+    auto member_fail = [&](int i, int rc) { g->err = "device " + std::to_string(g->members[i]->device) + ": " + g->members[i]->err; return rc; };
+    int rc;
+    for (int i = 0; i < n; ++i) {
+        drt_render_params r = *rp;
+        r.n_shards = outer * n;
+        r.shard = outer_shard * n + i;
+        r.flags &= ~(uint32_t)DRT_RENDER_ALLREDUCE;        // the group reduces below
+        if ((rc = render_launch(g->members[i], cam, &r, adjoint_rgb, out_rgb, out_param_grad, stats ? &mstats[i] : nullptr,
+                                gimg_param, out_gimg)) != DRT_OK)
+            return member_fail(i, rc);
+    }
+    if (backward && gimg_param < 0) {
+        const int words = g->members[0]->n_user_params * 3;
+        for (int i = 0; i < n; ++i) {
+            drt_hip_ctx* m = g->members[i];
+            if (g->leader[i] == i)
+                continue;
+            drt_hip_ctx* l = g->members[g->leader[i]];
+            HIPCHK(m, hipSetDevice(m->device));
+            HIPCHK(m, hipEventRecord(m->ev_done, m->stream));
+            HIPCHK(l, hipStreamWaitEvent(l->stream, m->ev_done, 0));
+            hipLaunchKernelGGL(k_add_f64, dim3((words + DRT_BLOCK - 1) / DRT_BLOCK), dim3(DRT_BLOCK), 0, l->stream,
+                               (double*)l->grad.p, (const double*)m->grad.p, words);
+        }
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i) {
+            drt_hip_ctx* m = g->members[i];
+            if (g->leader[i] != i)
+                continue;
+            r = ncclAllReduce(m->grad.p, m->grad.p, (size_t)words, ncclDouble, ncclSum, m->comm, m->stream);
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r != ncclSuccess || r2 != ncclSuccess) {
+            g->err = std::string("ncclAllReduce (group): ") + ncclGetErrorString(r != ncclSuccess ? r : r2);
+            return DRT_ERR_COMM;
+        }
+    }
+    for (int i = 0; i < n; ++i)        // every member copies its rows; member 0 (a leader) the reduced gradient
+        if ((rc = render_collect(g->members[i], i == 0)) != DRT_OK)
+            return member_fail(i, rc);
+    for (int i = 0; i < n; ++i)
+        if ((rc = render_finish(g->members[i], i == 0)) != DRT_OK)
+            return member_fail(i, rc);
+    if (stats) {
+        drt_hip_stats st = mstats[0];
+        for (int i = 1; i < n; ++i) {
+            st.paths += mstats[i].paths;
+            st.segments += mstats[i].segments;
+            st.batches += mstats[i].batches;
+            st.queue_rays_read += mstats[i].queue_rays_read;
+            st.queue_rays_written += mstats[i].queue_rays_written;
+            st.capped_paths += mstats[i].capped_paths;
+            for (int k = 0; k < DRT_K_COUNT; ++k) {
+                st.units[k] += mstats[i].units[k];
+                if (mstats[i].ms_kernel[k] > st.ms_kernel[k])
+                    st.ms_kernel[k] = mstats[i].ms_kernel[k];      // devices run side by side: the slowest counts
+            }
+        }
+        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *stats = st;
+    }
+    return DRT_OK;
+}
+
 static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                          const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
-                         int gimg_param, float* out_gimg);
+                         int gimg_param, float* out_gimg)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (!ctx->members.empty())
+        return render_group(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
+    int rc;
+    if ((rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg)) != DRT_OK) return rc;
+    if ((rc = render_reduce(ctx)) != DRT_OK) return rc;
+    if ((rc = render_collect(ctx)) != DRT_OK) return rc;
+    return render_finish(ctx);
+}
+
+extern "C" {
 
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats)
@@ -999,196 +1403,183 @@ int drt_hip_render_gradient_image(drt_hip_ctx* ctx, const drt_camera_desc* cam, 
 {
     if (!ctx)
         return DRT_ERR_INVALID;
-    if (!ctx->has_scene)
+    drt_hip_ctx* first = ctx->members.empty() ? ctx : ctx->members[0];
+    if (!first->has_scene)
         return fail(ctx, DRT_ERR_NO_SCENE, "render before upload_scene");
-    if (!rp || !out_grad_rgb || param < 0 || param >= ctx->n_user_params)
+    if (!rp || !out_grad_rgb || param < 0 || param >= first->n_user_params)
         return fail(ctx, DRT_ERR_INVALID, "gradient image: bad parameter index or NULL output");
     drt_render_params r = *rp;
     r.flags |= DRT_RENDER_BACKWARD;
     return render_common(ctx, cam, &r, adjoint_rgb, out_rgb, nullptr, stats, param, out_grad_rgb);
 }
 
-static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
-                         const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
-                         int gimg_param, float* out_gimg)
+// ---- multi-GPU: communicators and group contexts -------------------------------------------------
+static int comm_fail(drt_hip_ctx* ctx, const char* what, ncclResult_t r)
+{
+    if (ctx)
+        ctx->err = std::string(what) + ": " + ncclGetErrorString(r);
+    return DRT_ERR_COMM;
+}
+
+int drt_hip_comm_unique_id(drt_hip_unique_id* out)
+{
+    static_assert(sizeof(ncclUniqueId) == DRT_HIP_UNIQUE_ID_BYTES, "drt_hip_unique_id is an ncclUniqueId");
+    if (!out)
+        return DRT_ERR_INVALID;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess)
+        return DRT_ERR_COMM;
+    memcpy(out->bytes, &id, sizeof id);
+    return DRT_OK;
+}
+
+int drt_hip_comm_init_rank(drt_hip_ctx* ctx, const drt_hip_unique_id* id, int rank, int n_ranks)
+{
+    if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return ctx ? fail(ctx, DRT_ERR_INVALID, "comm_init_rank: bad arguments") : DRT_ERR_INVALID;
+    if (!ctx->members.empty())
+        return fail(ctx, DRT_ERR_INVALID, "comm_init_rank: a group context owns its communicators already");
+    if (ctx->comm)
+        return fail(ctx, DRT_ERR_INVALID, "comm_init_rank: the context already has a communicator");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId nid;
+    memcpy(&nid, id->bytes, sizeof nid);
+    const ncclResult_t r = ncclCommInitRank(&ctx->comm, n_ranks, nid, rank);
+    if (r != ncclSuccess) {
+        ctx->comm = nullptr;
+        return comm_fail(ctx, "ncclCommInitRank", r);
+    }
+    ctx->comm_rank = rank;
+    ctx->comm_size = n_ranks;
+    return DRT_OK;
+}
+
+int drt_hip_comm_size(const drt_hip_ctx* ctx)
+{
+    if (!ctx)
+        return 0;
+    if (!ctx->members.empty())
+        return ctx->members[0]->comm_size;
+    return ctx->comm ? ctx->comm_size : 0;
+}
+
+int drt_hip_comm_destroy(drt_hip_ctx* ctx)
 {
     if (!ctx)
         return DRT_ERR_INVALID;
-    if (!ctx->has_scene)
-        return fail(ctx, DRT_ERR_NO_SCENE, "render before upload_scene");
-    if (!cam || !rp || cam->width <= 0 || cam->height <= 0 || rp->spp <= 0 || rp->min_bounces < 0 ||
-        !(rp->absorb >= 0.0 && rp->absorb <= 1.0))
-        return fail(ctx, DRT_ERR_INVALID, "render: bad camera or render parameters");
-    if ((uint64_t)cam->width * (uint64_t)cam->height >= 0xFFFFFFFFull)
-        return fail(ctx, DRT_ERR_INVALID, "render: image too large");
-    const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;
-    const int band = rp->band_rows > 0 ? rp->band_rows : 1;
-    if (n_shards > 1 && (rp->shard < 0 || rp->shard >= n_shards))
-        return fail(ctx, DRT_ERR_INVALID, "render: shard out of range");
-    const bool backward = (rp->flags & DRT_RENDER_BACKWARD) != 0;
-    const bool dev_out = (rp->flags & DRT_RENDER_DEVICE_OUT) != 0;
-    const bool timing = (rp->flags & DRT_RENDER_TIMING) != 0;
-    const bool f64 = (rp->flags & DRT_RENDER_F64) != 0;
-    if (backward && !out_param_grad && gimg_param < 0)
-        return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
-
-    auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-
-    // rows owned by this shard
-    uint32_t local_rows = 0;
-    for (int y = 0; y < cam->height; ++y)
-        if (n_shards == 1 || (y / band) % n_shards == rp->shard)
-            ++local_rows;
-    const uint32_t n_local_pixels = local_rows * (uint32_t)cam->width;
-
-    // deepest vertex a path can reach: absorb == 1 kills every path at depth min_bounces
-    int depth_cap = rp->max_depth > 0 ? rp->max_depth : 64;
-    if (rp->absorb >= 1.0 && rp->min_bounces < depth_cap)
-        depth_cap = rp->min_bounces;
-
-    drt_hip_stats st;
-    memset(&st, 0, sizeof st);
-    ctx->events_used = 0;
-    ctx->timed.clear();
-
-    int rc;
-    const size_t npix_all = (size_t)cam->width * cam->height;
-    float* d_out = nullptr;
-    const float* d_adj = nullptr;
-    if (out_rgb) {
-        if ((rc = ensure(ctx, ctx->film, (size_t)(n_local_pixels ? n_local_pixels : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->film.p, 0, (size_t)(n_local_pixels ? n_local_pixels : 1) * 3 * sizeof(double), ctx->stream));
-        if (dev_out) {
-            d_out = out_rgb;
-        } else {
-            if ((rc = ensure(ctx, ctx->out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
-            d_out = (float*)ctx->out.p;
-            if (n_shards > 1)   // rows of other shards must come back untouched
-                HIPCHK(ctx, hipMemcpyAsync(d_out, out_rgb, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        }
-    }
-    if (backward) {
-        if ((rc = ensure(ctx, ctx->grad, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double), ctx->stream));
-        if (adjoint_rgb) {
-            if (dev_out) {
-                d_adj = adjoint_rgb;
-            } else {
-                if ((rc = ensure(ctx, ctx->adjoint, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
-                HIPCHK(ctx, hipMemcpyAsync(ctx->adjoint.p, adjoint_rgb, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-                d_adj = (const float*)ctx->adjoint.p;
-            }
-        }
-    }
-    float* d_gimg = nullptr;
-    if (gimg_param >= 0) {
-        const size_t fb = (size_t)(n_local_pixels ? n_local_pixels : 1) * 3 * sizeof(double);
-        if ((rc = ensure(ctx, ctx->gfilm, fb)) != DRT_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->gfilm.p, 0, fb, ctx->stream));
-        if (dev_out) {
-            d_gimg = out_gimg;
-        } else {
-            if ((rc = ensure(ctx, ctx->gimg_out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
-            d_gimg = (float*)ctx->gimg_out.p;
-            if (n_shards > 1)
-                HIPCHK(ctx, hipMemcpyAsync(d_gimg, out_gimg, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        }
-    }
-    size_t n_count_words = 0;
-    double* d_film = out_rgb ? (double*)ctx->film.p : nullptr;   // no image requested: skip K5
-    rc = DRT_OK;
-    if (n_local_pixels > 0) {
-        if (f64)
-            rc = render_impl<double>(ctx, cam, rp, d_adj, d_out, backward, timing, &st, n_local_pixels,
-                                     depth_cap, &n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, d_gimg);
-        else
-            rc = render_impl<float>(ctx, cam, rp, d_adj, d_out, backward, timing, &st, n_local_pixels,
-                                    depth_cap, &n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, d_gimg);
-    }
-    if (rc != DRT_OK)
-        return rc;
-
-    // parameters that do not require grad keep a zero gradient (vector.hpp:156-162)
-    if (backward && dev_out && out_param_grad) {
-        for (int p = 0; p < ctx->n_user_params; ++p)
-            if (!ctx->requires_grad[p])
-                HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad.p + (size_t)p * 3, 0, 3 * sizeof(double), ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(out_param_grad, ctx->grad.p, (size_t)ctx->n_user_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    }
-
-    const bool sync = !dev_out || (rp->flags & DRT_RENDER_SYNC) || timing || stats;
-    const size_t img_bytes = npix_all * 3 * sizeof(float), grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
-    const size_t off_grad = 32, off_img = off_grad + ((grad_bytes + 15) & ~(size_t)15), off_gimg = off_img + img_bytes;
-    {
-        const size_t need = off_gimg + img_bytes;
-        if (ctx->h_stage_cap < need) {
-            if (ctx->h_stage)
-                (void)hipHostFree(ctx->h_stage);
-            ctx->h_stage = nullptr;
-            ctx->h_stage_cap = 0;
-            HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage, need));
-            ctx->h_stage_cap = need;
-        }
-    }
-    if (!dev_out) {
-        if (out_rgb)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + off_img, d_out, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        if (backward && out_param_grad)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + off_grad, ctx->grad.p, grad_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        if (gimg_param >= 0 && out_gimg)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage + off_gimg, d_gimg, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    ctx->h_segments = 0;
-    const bool want_segments = stats && n_count_words;
-    if (want_segments)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    if (sync)
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h_queue[2] = {0, 0};
-    if (want_segments) {
-        memcpy(&ctx->h_segments, ctx->h_stage, sizeof(unsigned long long));
-        memcpy(h_queue, ctx->h_stage + sizeof(unsigned long long), sizeof h_queue);
-    }
-    if (!dev_out) {
-        if (out_rgb)
-            memcpy(out_rgb, ctx->h_stage + off_img, img_bytes);
-        if (backward && out_param_grad)
-            memcpy(out_param_grad, ctx->h_stage + off_grad, grad_bytes);
-        if (gimg_param >= 0 && out_gimg)
-            memcpy(out_gimg, ctx->h_stage + off_gimg, img_bytes);
-    }
-    if (!dev_out && backward && out_param_grad)
-        for (int p = 0; p < ctx->n_user_params; ++p)
-            if (!ctx->requires_grad[p])
-                out_param_grad[p * 3] = out_param_grad[p * 3 + 1] = out_param_grad[p * 3 + 2] = 0.0;
-
-    if (stats) {
-        st.segments = ctx->h_segments;
-        st.queue_rays_read = h_queue[0];
-        st.queue_rays_written = h_queue[1];
-        st.units[DRT_K_INTERSECT] = st.segments;
-        st.units[DRT_K_SHADE] = st.segments;
-        st.units[DRT_K_BACKWARD] = backward ? st.segments : 0;
-        if (timing) {
-            for (const TimedLaunch& t : ctx->timed) {
-                float ms = 0;
-                HIPCHK(ctx, hipEventElapsedTime(&ms, t.e0, t.e1));
-                st.ms_kernel[t.kernel] += (double)ms;
-            }
-        }
-        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        *stats = st;
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream)
+            (void)hipStreamSynchronize(ctx->stream);
+        (void)ncclCommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_size = 0;
     }
     return DRT_OK;
 }
 
-void* drt_hip_stream(drt_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int drt_hip_create_group(const int* device_ids, int n_devices, drt_hip_ctx** out)
+{
+    if (!out)
+        return DRT_ERR_INVALID;
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64)
+        return DRT_ERR_INVALID;
+    drt_hip_ctx* g = new drt_hip_ctx();
+    g->device = device_ids[0];
+    std::vector<int> distinct;           // the devices of the communicator, in order of first appearance
+    for (int i = 0; i < n_devices; ++i) {
+        drt_hip_ctx* m = nullptr;
+        const int rc = drt_hip_create(device_ids[i], &m);
+        if (rc != DRT_OK) {
+            drt_hip_destroy(g);
+            return rc;
+        }
+        m->is_member = true;
+        g->members.push_back(m);
+        int lead = i;
+        for (int e = 0; e < i; ++e)
+            if (device_ids[e] == device_ids[i]) { lead = e; break; }
+        g->leader.push_back(lead);
+        if (lead == i)
+            distinct.push_back(device_ids[i]);
+        if (hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess) {
+            drt_hip_destroy(g);
+            return DRT_ERR_HIP;
+        }
+    }
+    std::vector<ncclComm_t> comms(distinct.size(), nullptr);
+    if (ncclCommInitAll(comms.data(), (int)distinct.size(), distinct.data()) != ncclSuccess) {
+        drt_hip_destroy(g);
+        return DRT_ERR_COMM;
+    }
+    for (int i = 0, k = 0; i < n_devices; ++i)
+        if (g->leader[i] == i) {
+            g->members[i]->comm = comms[k];
+            g->members[i]->comm_rank = k;
+            g->members[i]->comm_size = (int)distinct.size();
+            ++k;
+        }
+    *out = g;
+    return DRT_OK;
+}
+
+int drt_hip_group_size(const drt_hip_ctx* ctx) { return ctx ? (ctx->members.empty() ? 1 : (int)ctx->members.size()) : 0; }
+
+int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (ctx->members.empty())
+        return upload_scene_one(ctx, s);
+    for (drt_hip_ctx* m : ctx->members) {
+        const int rc = upload_scene_one(m, s);
+        if (rc != DRT_OK) {
+            ctx->err = m->err;
+            return rc;
+        }
+    }
+    ctx->has_scene = true;
+    return DRT_OK;
+}
+
+int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (ctx->members.empty())
+        return update_params_one(ctx, params);
+    for (drt_hip_ctx* m : ctx->members) {
+        const int rc = update_params_one(m, params);
+        if (rc != DRT_OK) {
+            ctx->err = m->err;
+            return rc;
+        }
+    }
+    return DRT_OK;
+}
+
+void* drt_hip_stream(drt_hip_ctx* ctx)
+{
+    if (!ctx)
+        return nullptr;
+    return (void*)(ctx->members.empty() ? ctx->stream : ctx->members[0]->stream);
+}
 
 int drt_hip_synchronize(drt_hip_ctx* ctx)
 {
     if (!ctx)
         return DRT_ERR_INVALID;
+    if (!ctx->members.empty()) {
+        for (drt_hip_ctx* m : ctx->members) {
+            const int rc = drt_hip_synchronize(m);
+            if (rc != DRT_OK) {
+                ctx->err = m->err;
+                return rc;
+            }
+        }
+        return DRT_OK;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return DRT_OK;
@@ -1199,7 +1590,7 @@ const char* drt_hip_last_error(drt_hip_ctx* ctx) { return ctx ? ctx->err.c_str()
 const char* drt_hip_kernel_name(int k)
 {
     static const char* names[DRT_K_COUNT] = {"k_raygen", "k_intersect", "k_shade", "k_film",
-                                             "k_backward", "k_gradreduce", "", ""};
+                                             "k_backward", "k_gradreduce", "k_intersect_mesh", "k_path"};
     return (k >= 0 && k < DRT_K_COUNT) ? names[k] : "";
 }
 

@@ -1077,6 +1077,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
             const bool next_cap = (kk + 1) >= a.depth_cap;
             TapeRec<R>* __restrict__ tape_kk = tape_k + (size_t)it * N;
             alive = false;
+            bool capped = false;                                   // cut short by max_depth (not by the roulette)
             if (live) {
                 HitRec<R> h;
                 if (FUSED) {
@@ -1127,6 +1128,9 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                         alive = !next_cap;
                         if (alive && next_rr)
                             alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                        // a user max_depth ends the path here: had the reference's roulette let it live?
+                        if (next_cap && !a.cap_is_roulette)
+                            capped = !next_rr || !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
                         tr.m = mk_;
                         tr.ids = (uint32_t)m.param | (eid << 16);
                         ended = !alive;
@@ -1146,6 +1150,11 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                     if (ended)
                         nv[pid] = n_vertices;
                 }
+            }
+            if (next_cap && !a.cap_is_roulette) {                  // row D of the counts: paths the cap cut short
+                const uint32_t n_cap = (uint32_t)__popcll(__ballot(capped));
+                if (lane == 0 && n_cap)
+                    atomicAdd(counts_k + (size_t)(it + 1) * count_stride + w, n_cap);
             }
             if (it + 1 >= nb)
                 break;
@@ -1189,7 +1198,8 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         running += n_alive;
         if (nw != w) {                                         // region finished
             if (lane == 0) {
-                counts_next[w] = running;
+                if (k + nb < a.depth_cap)                      // (row depth_cap counts capped paths, see above)
+                    counts_next[w] = running;
                 if (CAM)
                     counts_k[w] = cnt;                         // depth 0: every path of the region
             }
@@ -1230,15 +1240,17 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
 // segments of one batch = rays queued at depths 0..D-1, summed over regions -> 64-bit total
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned long long* __restrict__ total,
-             uint32_t row_words, unsigned long long read_rows, unsigned long long written_rows)
+             uint32_t row_words, unsigned long long read_rows, unsigned long long written_rows, uint32_t cap_row)
 {
-    // total[0] += all words (= segments); total[1] += the rows a shade launch STARTED from (rays read from
-    // the queue), total[2] += the rows a launch ended on (survivors written back); row r = bit r of the masks
-    __shared__ unsigned long long red[3][DRT_BLOCK / DRT_WAVE];
-    unsigned long long v = 0, vr = 0, vw = 0;
+    // total[0] += all words of rows != cap_row (= segments); total[1] += the rows a shade launch STARTED from (rays
+    // read from the queue), total[2] += the rows a launch ended on (survivors written back); row r = bit r of the
+    // masks; total[3] += row cap_row (paths that were still alive when the depth cap cut them: never queued)
+    __shared__ unsigned long long red[4][DRT_BLOCK / DRT_WAVE];
+    unsigned long long v = 0, vr = 0, vw = 0, vc = 0;
     for (uint32_t i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n_words; i += gridDim.x * DRT_BLOCK) {
         const unsigned long long c = counts[i];
         const uint32_t row = row_words ? i / row_words : 0u;
+        if (row == cap_row) { vc += c; continue; }
         v += c;
         if (row < 64u && ((read_rows >> row) & 1ull)) vr += c;
         if (row < 64u && ((written_rows >> row) & 1ull)) vw += c;
@@ -1247,14 +1259,16 @@ k_sum_counts(const uint32_t* __restrict__ counts, uint32_t n_words, unsigned lon
         v += __shfl_down(v, off);
         vr += __shfl_down(vr, off);
         vw += __shfl_down(vw, off);
+        vc += __shfl_down(vc, off);
     }
     if ((threadIdx.x & (DRT_WAVE - 1)) == 0) {
         red[0][threadIdx.x / DRT_WAVE] = v;
         red[1][threadIdx.x / DRT_WAVE] = vr;
         red[2][threadIdx.x / DRT_WAVE] = vw;
+        red[3][threadIdx.x / DRT_WAVE] = vc;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         unsigned long long t = 0;
         for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
             t += red[threadIdx.x][w];

@@ -7,7 +7,9 @@
 // scene parameters by tape-node identity (handles share nodes: `white` feeds two materials in
 // render.cpp:28,34-35), uploads the POD scene, renders on one or several MI355X devices and, when
 // options.backward is set, ADDS the returned gradients into param.grad() -- the accumulate
-// semantics of VariableNode::backward (vector.hpp:185-188).
+// semantics of VariableNode::backward (vector.hpp:185-188).  Several devices = ONE group context
+// (drt_hip_create_group): the library deals the row bands to the devices, runs them side by side and
+// sums the gradient vector across them with a single RCCL all-reduce; this header adds nothing.
 //
 // No CPU fallback: if libdrt_hip.so cannot create a context this throws std::runtime_error.
 #pragma once
@@ -18,7 +20,6 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../drt_hip.h"
@@ -33,7 +34,8 @@ struct Options {
     bool unbiased = false;          // backward with the unbiased integration operator (integrate.hpp:39-52)
     uint32_t seed = 1;
     int max_depth = 0;              // 0 = library default (64)
-    std::vector<int> devices = {0}; // pixel-row bands are dealt round-robin to these devices
+    std::vector<int> devices = {0}; // pixel-row bands are dealt round-robin to these devices (several: one group
+                                    // context, gradients reduced across them by RCCL inside the library)
     int band_rows = 16;
     bool f64 = false;               // verification mode: compute in double on the device
     long long batch_paths = 0;
@@ -43,6 +45,7 @@ struct Options {
 
 struct Stats {
     unsigned long long paths = 0, segments = 0;
+    unsigned long long capped_paths = 0;   // paths Options::max_depth cut short (the reference has no cap)
     double ms = 0;
 };
 
@@ -223,12 +226,21 @@ inline drt_camera_desc describe(const Camera<T>& cam)
 
 class Context {
 public:
-    explicit Context(int device)
+    explicit Context(int device) : Context(std::vector<int>{device}) {}
+    // one device: a plain context; several: a group context (the library owns the RCCL communicators)
+    explicit Context(const std::vector<int>& devices)
     {
-        const int rc = drt_hip_create(device, &m_ctx);
-        if (rc != DRT_OK)
-            throw std::runtime_error("drt_hip_create(device " + std::to_string(device) + ") failed with status " +
-                                     std::to_string(rc) + " (no HIP device? there is no CPU fallback)");
+        if (devices.empty())
+            throw std::runtime_error("drt::hip::Context: no device given");
+        const int rc = devices.size() == 1 ? drt_hip_create(devices[0], &m_ctx)
+                                           : drt_hip_create_group(devices.data(), (int)devices.size(), &m_ctx);
+        if (rc != DRT_OK) {
+            std::string list;
+            for (int d : devices)
+                list += (list.empty() ? "" : ", ") + std::to_string(d);
+            throw std::runtime_error("drt_hip_create" + std::string(devices.size() == 1 ? "" : "_group") + "(device " + list +
+                                     ") failed with status " + std::to_string(rc) + " (no HIP device? there is no CPU fallback)");
+        }
     }
     ~Context() { drt_hip_destroy(m_ctx); }
     Context(const Context&) = delete;
@@ -266,14 +278,13 @@ private:
 
 // Contexts are kept between calls: creating one (HIP module load, stream) and growing its queues
 // (gigabytes of hipMalloc for a 512 x 512 x 64 frame) costs ~0.3 s, a render 2 ms -- an optimisation
-// loop around drt::hip::render must not pay that per iteration.  One context per (device, slot); slot
-// distinguishes several entries of Options::devices that name the same device.  They live until
-// release_contexts() or process exit (deliberately not destroyed by static destructors: the HIP
-// runtime may be gone by then).
+// loop around drt::hip::render must not pay that per iteration.  One context per device list (a
+// group context for several devices).  They live until release_contexts() or process exit
+// (deliberately not destroyed by static destructors: the HIP runtime may be gone by then).
 namespace detail {
 struct ContextPool {
     std::mutex m;
-    std::map<std::pair<int, int>, Context*> contexts;
+    std::map<std::vector<int>, Context*> contexts;
 };
 inline ContextPool& pool()
 {
@@ -282,15 +293,16 @@ inline ContextPool& pool()
 }
 } // namespace detail
 
-inline Context& pooled_context(int device, int slot = 0)
+inline Context& pooled_context(const std::vector<int>& devices)
 {
     detail::ContextPool& p = detail::pool();
     std::lock_guard<std::mutex> lock(p.m);
-    Context*& c = p.contexts[std::make_pair(device, slot)];
+    Context*& c = p.contexts[devices];
     if (!c)
-        c = new Context(device);
+        c = new Context(devices);
     return *c;
 }
+inline Context& pooled_context(int device) { return pooled_context(std::vector<int>{device}); }
 
 inline void release_contexts()
 {
@@ -321,78 +333,49 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
                 adj[i * 3 + c] = float(real(adjoint[i][c]));
     }
     const std::size_t P = flat.requires_grad.size();
-    std::vector<std::vector<float>> frames(n_dev, std::vector<float>(npix * 3, 0.f));
-    std::vector<std::vector<double>> grads(n_dev, std::vector<double>(P * 3, 0.0));
-    std::vector<drt_hip_stats> stats(n_dev);
-    std::vector<std::string> errors(n_dev);
-
-    auto work = [&](int d) {
-        try {
-            int slot = 0;                                      // how many earlier entries name the same device
-            for (int e = 0; e < d; ++e)
-                slot += opt.devices[e] == opt.devices[d] ? 1 : 0;
-            std::unique_ptr<Context> own;
-            if (!opt.reuse_context)
-                own.reset(new Context(opt.devices[d]));
-            Context& ctx = own ? *own : pooled_context(opt.devices[d], slot);
-            std::lock_guard<std::mutex> lock(ctx.mutex());
-            ctx.set_scene(flat);
-            drt_render_params rp{};
-            rp.spp = (int32_t)spp;
-            rp.min_bounces = (int32_t)tracer.min_bounces();
-            rp.absorb = tracer.absorb();
-            rp.max_depth = opt.max_depth;
-            rp.seed = opt.seed;
-            rp.shard = d;
-            rp.n_shards = n_dev;
-            rp.band_rows = opt.band_rows;
-            rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
-                       (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
-            rp.batch_paths = opt.batch_paths;
-            rp.bounces_per_launch = opt.bounces_per_launch;
-            ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, frames[d].data(),
-                                     opt.backward ? grads[d].data() : nullptr, &stats[d]),
-                      "drt_hip_render");
-        } catch (const std::exception& e) {
-            errors[d] = e.what();
-        }
-    };
-    if (n_dev == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int d = 0; d < n_dev; ++d)
-            pool.emplace_back(work, d);
-        for (auto& t : pool)
-            t.join();
+    std::vector<float> frame(npix * 3, 0.f);
+    std::vector<double> grads(P * 3, 0.0);
+    drt_hip_stats st{};
+    {
+        std::unique_ptr<Context> own;
+        if (!opt.reuse_context)
+            own.reset(new Context(opt.devices));
+        Context& ctx = own ? *own : pooled_context(opt.devices);
+        std::lock_guard<std::mutex> lock(ctx.mutex());
+        ctx.set_scene(flat);
+        drt_render_params rp{};
+        rp.spp = (int32_t)spp;
+        rp.min_bounces = (int32_t)tracer.min_bounces();
+        rp.absorb = tracer.absorb();
+        rp.max_depth = opt.max_depth;
+        rp.seed = opt.seed;
+        rp.shard = 0;
+        rp.n_shards = 1;                // a group context deals the bands to its devices itself
+        rp.band_rows = opt.band_rows;
+        rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
+                   (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
+        rp.batch_paths = opt.batch_paths;
+        rp.bounces_per_launch = opt.bounces_per_launch;
+        // n_dev > 1: out_param_grad comes back ALREADY summed over the devices (one ncclAllReduce in the library)
+        ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, frame.data(),
+                                 opt.backward ? grads.data() : nullptr, &st),
+                  "drt_hip_render");
     }
-    for (const std::string& e : errors)
-        if (!e.empty())
-            throw std::runtime_error(e);
-
-    // disjoint rows: every device left the other shards' rows at zero
-    Stats total;
     for (std::size_t i = 0; i < npix; ++i)
-        for (int c = 0; c < 3; ++c) {
-            float v = 0.f;
-            for (int d = 0; d < n_dev; ++d)
-                v += frames[d][i * 3 + c];
-            img[i][c] = T(v);
-        }
-    for (int d = 0; d < n_dev; ++d) {
-        total.paths += stats[d].paths;
-        total.segments += stats[d].segments;
-        if (stats[d].ms_total > total.ms)
-            total.ms = stats[d].ms_total;
-    }
+        for (int c = 0; c < 3; ++c)
+            img[i][c] = T(frame[i * 3 + c]);
+    Stats total;
+    total.paths = st.paths;
+    total.segments = st.segments;
+    total.capped_paths = st.capped_paths;
+    total.ms = st.ms_total;
     if (opt.backward) {
         for (std::size_t p = 0; p < P; ++p) {
             if (!flat.requires_grad[p])
                 continue;
             Vector<T, 3> g(T(0));
-            for (int d = 0; d < n_dev; ++d)
-                for (int c = 0; c < 3; ++c)
-                    g[c] += T(grads[d][p * 3 + c]);
+            for (int c = 0; c < 3; ++c)
+                g[c] = T(grads[p * 3 + c]);
             flat.handles[p].grad() += g;          // accumulate, like m_grad += grad
         }
     }

@@ -25,6 +25,16 @@
  * set (then outputs are device pointers, written on the context's stream, and the call returns
  * after enqueueing unless DRT_RENDER_SYNC is also set).
  *
+ *   drt_hip_create_group    the same path on SEVERAL GPUs of one node from one process (SURVEY 8b:
+ *   drt_hip_comm_init_rank  "ctx owns device memory/streams/RCCL comms"): the rows of the frame are
+ *                           dealt to the devices in interleaved bands, every device runs the whole
+ *                           pipeline on its bands, and the ONE cross-device step is the reduction of
+ *                           the gradient accumulator VariableNode::backward's `m_grad += grad`
+ *                           (include/drt/vector.hpp:185-188): one ncclAllReduce(sum, f64, P x 3) over
+ *                           xGMI, enqueued by the library on the context's stream after K7.
+ *                           create_group = one process, n devices; comm_init_rank = one process per
+ *                           GPU (the launcher broadcasts the 128-byte id out of band).
+ *
  * There is NO CPU fallback behind this ABI: without a HIP device drt_hip_create fails with
  * DRT_ERR_NO_DEVICE.
  */
@@ -38,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 3
+#define DRT_HIP_ABI_VERSION 4
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -47,7 +57,8 @@ typedef enum drt_status {
     DRT_ERR_HIP = -3,         /* a HIP runtime call failed, see drt_hip_last_error */
     DRT_ERR_NO_SCENE = -4,    /* render before upload_scene */
     DRT_ERR_OOM = -5,         /* device allocation failed */
-    DRT_ERR_UNSUPPORTED = -6  /* feature reserved in the ABI but not built yet */
+    DRT_ERR_UNSUPPORTED = -6, /* the request is outside what the device path covers (see drt_hip_last_error) */
+    DRT_ERR_COMM = -7         /* an RCCL call failed, see drt_hip_last_error */
 } drt_status;
 
 /* ---- scene description (host-side POD, doubles: the reference computes in double,
@@ -117,6 +128,11 @@ typedef struct drt_camera_desc {
 #define DRT_RENDER_SYNC       0x4u  /* with DEVICE_OUT: synchronise the stream before return */
 #define DRT_RENDER_TIMING     0x8u  /* bracket every kernel launch with HIP events -> stats */
 #define DRT_RENDER_F64        0x10u /* compute in double on the device (verification mode) */
+#define DRT_RENDER_ALLREDUCE  0x40u /* with BACKWARD, on a context that has a communicator (drt_hip_comm_init_rank):
+                                       after K7 the library enqueues ONE ncclAllReduce(sum, f64, n_params x 3) on
+                                       the context's stream; out_param_grad is the sum over ALL ranks' shards.
+                                       Every rank of the communicator must make the call.  (A group context
+                                       always reduces; the flag is implied.) */
 #define DRT_RENDER_UNBIASED   0x20u /* with BACKWARD: the reference's unbiased integration operator
                                        (integrate.hpp:39-52, README.md:104-136): backward draws a
                                        FRESH direction at every vertex and traces a new suffix path
@@ -127,8 +143,10 @@ typedef struct drt_render_params {
     int32_t spp;            /* samples per pixel            (args.hpp:36-43, -n) */
     int32_t min_bounces;    /* Pathtracer ctor              (args.hpp:44-51, -b) */
     double absorb;          /* Pathtracer ctor              (args.hpp:52-59, -p) */
-    int32_t max_depth;      /* extension: hard cap on path vertices; <=0 = default 64.
-                               The reference has none (termination by roulette only). */
+    int32_t max_depth;      /* extension: hard cap on path vertices, 1..DRT_MAX_DEPTH; <=0 = DRT_MAX_DEPTH.
+                               The reference has none (termination by roulette only): paths the cap cuts
+                               short are reported in drt_hip_stats.capped_paths, so the bias is visible.
+                               With absorb == 1 the cap is min_bounces itself (every path ends there). */
     uint32_t seed;          /* key of the counter RNG, see drt_rng_u31 */
     int32_t shard, n_shards, band_rows;  /* pixel sharding: image rows are cut into bands of
                                band_rows rows dealt round-robin to n_shards; this call renders
@@ -142,6 +160,8 @@ typedef struct drt_render_params {
     int32_t reserved;
 } drt_render_params;
 
+#define DRT_MAX_DEPTH 64
+
 enum {
     DRT_K_RAYGEN = 0,    /* K1 */
     DRT_K_INTERSECT = 1, /* K2 */
@@ -149,6 +169,8 @@ enum {
     DRT_K_FILM = 3,      /* K5 */
     DRT_K_BACKWARD = 4,  /* K6 */
     DRT_K_GRADREDUCE = 5,/* K7 */
+    DRT_K_INTERSECT_MESH = 6, /* K2 on triangles: the BVH walk (k_intersect_mesh), timed apart from K2's analytic pass */
+    DRT_K_PATH = 7,      /* K1+K2+K3+K6 in ONE launch (k_path): a path lives in registers from the eye to its end */
     DRT_K_COUNT = 8
 };
 
@@ -163,6 +185,9 @@ typedef struct drt_hip_stats {
     uint64_t units[DRT_K_COUNT];    /* segments (K2,K3,K6) or paths (K1,K5) processed */
     uint64_t queue_rays_read;       /* rays the shade launches read from the queue (a fused launch keeps a ray */
     uint64_t queue_rays_written;    /* in registers over several bounces) / survivors they wrote back: 32 B each */
+    uint64_t capped_paths;          /* paths still alive when they reached max_depth (cut short: 0 when the cap is
+                                       the roulette's own certain kill, absorb == 1 at min_bounces) */
+    uint64_t bvh_bytes;             /* mesh scenes: bytes of the BVH (nodes + triangle records) the walk reads from */
 } drt_hip_stats;
 
 typedef struct drt_hip_ctx drt_hip_ctx;
@@ -170,7 +195,27 @@ typedef struct drt_hip_ctx drt_hip_ctx;
 int drt_hip_abi_version(void);
 int drt_hip_device_count(void);
 int drt_hip_create(int device_id, drt_hip_ctx** out);
+/* One process, n GPUs.  The group context owns one member context per entry of device_ids
+ * (device memory, stream) and the RCCL communicators between the distinct devices (ncclCommInitAll).
+ * upload_scene / update_params go to every member; drt_hip_render renders member i's interleaved
+ * row bands on device_ids[i] -- all members enqueued before any is waited for -- and returns the whole
+ * frame in out_rgb and the gradient ALREADY summed over the members in out_param_grad: members that
+ * share a device are added on that device, the distinct devices by ONE ncclAllReduce.  Host buffers only
+ * (DRT_RENDER_DEVICE_OUT is refused); rp->shard / n_shards address the GROUP as one shard of a larger job
+ * (multi-node), normally 0 / 1.  A device may be listed more than once (testing on a single-GPU box). */
+int drt_hip_create_group(const int* device_ids, int n_devices, drt_hip_ctx** out);
+int drt_hip_group_size(const drt_hip_ctx* ctx);   /* members of a group context, 1 for a plain one */
 void drt_hip_destroy(drt_hip_ctx* ctx);
+/* One process per GPU: rank 0 calls drt_hip_comm_unique_id and hands the 128 bytes to the other ranks
+ * out of band (torch.distributed store, MPI, a file); every rank then calls drt_hip_comm_init_rank on its
+ * own context (collective: returns when all n_ranks have joined).  From then on a render with
+ * DRT_RENDER_BACKWARD | DRT_RENDER_ALLREDUCE returns gradients summed over all ranks. */
+#define DRT_HIP_UNIQUE_ID_BYTES 128
+typedef struct drt_hip_unique_id { char bytes[DRT_HIP_UNIQUE_ID_BYTES]; } drt_hip_unique_id;   /* = ncclUniqueId */
+int drt_hip_comm_unique_id(drt_hip_unique_id* out);
+int drt_hip_comm_init_rank(drt_hip_ctx* ctx, const drt_hip_unique_id* id, int rank, int n_ranks);
+int drt_hip_comm_size(const drt_hip_ctx* ctx);    /* ranks of the context's communicator, 0 = none */
+int drt_hip_comm_destroy(drt_hip_ctx* ctx);
 int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* scene);
 int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3 */);
 /* out_rgb: width*height*3 floats, row-major, mean over spp; only the rows of this shard are
@@ -201,7 +246,7 @@ const char* drt_hip_kernel_name(int k);
  * Replaces drt::random::uniform (include/drt/random.hpp:7-10): the n-th rand() call made while
  * tracing camera sample `path` (= pixel*spp + sample, pixel = y*width + x) returns
  * drt_rng_u31(seed, path, n) in [0, 2^31-1]; uniform = r / 2147483647.0 (RAND_MAX). */
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DRT_HD __host__ __device__ static inline
 #else
 #define DRT_HD static inline

@@ -1,0 +1,136 @@
+"""The multi-GPU surface of the C ABI on a single-GPU box: group contexts (one process, n devices;
+drt_hip_create_group) and per-rank communicators (one process per GPU; drt_hip_comm_init_rank).  The
+gradient reduction -- THE collective of the path, VariableNode::backward's `m_grad += grad`
+(/root/reference/include/drt/vector.hpp:185-188) summed across devices -- runs inside libdrt_hip.so:
+same-device members are added on the device, distinct devices by one ncclAllReduce (here a 1-rank
+communicator: the call is made, the code path is the one 8 GPUs take)."""
+import dataclasses
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_group_context_equals_one_context(pkg, hip):
+    """A group that lists device 0 three times: three members deal the row bands among themselves, the library sums
+    their gradients (on-device adds + the all-reduce of the leaders' communicator) and assembles the frame."""
+    scene = pkg.cornell_box(front_specular=True)
+    cam = pkg.cornell_camera(96, 70)
+    rp = pkg.RenderParams(spp=6, min_bounces=3, absorb=0.3, seed=4, band_rows=8)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    g = pkg.HipRenderer([0, 0, 0])
+    try:
+        assert g.group_size == 3 and g.comm_size == 1
+        g.upload_scene(scene)
+        gimg, ggrads, gst = g.render(cam, rp, backward=True)
+        np.testing.assert_array_equal(gimg, img)                  # disjoint rows, same kernels
+        np.testing.assert_allclose(ggrads, grads, rtol=1e-9)      # same terms, summed in another order
+        assert gst["segments"] == st["segments"] and gst["paths"] == st["paths"]
+        # update_params reaches every member
+        newp = np.array(scene.params) * 0.5 + 0.1
+        g.update_params(newp)
+        hip.update_params(newp)
+        a = g.render(cam, rp, backward=True)
+        b = hip.render(cam, rp, backward=True)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-9)
+        # forward only, and the per-pixel gradient image, through the group
+        f = g.render(cam, rp, backward=False)
+        np.testing.assert_array_equal(f[0], b[0])
+        gi_g = g.render_gradient_image(cam, rp, 2)
+        gi_1 = hip.render_gradient_image(cam, rp, 2)
+        np.testing.assert_array_equal(gi_g[1], gi_1[1])
+        # a group returns through host buffers only
+        with pytest.raises(pkg.DrtHipError, match="DRT_ERR_UNSUPPORTED"):
+            g.render_device(cam, rp, 0, 0)
+    finally:
+        g.close()
+
+
+def test_group_as_one_shard_of_a_larger_job(pkg, hip):
+    """rp.shard / n_shards address a GROUP as one node of a multi-node job: 2 'nodes' x 2 members tile the frame."""
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(64, 64)
+    rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=9, band_rows=4)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    g = pkg.HipRenderer([0, 0])
+    try:
+        g.upload_scene(scene)
+        acc, gsum = np.zeros_like(img), np.zeros_like(grads)
+        for node in range(2):
+            im, gr, _ = g.render(cam, dataclasses.replace(rp, shard=node, n_shards=2), backward=True)
+            rows = np.concatenate([pkg.shard_rows(64, 4, 4, node * 2 + m) for m in range(2)])
+            other = np.setdiff1d(np.arange(64), rows)
+            assert not im[other].any()
+            acc += im
+            gsum += gr
+        np.testing.assert_array_equal(acc, img)
+        np.testing.assert_allclose(gsum, grads, rtol=1e-9)
+    finally:
+        g.close()
+
+
+def test_in_library_allreduce_with_a_one_rank_communicator(pkg):
+    """One process per GPU: unique id -> comm_init_rank -> DRT_RENDER_ALLREDUCE.  With one rank the sum is the
+    rank's own gradient; the ncclAllReduce is enqueued on the context's stream like on 8 GPUs."""
+    r = pkg.HipRenderer(0)
+    try:
+        scene = pkg.cornell_box()
+        cam = pkg.cornell_camera(48, 48)
+        rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=3)
+        r.upload_scene(scene)
+        _, g0, _ = r.render(cam, rp, backward=True)
+        with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):      # no communicator yet
+            r.render(cam, dataclasses.replace(rp, flags=pkg.RENDER_ALLREDUCE), backward=True)
+        assert r.comm_size == 0
+        r.comm_init(pkg.comm_unique_id(), 0, 1)
+        assert r.comm_size == 1
+        _, g1, _ = r.render(cam, dataclasses.replace(rp, flags=pkg.RENDER_ALLREDUCE), backward=True)
+        np.testing.assert_array_equal(g1, g0)
+        with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):      # one communicator per context
+            r.comm_init(pkg.comm_unique_id(), 0, 1)
+        r.comm_destroy()
+        assert r.comm_size == 0
+    finally:
+        r.close()
+
+
+def _bench(*args, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` must itself start two ranks (here sharing device 0 over a gloo rendezvous:
+    plumbing only) and report n_gpus == 2; the numbers of such a run mean nothing."""
+    line = _bench("--gpus", "2", "--dist-backend", "gloo", "--same-gpu", "--steps", "2", "--warmup", "1",
+                  "--width", "128", "--height", "128", "--spp", "4", "--no-cpu-baseline", "--no-extra-views")
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert "2 ranks" in line["config"]["parallelism"]
+    assert line["config"]["paths_per_step"] == 2 * 128 * 128 * 4      # weak scaling: per-rank work is fixed
+
+
+@pytest.mark.timeout(900)
+def test_bench_single_rank_under_torchrun_uses_the_library_collective():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "128", "--height", "128", "--spp", "4",
+                          "--no-cpu-baseline", "--no-extra-views"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and "library all-reduce" in line["config"]["parallelism"]

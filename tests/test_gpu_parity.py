@@ -4,9 +4,14 @@ the unmodified reference and against the fp64 oracle.  All tests need a real MI3
 Stated tolerances (north star: fp32 forward tolerance, gradients within 1e-4 relative):
   * f64 device mode vs oracle/reference: 1e-9 relative on image and gradients (same algorithm,
     same RNG draws; only FMA contraction / libm differ).
-  * f32 device mode: gradients 1e-4 of the largest gradient component; image mean 1e-4 relative;
-    per pixel |d| <= 2e-4 * max(image) except for an outlier budget of 0.5 % of the pixels
-    (a discrete hit/miss decision flipped by fp32 rounding changes one of the spp samples).
+  * f32 device mode, the reference's scenes: gradients 1e-4 of the largest gradient component, image
+    mean 1e-4 relative, EVERY pixel within 2e-4 * max(image), segment count within one path's length.
+    Measured at HEAD (profiles/r02_parity_report.txt): gradients <= 2e-6, pixels <= 3e-5, no flipped path.
+  * f32, the RANDOM test scenes only (g7, g8, random<seed>: roulette-boosted long paths, exponent-80
+    lobes, non-unit wall normals -- per-path weights span six orders of magnitude):
+    a single path whose discrete hit decision flips under f32 rounding moves a tiny fixture's gradient
+    by ~1e-4 (g7: 13 of 32,450 segments, 8.3e-5 measured), so they get 2x that measured value and an
+    outlier budget of 0.5 % of the pixels.  The f64 mode, flip-free, is what pins those scenes.
 """
 import os
 
@@ -18,30 +23,30 @@ from conftest import SMALL_GOLDENS, case_inputs, load_golden
 pytestmark = pytest.mark.gpu
 
 GRAD_TOL = 1e-4
-# the random scenes (roulette-boosted long paths, exponent-80 lobes, non-unit wall normals) have heavy-tailed
-# per-path weights: the handful of f32-flipped paths of a tiny fixture (13 of 32,450 segments in g7) move
-# its gradient by ~1e-4; DESIGN.md section 6
-GRAD_TOL_HEAVY = 5e-4
+GRAD_TOL_HEAVY = 2e-4        # random scenes only: 2 x the 8.3e-5 measured on g7 (see above)
 MEAN_TOL = 1e-4
 PIXEL_TOL = 2e-4
-OUTLIER_FRAC = 5e-3
+OUTLIER_FRAC_HEAVY = 5e-3    # random scenes only
 
 
 def grad_rel_err(got, want):
     return float(np.abs(got - want).max() / np.abs(want).max())
 
 
-def check_f32(img, grads, segments, g_img, g_grads, g_segments, grad_tol=GRAD_TOL):
+def check_f32(img, grads, segments, g_img, g_grads, g_segments, heavy_tailed=False):
+    """The f32 device mode against reference numbers.  No self-widening terms: the bounds are the stated ones."""
     scale = float(np.abs(g_img).max())
     bad = np.abs(img.astype(np.float64) - g_img).max(-1) > PIXEL_TOL * scale
-    assert bad.mean() <= OUTLIER_FRAC, f"{bad.sum()} of {bad.size} pixels outside fp32 tolerance"
+    if heavy_tailed:
+        assert bad.mean() <= OUTLIER_FRAC_HEAVY, f"{bad.sum()} of {bad.size} pixels outside fp32 tolerance"
+    else:
+        assert bad.sum() == 0, f"{bad.sum()} of {bad.size} pixels outside fp32 tolerance"
     m_got, m_want = img.astype(np.float64).mean((0, 1)), g_img.mean((0, 1))
-    # flipped samples move the mean by at most (#flipped / #paths): allow that on tiny renders
-    assert np.abs(m_got - m_want).max() <= MEAN_TOL * m_want.max() + 2.0 * bad.sum() / bad.size * scale
+    assert np.abs(m_got - m_want).max() <= (5 * MEAN_TOL if heavy_tailed else MEAN_TOL) * m_want.max()
     # one path whose fp32 hit/miss decision flips can change the count by its whole length (<= 64)
-    assert abs(int(segments) - int(g_segments)) <= max(64, int(2e-4 * g_segments))
+    assert abs(int(segments) - int(g_segments)) <= (max(64, int(2e-4 * g_segments)) if heavy_tailed else 64)
     if g_grads is not None:
-        assert grad_rel_err(grads, g_grads) <= grad_tol + 4.0 * bad.sum() / bad.size
+        assert grad_rel_err(grads, g_grads) <= (GRAD_TOL_HEAVY if heavy_tailed else GRAD_TOL)
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS)
@@ -50,8 +55,7 @@ def test_f32_matches_reference_golden(pkg, hip, name):
     scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
     hip.upload_scene(scene)
     img, grads, stats = hip.render(cam, rp, backward=True, adjoint=adjoint)
-    check_f32(img, grads, stats["segments"], g["image"], g["grads"], g["segments"],
-              GRAD_TOL_HEAVY if "random" in name else GRAD_TOL)
+    check_f32(img, grads, stats["segments"], g["image"], g["grads"], g["segments"], heavy_tailed="random" in name)
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS)
@@ -168,7 +172,7 @@ def test_matches_oracle_on_random_scenes(pkg, hip, oracle):
         assert stats["segments"] == ref["stats"]["segments"]
         assert grad_rel_err(grads, ref["grads"]) < 1e-9
         img, grads, stats = hip.render(cam, rp, backward=True, adjoint=adj)
-        check_f32(img, grads, stats["segments"], ref["image"], ref["grads"], ref["stats"]["segments"], GRAD_TOL_HEAVY)
+        check_f32(img, grads, stats["segments"], ref["image"], ref["grads"], ref["stats"]["segments"], heavy_tailed=True)
 
 
 def test_edge_cases(pkg, hip, oracle):
@@ -215,6 +219,10 @@ def test_error_behaviour(pkg):
         r.render(cam, pkg.RenderParams(spp=0))
     with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
         r.render(cam, pkg.RenderParams(spp=1, absorb=1.5))
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):      # deeper than DRT_MAX_DEPTH: refused, not truncated
+        r.render(cam, pkg.RenderParams(spp=1, max_depth=pkg.MAX_DEPTH + 1))
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
+        r.render(cam, pkg.RenderParams(spp=1, min_bounces=pkg.MAX_DEPTH + 6, absorb=1.0))
     bad = pkg.cornell_box()
     bad.shapes[0] = (pkg.SHAPE_SPHERE, 99, -1, (0., 0., 3., 1.))
     with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
@@ -222,6 +230,32 @@ def test_error_behaviour(pkg):
     with pytest.raises(pkg.DrtHipError):
         pkg.HipRenderer(4096)            # no such device
     r.close()
+
+
+def test_capped_paths_are_reported(pkg, hip, oracle):
+    """The reference ends paths by roulette only; max_depth is this library's extension.  Paths it cuts short are
+    counted (drt_hip_stats.capped_paths), so the bias of a cap is visible; a cap that IS the roulette's certain
+    kill (absorb == 1 at min_bounces) cuts nothing."""
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(64, 48)
+    hip.upload_scene(scene)
+    _, _, st = hip.render(cam, pkg.RenderParams(spp=4, min_bounces=5, absorb=1.0, seed=2), backward=True)
+    assert st["capped_paths"] == 0
+    for nb in (0, 1, 3):
+        rp = pkg.RenderParams(spp=4, min_bounces=1, absorb=0.1, seed=2, max_depth=6, bounces_per_launch=nb)
+        _, _, st = hip.render(cam, rp, backward=True, f64=True)
+        # the oracle run without the cap tells which paths reach vertex 7: those with > 6 vertices
+        ref6 = oracle.render(scene, cam, rp, backward=False)
+        ref_long = oracle.render(scene, cam, dataclasses_replace(rp, max_depth=7), backward=False)
+        assert st["segments"] == ref6["stats"]["segments"]
+        assert st["capped_paths"] == ref_long["stats"]["segments"] - ref6["stats"]["segments"] > 0
+    _, _, st = hip.render(cam, pkg.RenderParams(spp=4, min_bounces=1, absorb=0.1, seed=2), backward=True)
+    assert st["capped_paths"] == 0       # the default cap of 64 vertices is never reached at this absorb
+
+
+def dataclasses_replace(obj, **kw):
+    import dataclasses
+    return dataclasses.replace(obj, **kw)
 
 
 def test_finite_difference_of_albedo(pkg, hip):
@@ -266,7 +300,7 @@ def test_gradient_image_matches_reference(pkg, hip, name):
     np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
     img, gimg, st = hip.render_gradient_image(cam, rp, p, adjoint=adjoint)
     bad = np.abs(gimg.astype(np.float64) - g["grad_image"]).max(-1) > PIXEL_TOL * scale
-    assert bad.mean() <= OUTLIER_FRAC
+    assert bad.sum() == 0
     # its pixel sum is the ordinary gradient of that parameter
     _, grads, _ = hip.render(cam, rp, backward=True, adjoint=adjoint)
     np.testing.assert_allclose(gimg.astype(np.float64).sum((0, 1)) * rp.spp, grads[p], rtol=1e-5)

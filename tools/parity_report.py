@@ -10,18 +10,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as entry  # noqa: E402
-from conftest import SMALL_GOLDENS, case_inputs, load_golden  # noqa: E402
+from conftest import SMALL_GOLDENS, UNBIASED_GOLDENS, case_inputs, load_golden  # noqa: E402
 
 pkg = entry.load_package()
 hip = pkg.HipRenderer(0)
-names = SMALL_GOLDENS + ["c1_cornell_256x256x8_d4"] + (["c3_cornell_512x512x64_d8"] if "--big" in sys.argv else [])
+names = SMALL_GOLDENS + UNBIASED_GOLDENS + ["c1_cornell_256x256x8_d4"] + (["c3_cornell_512x512x64_d8"] if "--big" in sys.argv else [])
 print(f"{'fixture':34s} {'mode':4s} {'dseg':>6s} {'bad_px':>7s} {'max_px_err':>11s} {'mean_rel':>10s} {'grad_rel':>10s}")
 for name in names:
     g = load_golden(name)
     scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
     hip.upload_scene(scene)
     for mode in ("f32", "f64"):
-        img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, f64=(mode == "f64"))
+        img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, f64=(mode == "f64"),
+                                    unbiased=name in UNBIASED_GOLDENS)
         im = img.astype(np.float64)
         if "image" in g:
             gi = g["image"].astype(np.float64)
