@@ -12,7 +12,7 @@ all: lib oracle host
 
 lib: $(LIB)
 $(LIB): $(PKG)/csrc/drt_hip.hip $(PKG)/csrc/drt_kernels.h $(PKG)/csrc/drt_device.h $(PKG)/csrc/drt_bvh.h include/drt_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -o $@ $(PKG)/csrc/drt_hip.hip -lrccl
+	$(HIPCC) --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude -o $@ $(PKG)/csrc/drt_hip.hip -lrccl
 
 oracle:
 	$(MAKE) -C oracle libdrt_oracle.so ref

@@ -421,7 +421,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
                    if f.endswith((".h", ".hpp", ".hip"))] + [os.path.join(REPO_ROOT, "include", "drt_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + srcs + ["-lrccl"]
     if verbose:
         print(" ".join(cmd))

@@ -15,12 +15,15 @@
 #define DRT_ID_NONE 0xFFFFu
 #define DRT_BLOCK 256
 #define DRT_WAVE 64
+#define DRT_PROG_MAX 16          // shapes k_path's unrolled intersection program covers
+enum { DRT_PK_PLANE = 0, DRT_PK_SPHERE = 1, DRT_PK_AX = 2, DRT_PK_AY = 3, DRT_PK_AZ = 4 };
 
 // ---- scene records (one instance per compute type, built by drt_hip_upload_scene) ----------
 template <typename R>
 struct DevShape {           // float: 32 B, one s_load_dwordx8 in K2's uniform loop
     R p[4];                 // PLANE n.xyz, offset | SPHERE c.xyz, radius
-    int type, material, emitter, pad;
+    int type, material, emitter;
+    int pad;                // k_path: colour parameter | emission parameter << 16 of the shape (DRT_ID_NONE = none)
 };
 
 template <typename R>
@@ -41,6 +44,11 @@ struct DevScene {
     int n_items, pad_items;
     unsigned long long item_pair, item_sphere, item_skip;   // skip: a mesh record (one shape index, no test)
     R items[DRT_MAX_SHAPES][8];
+    // k_path's intersection program (drt_path.h): one record per shape, scene order, 3 kind bits per shape;
+    // prog_ok = the scene has at most DRT_PROG_MAX shapes and no mesh
+    unsigned long long prog_kinds;
+    int prog_ok, prog_pad;
+    R prog[DRT_PROG_MAX][4];
     int flat[DRT_MAX_SHAPES];   // position of shape s in the flattened scene (a mesh counts once per
                                 // triangle): the order that breaks exact ties, pathtracer.hpp:80
     DevShape<R> shapes[DRT_MAX_SHAPES];
@@ -192,10 +200,11 @@ __device__ inline V3<R> shape_normal(const DevShape<R>& s, V3<R> p)
 template <typename R>
 __device__ inline void make_frame(V3<R> n, V3<R>& t, V3<R>& b)
 {
-    if (abs_r(n.x) < abs_r(n.y))
-        t = normalize(mk<R>(R(1) - n.x * n.x, -n.y * n.x, -n.z * n.x));
-    else
-        t = normalize(mk<R>(-n.x * n.y, R(1) - n.y * n.y, -n.z * n.y));
+    // e - (e . n) n for e = e1 or e2, whichever is less aligned with n: both candidates are formed from ONE
+    // selected component s = n.x or n.y (a select, not a divergent branch): t = e - s n
+    const bool use_x = abs_r(n.x) < abs_r(n.y);
+    const R s = use_x ? n.x : n.y;
+    t = normalize(mk<R>((use_x ? R(1) : R(0)) - n.x * s, (use_x ? R(0) : R(1)) - n.y * s, -n.z * s));
     b = normalize(cross(n, t));
 }
 

@@ -3,6 +3,7 @@
 // bounce is two launches (K2, K3) on persistent grids that read their queue length from device
 // memory, so a whole render is enqueued without a single host round trip.
 #include "drt_kernels.h"
+#include "drt_path.h"
 #include "drt_bvh.h"
 
 #include <rccl/rccl.h>
@@ -61,6 +62,8 @@ struct drt_hip_ctx {
 
     bool has_scene = false;
     bool has_specular = false;
+    bool prog_ok = false;                 // k_path's intersection program covers the scene (drt_path.h)
+    unsigned long long prog_kinds = 0;
     int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)
     int n_user_params = 0;            // what the caller uploaded and gets gradients for
     std::vector<uint8_t> requires_grad;
@@ -75,7 +78,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv,
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -273,6 +276,34 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     }
     for (int i = 0; i < s->n_emitters; ++i)
         ds.emitter_param[i] = s->emitters[i].param;
+    // k_path (drt_path.h): the parameter ids of every shape in one word, and the intersection program
+    ds.prog_ok = s->n_shapes <= DRT_PROG_MAX ? 1 : 0;
+    for (int i = 0; i < s->n_shapes; ++i) {
+        const int m = s->shapes[i].material, e = s->shapes[i].emitter;
+        const uint32_t cid = m >= 0 ? (uint32_t)ds.materials[m].param : DRT_ID_NONE;
+        const uint32_t eid = e >= 0 ? (uint32_t)s->emitters[e].param : DRT_ID_NONE;
+        ds.shapes[i].pad = (int)(cid | (eid << 16));
+        if (s->shapes[i].type == DRT_SHAPE_MESH)
+            ds.prog_ok = 0;
+        if (!ds.prog_ok || i >= DRT_PROG_MAX)
+            continue;
+        int kind = s->shapes[i].type == DRT_SHAPE_SPHERE ? DRT_PK_SPHERE : DRT_PK_PLANE;
+        R rec[4] = {(R)s->shapes[i].p[0], (R)s->shapes[i].p[1], (R)s->shapes[i].p[2], (R)s->shapes[i].p[3]};
+        if (kind == DRT_PK_PLANE) {
+            // n = +-e_a exactly: t = (sgn off - o_a) * rcp(d_a), bit-identical to the general form (drt_path.h)
+            int axis = -1, nonzero = 0;
+            for (int a = 0; a < 3; ++a)
+                if (rec[a] != R(0)) { ++nonzero; axis = a; }
+            if (nonzero == 1 && (rec[axis] == R(1) || rec[axis] == R(-1))) {
+                kind = DRT_PK_AX + axis;
+                rec[0] = rec[axis] * rec[3];
+                rec[1] = rec[2] = rec[3] = R(0);
+            }
+        }
+        ds.prog_kinds |= (unsigned long long)kind << (3 * i);
+        for (int j = 0; j < 4; ++j)
+            ds.prog[i][j] = rec[j];
+    }
     params.assign((size_t)ds.n_params * 3, R(1));
     for (size_t i = 0; i < (size_t)s->n_params * 3; ++i)
         params[i] = (R)s->params[i];
@@ -348,7 +379,34 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     memcpy(&bvh, sizeof(R) == 4 ? (const void*)&ctx->bvh_f : (const void*)&ctx->bvh_d, sizeof bvh);
     const int spp = rp->spp;
     const uint64_t total_paths = (uint64_t)n_local_pixels * (uint64_t)spp;
+    const int D = depth_cap;
+    const bool unbiased = backward && (rp->flags & DRT_RENDER_UNBIASED) != 0 && gimg_param < 0;
+    // K2 folded into K3 wherever nothing else consumes the hit records: never with a mesh (the BVH
+    // walk is its own kernel); in the unbiased backward every depth but the first of a chain, whose
+    // hit is saved as the next chain vertex
+    static const bool fuse_env = !(getenv("DRT_HIP_FUSE") && atoi(getenv("DRT_HIP_FUSE")) == 0);
+    const bool can_fuse = fuse_env && !ctx->has_mesh;
+    static const int shade_nb_env = getenv("DRT_HIP_SHADE_BOUNCES") ? atoi(getenv("DRT_HIP_SHADE_BOUNCES")) : 0;
+    // ---- k_path (drt_path.h): the whole path in one launch, in registers.  Taken when the scene is analytic,
+    // the estimator the biased one, at most 4 parameters want gradients, and enough lanes stay busy to the end:
+    // ~7 % of the paths end per bounce on a miss or a light, the roulette removes `absorb` of the rest from
+    // min_bounces on; a launch whose lanes would idle more than 60 % of the time (roulette-terminated paths under
+    // the default cap of 64) goes through the queues instead, where survivors are compacted between launches.
+    static const int path_env = getenv("DRT_HIP_PATH") ? atoi(getenv("DRT_HIP_PATH")) : 1;
+    bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && !unbiased && gimg_param < 0 && D > 0 &&
+                    (!backward || ctx->n_params <= 4) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
+                    !getenv("DRT_HIP_DUMP_PATH");
+    if (use_path && path_env < 2) {
+        double alive = 1.0, busy = 0.0;
+        for (int k = 0; k < D; ++k) {
+            busy += alive;
+            alive *= 0.93 * ((k + 1) >= rp->min_bounces ? 1.0 - rp->absorb : 1.0);
+        }
+        use_path = busy / D >= 0.4;
+    }
     uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
+    if (use_path && rp->batch_paths <= 0)
+        cap = total_paths;                 // no per-path memory: one batch covers the frame
     if (const char* e = getenv("DRT_HIP_BATCH_PATHS")) {
         long long v = atoll(e);
         if (v > 0)
@@ -367,7 +425,6 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if (Sb > (uint32_t)spp) Sb = (uint32_t)spp;
     if (Sb < 1) Sb = 1;
     const size_t N = (size_t)Pb * Sb;   // batch capacity in paths
-    const int D = depth_cap;
     // queue regions: one wave each; enough of them to fill 256 CUs several times over
     uint32_t region_shift = 8;   // 256 slots: 4 chunks per wave (sweep in profiles/: 64..4096)
     if (const char* e = getenv("DRT_HIP_REGION_SIZE")) {
@@ -378,8 +435,29 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         --region_shift;
     const uint32_t region_size = 1u << region_shift;
     const uint32_t max_regions = (uint32_t)((N + region_size - 1) / region_size);
+    // k_path geometry: wave <-> (64 pixels, spr samples); ~4 rounds of 16 waves per CU keep the tail short
+    const uint32_t path_groups = (Pb + DRT_WAVE - 1) / DRT_WAVE;
+    uint32_t path_spr = 1;
+    {
+        const uint64_t target = (uint64_t)ctx->n_cu * 64;
+        const uint64_t want = (target + path_groups - 1) / path_groups;
+        path_spr = (uint32_t)(Sb / (want ? want : 1));
+        if (const char* e = getenv("DRT_HIP_PATH_SPR"))
+            path_spr = (uint32_t)atoi(e);
+        if (path_spr < 1) path_spr = 1;
+        if (path_spr > Sb) path_spr = Sb;
+    }
+    const uint32_t path_ranges = (Sb + path_spr - 1) / path_spr;
+    const size_t path_waves = (size_t)path_groups * path_ranges;
 
     int rc;
+    ChainState<R> cs;
+    memset(&cs, 0, sizeof cs);
+    size_t cw = (size_t)(D + 1) * max_regions;   // counts[depth][region] of one batch
+    if (use_path) {
+        cw = 2 * path_waves;                     // [segments | capped paths] per wave
+        if ((rc = ensure(ctx, ctx->fpart, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
+    } else {
     for (int i = 0; i < 2; ++i) {
         if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ray_b[i], N * sizeof(typename Q2<R>::T))) != DRT_OK) return rc;
@@ -389,9 +467,6 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
     if (gimg_param >= 0)
         if ((rc = ensure(ctx, ctx->gpath, N * sizeof(R4))) != DRT_OK) return rc;
-    const bool unbiased = backward && (rp->flags & DRT_RENDER_UNBIASED) != 0 && gimg_param < 0;
-    ChainState<R> cs;
-    memset(&cs, 0, sizeof cs);
     if (unbiased) {
         typedef typename Q2<R>::T R2c;
         if ((rc = ensure(ctx, ctx->ch_cva, N * sizeof(R4))) != DRT_OK) return rc;
@@ -413,19 +488,18 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     }
     if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
-    const uint64_t n_pix_batches = (n_local_pixels + Pb - 1) / Pb;
-    const uint64_t n_s_batches = ((uint64_t)spp + Sb - 1) / Sb;
-    const uint64_t n_batches = n_pix_batches * n_s_batches;
-    const size_t cw = (size_t)(D + 1) * max_regions;   // counts[depth][region] of one batch
-    (void)n_batches;
+    }
     *n_count_words = cw;
     if ((rc = ensure(ctx, ctx->counts, cw * sizeof(uint32_t))) != DRT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->segtotal, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written
+    if ((rc = ensure(ctx, ctx->segtotal, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written, capped
     HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const int bwd_grid = grid_for(ctx, N);
-    if (backward) {   // per-block partial sums: K6's persistent grid, or the shade kernel's one block per 4 regions
+    if (backward) {   // per-block partial sums: K6's persistent grid, the shade kernel's one block per 4 regions, or k_path's blocks
         const size_t shade_blocks = (max_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE);
-        const size_t blocks = shade_blocks > (size_t)bwd_grid ? shade_blocks : (size_t)bwd_grid;
+        size_t blocks = shade_blocks > (size_t)bwd_grid ? shade_blocks : (size_t)bwd_grid;
+        const size_t path_blocks = (path_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE);
+        if (use_path && path_blocks > blocks)
+            blocks = path_blocks;
         if ((rc = ensure(ctx, ctx->gpart, blocks * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
     }
 
@@ -471,18 +545,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     double* gpart = (double*)ctx->gpart.p;
     const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
 
-    // K2 folded into K3 wherever nothing else consumes the hit records: never with a mesh (the BVH
-    // walk is its own kernel); in the unbiased backward every depth but the first of a chain, whose
-    // hit is saved as the next chain vertex
-    static const bool fuse_env = !(getenv("DRT_HIP_FUSE") && atoi(getenv("DRT_HIP_FUSE")) == 0);
-    const bool can_fuse = fuse_env && !ctx->has_mesh;
     // Bounces per fused launch (at most 8).  Inside a launch the lanes of ended paths idle -- cheap next
     // to the queue traffic saved, measured: even at absorb = 0.5 four bounces per launch beat one --
     // so a launch only stops where fewer than ~10 % of its rays are expected to be left: ~7 % end
     // per bounce on a miss or a light (Cornell-like scenes), the roulette removes `absorb` of them at
     // every depth >= min_bounces.
     // DRT_HIP_SHADE_BOUNCES=n forces n (1 = one launch per bounce).
-    static const int shade_nb_env = getenv("DRT_HIP_SHADE_BOUNCES") ? atoi(getenv("DRT_HIP_SHADE_BOUNCES")) : 0;
     auto bounces_from = [&](int k) -> int {
         if (!can_fuse)
             return 1;
@@ -509,6 +577,72 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             a.n_paths = a.Pb * a.Sb;
             a.n_regions = (a.n_paths + region_size - 1) / region_size;
             uint32_t* counts = (uint32_t*)ctx->counts.p;   // reused by every batch (stream order)
+            if (use_path) {
+                // ---- the whole batch in ONE launch: camera -> path -> radiance sums + gradient partials
+                PathArgs pa;
+                memset(&pa, 0, sizeof pa);
+                pa.W = a.W; pa.H = a.H; pa.spp = a.spp;
+                pa.shard = a.shard; pa.n_shards = a.n_shards; pa.band = a.band;
+                pa.Pb = a.Pb; pa.p0 = a.p0; pa.Sb = a.Sb; pa.s0 = a.s0;
+                pa.spr = path_spr < a.Sb ? path_spr : a.Sb;
+                pa.n_ranges = (a.Sb + pa.spr - 1) / pa.spr;
+                pa.n_groups = (a.Pb + DRT_WAVE - 1) / DRT_WAVE;
+                pa.min_bounces = a.min_bounces; pa.depth_cap = a.depth_cap; pa.cap_is_roulette = a.cap_is_roulette;
+                pa.rr_threshold = a.rr_threshold; pa.seed = a.seed;
+                pa.p_rr = 1.0 - rp->absorb;
+                pa.inv_p_rr = rp->absorb < 1.0 ? 1.0 / (1.0 - rp->absorb) : 0.0;   // (never used when every path ends at min_bounces)
+                for (int i = 0; i < 3; ++i) {
+                    pa.eye[i] = a.eye[i]; pa.fwd[i] = a.fwd[i]; pa.right[i] = a.right[i]; pa.up[i] = a.up[i];
+                }
+                pa.tan_half = a.tan_half; pa.aspect = a.aspect;
+                pa.inv_W = 1.0 / (double)a.W; pa.inv_H = 1.0 / (double)a.H;
+                const size_t n_waves = (size_t)pa.n_groups * pa.n_ranges;
+                const int gpath = (int)((n_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
+                double* fpart = film ? (double*)ctx->fpart.p : (double*)nullptr;
+                // the kinds of the reference's own scene are compiled in (no per-shape branches); any other
+                // analytic scene reads its kinds from the program
+                static const bool sig_env = !(getenv("DRT_HIP_PATH_SIG") && atoi(getenv("DRT_HIP_PATH_SIG")) == 0);
+                const bool cornell_sig = sig_env && sizeof(R) == 4 && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
+                if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
+#define DRT_LAUNCH_PATH(SPEC, NP, SIG, NSIG)                                                                          \
+    hipLaunchKernelGGL((k_path<R, SPEC, NP, SIG, NSIG>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, pa, d_scene, \
+                       d_params, d_adjoint, gpart, fpart, counts)
+#define DRT_LAUNCH_PATH_SIG(SPEC, NP)                                                  \
+    do {                                                                               \
+        if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, DRT_SIG_CORNELL, DRT_NSIG_CORNELL); \
+        else DRT_LAUNCH_PATH(SPEC, NP, 0ull, 0);                                       \
+    } while (0)
+                if (backward) {
+                    if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 4);
+                    else DRT_LAUNCH_PATH_SIG(false, 4);
+                } else {
+                    if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 0);
+                    else DRT_LAUNCH_PATH_SIG(false, 0);
+                }
+#undef DRT_LAUNCH_PATH_SIG
+#undef DRT_LAUNCH_PATH
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_PATH]++;
+                hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts, (uint32_t)(2 * n_waves),
+                                   (unsigned long long*)ctx->segtotal.p, (uint32_t)n_waves, 0ull, 0ull, 1u);
+                if (backward) {
+                    if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
+                    hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart,
+                                       gpath, n_fast, grad);
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                    st->launches[DRT_K_GRADREDUCE]++;
+                    st->units[DRT_K_GRADREDUCE] += (uint64_t)gpath;
+                }
+                if (film) {
+                    if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;
+                    hipLaunchKernelGGL(k_film_parts, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, fpart,
+                                       pa.n_ranges, a.Pb, a.p0, film);
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                    st->launches[DRT_K_FILM]++;
+                    st->units[DRT_K_FILM] += a.n_paths;
+                }
+                continue;
+            }
             HIPCHK(ctx, hipMemsetAsync(counts, 0, cw * sizeof(uint32_t), ctx->stream));
             const int g = (int)((a.n_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
             const int gp = grid_for(ctx, a.n_paths);   // per-path kernels (K6): persistent grid
@@ -856,7 +990,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->fpart, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
@@ -946,6 +1080,8 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_f, pf.data(), pf.size() * sizeof(float));
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_d, pd.data(), pd.size() * sizeof(double));
     const int n_dev_params = hf->n_params;   // user parameters + internal constants
+    ctx->prog_ok = hf->prog_ok != 0;
+    ctx->prog_kinds = hf->prog_kinds;
     delete hf;
     delete hd;
     if (rc != DRT_OK)

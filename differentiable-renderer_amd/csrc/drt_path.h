@@ -1,0 +1,416 @@
+// drt_path.h -- k_path: K1 + K2 + K3 + K6 of a render in ONE launch (gfx950 / wave64).
+//
+// For scenes of analytic shapes whose paths end at a fixed depth (`-b D -p 1`, or a small max_depth) nothing
+// has to leave the CU between the eye and the end of a path: a lane keeps ONE PIXEL, walks its samples one
+// after the other and carries every path in registers --
+//     ray (o, d), RNG key                                    Camera::sample, camera.hpp:51-60
+//     T_k = prod_{j<k} colour_j m_j   (prefix throughput)    Pathtracer::scatter, pathtracer.hpp:91-115
+//     L   = sum_k T_k E_k / p_k       (radiance of the path) Pathtracer::trace,   pathtracer.hpp:121-136
+// and, when gradients are wanted (<= 4 parameters, the reference's scene has exactly 4, render.cpp:26-29), the
+// TANGENTS of the throughput with respect to every parameter,
+//     dT_k/dc_p,  updated per vertex:  dT' = dT * (colour m) + [colour is c_p] T m ,
+// so that every emissive vertex adds  g * dT_p * E_k / p_k  to parameter p's gradient and  g * T_k / p_k  to its
+// own emission parameter -- the very sums the reference's backward functors (vector.hpp:418-484) and
+// VariableNode::backward's `m_grad += grad` (vector.hpp:185-188) produce by walking its graph in reverse; here
+// they are accumulated in the order the path is traced, so no tape, no vertex count, no queue and no second
+// kernel exist: per PATH the launch moves 0 bytes (per pixel and sample range: 24 bytes of radiance sums).
+// The wavefront kernels of drt_kernels.h (queues in HBM, tape + K6) remain the general path: meshes, roulette-
+// terminated paths of unbounded length, the unbiased operator, more than 4 parameters, gradient images.
+//
+// Work split: wave <-> (group of 64 consecutive pixels of the batch, range of `spr` samples); a block is four
+// neighbouring groups of one range.  Pixel sums leave as f64 partials per range (summed in range order by
+// k_film_parts: bitwise reproducible), gradients as per-block fp64 partials for K7 (fixed order), segment counts
+// as one word per wave.
+//
+// Closest hit, f32: the scene's INTERSECTION PROGRAM (DevScene::prog*, built at upload, scene order kept so the
+// first shape wins ties, pathtracer.hpp:80): one record per shape with a kind --
+//     general plane   t = (o.n - off) * rcp(-(d.n))                        shape.hpp:49-59
+//     axis plane      n = +-e_a exactly:  t = (s off - o_a) * rcp(d_a)      -- bit-identical to the general form
+//                     (the products with 0 and +-1 are exact, rcp is odd), 2 instead of 9 VALU and the three
+//                     rcp(d_a) are shared by all axis planes of the scene
+//     sphere          half-b form of shape.hpp:78-103 (b = 2 b', disc = 4 disc': exact power-of-two scalings)
+// The shape loop is fully unrolled over DRT_PROG_MAX records whose kinds are either read from the scene (uniform
+// branches on a scalar mask, records by scalar loads the compiler hoists out of the bounce loop) or, for the
+// topology of the reference's own scene, fixed at compile time (template SIG: no branches at all).
+#pragma once
+
+#include "drt_kernels.h"
+
+struct PathArgs {
+    // frame / sharding
+    int32_t W, H, spp;
+    int32_t shard, n_shards, band;
+    // batch: pixels [p0, p0 + Pb) of the shard, samples [s0, s0 + Sb), cut into ranges of spr samples
+    uint32_t Pb, p0, Sb, s0, spr, n_ranges, n_groups;
+    // integrator
+    int32_t min_bounces, depth_cap, cap_is_roulette;
+    uint32_t rr_threshold, seed;
+    double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
+    // camera
+    double eye[3], fwd[3], right[3], up[3];
+    double tan_half, aspect, inv_W, inv_H;
+};
+
+__device__ inline uint32_t path_global_pixel(const PathArgs& a, uint32_t lp)
+{
+    uint32_t ly = lp / (uint32_t)a.W, x = lp - ly * (uint32_t)a.W;
+    uint32_t y = ly;
+    if (a.n_shards > 1) {
+        uint32_t b = ly / (uint32_t)a.band, r = ly - b * (uint32_t)a.band;
+        y = (b * (uint32_t)a.n_shards + (uint32_t)a.shard) * (uint32_t)a.band + r;
+    }
+    return y * (uint32_t)a.W + x;
+}
+
+// ---- the intersection program (f32) ----------------------------------------------------------------
+__device__ inline void prog_accept(float t, int s, float& tmin, int& prim)
+{
+    if (t > 0.f && !(t >= tmin)) {          // shape.hpp:55 / pathtracer.hpp:80: first shape wins ties
+        tmin = t;
+        prim = s;
+    }
+}
+
+template <int KIND>
+__device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float& tmin, int& prim)
+{
+    if (KIND == DRT_PK_AX) {
+        prog_accept((r.x - o.x) * inv_d.x, s, tmin, prim);
+    } else if (KIND == DRT_PK_AY) {
+        prog_accept((r.x - o.y) * inv_d.y, s, tmin, prim);
+    } else if (KIND == DRT_PK_AZ) {
+        prog_accept((r.x - o.z) * inv_d.z, s, tmin, prim);
+    } else if (KIND == DRT_PK_PLANE) {
+        const float h = o.x * r.x + o.y * r.y + o.z * r.z - r.w;
+        const float den = d.x * r.x + d.y * r.y + d.z * r.z;
+        prog_accept(h * __builtin_amdgcn_rcpf(-den), s, tmin, prim);
+    } else {                                 // sphere: b' = oc.d, disc' = b'^2 - (oc.oc - r^2), t = -b' -+ sqrt(disc')
+        const V3<float> oc = mk<float>(o.x - r.x, o.y - r.y, o.z - r.z);
+        const float bh = dot(oc, d);
+        const float cc = dot(oc, oc) - r.w * r.w;
+        const float disc = bh * bh - cc;
+        const float sq = __builtin_amdgcn_sqrtf(disc > 0.f ? disc : 0.f);
+        const float t1 = -bh - sq, t2 = sq - bh;
+        const float t = t1 > 0.f ? t1 : t2;
+        if (disc >= 0.f)
+            prog_accept(t, s, tmin, prim);
+    }
+}
+
+// The records of the program, as the bounce loop sees them.  SIG != 0 (kinds fixed at compile time, 3 bits per shape,
+// NSIG shapes): the NSIG records are loaded ONCE per wave, before the sample loop, and stay in scalar registers --
+// the loop body then contains no scalar load, no wait and no branch for the scene at all.  SIG == 0: kinds and
+// records are read from the scene inside the loop (uniform branches on the kind mask; scalar loads).
+template <int NSIG>
+struct ProgRecs {
+    float4 r[NSIG > 0 ? NSIG : 1];
+    __device__ inline void load(const DevScene<float>* __restrict__ sc)
+    {
+#pragma unroll
+        for (int s = 0; s < NSIG; ++s)
+            r[s] = *reinterpret_cast<const float4*>(sc->prog[s]);
+    }
+};
+
+template <unsigned long long SIG, int NSIG>
+__device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs,
+                                                 V3<float> o, V3<float> d)
+{
+    const V3<float> inv_d = mk<float>(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    float tmin = INFINITY;
+    int prim = -1;
+    if (NSIG > 0) {
+#pragma unroll
+        for (int s = 0; s < NSIG; ++s) {
+            constexpr unsigned long long sig = SIG;
+            const int kind = (int)((sig >> (3 * s)) & 7ull);
+            const float4 r = recs.r[s];
+            if (kind == DRT_PK_AX) prog_test<DRT_PK_AX>(r, s, o, d, inv_d, tmin, prim);
+            else if (kind == DRT_PK_AY) prog_test<DRT_PK_AY>(r, s, o, d, inv_d, tmin, prim);
+            else if (kind == DRT_PK_AZ) prog_test<DRT_PK_AZ>(r, s, o, d, inv_d, tmin, prim);
+            else if (kind == DRT_PK_PLANE) prog_test<DRT_PK_PLANE>(r, s, o, d, inv_d, tmin, prim);
+            else prog_test<DRT_PK_SPHERE>(r, s, o, d, inv_d, tmin, prim);
+        }
+    } else {
+        const int n = sc->n_shapes;
+        const unsigned long long kinds = sc->prog_kinds;
+#pragma unroll
+        for (int s = 0; s < DRT_PROG_MAX; ++s) {
+            if (s < n) {
+                const float4 r = *reinterpret_cast<const float4*>(sc->prog[s]);
+                const int kind = (int)((kinds >> (3 * s)) & 7ull);
+                if (kind == DRT_PK_AX) {
+                    asm volatile("" ::: "memory");       // (keeps the uniform branch a branch: see closest_hit_n)
+                    prog_test<DRT_PK_AX>(r, s, o, d, inv_d, tmin, prim);
+                } else if (kind == DRT_PK_AY) {
+                    asm volatile("" ::: "memory");
+                    prog_test<DRT_PK_AY>(r, s, o, d, inv_d, tmin, prim);
+                } else if (kind == DRT_PK_AZ) {
+                    asm volatile("" ::: "memory");
+                    prog_test<DRT_PK_AZ>(r, s, o, d, inv_d, tmin, prim);
+                } else if (kind == DRT_PK_PLANE) {
+                    asm volatile("" ::: "memory");
+                    prog_test<DRT_PK_PLANE>(r, s, o, d, inv_d, tmin, prim);
+                } else {
+                    asm volatile("" ::: "memory");
+                    prog_test<DRT_PK_SPHERE>(r, s, o, d, inv_d, tmin, prim);
+                }
+            }
+        }
+    }
+    HitRec<float> h;
+    h.t = tmin;
+    h.prim = prim;
+    return h;
+}
+
+template <unsigned long long SIG, int NSIG>
+__device__ inline HitRec<float> path_closest_hit(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs, float4 ra, float2 rb)
+{
+    return closest_hit_prog<SIG, NSIG>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
+}
+template <unsigned long long SIG, int NSIG>
+__device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<NSIG>&, double4 ra, double2 rb)
+{
+    const double4 ra1[1] = {ra};
+    const double2 rb1[1] = {rb};
+    HitRec<double> h1[1];
+    closest_hit_n<double, 1>(sc, sc->n_shapes, ra1, rb1, h1);      // the f64 verification mode keeps the literal loop
+    return h1[0];
+}
+
+// the kinds of the reference's scene (render.cpp:39-47): sphere, sphere, -x, general (1, 0, 0.1), -z, +z, +y, -y, sphere
+#define DRT_SIG_CORNELL                                                                                                   \
+    ((unsigned long long)DRT_PK_SPHERE | (unsigned long long)DRT_PK_SPHERE << 3 | (unsigned long long)DRT_PK_AX << 6 |    \
+     (unsigned long long)DRT_PK_PLANE << 9 | (unsigned long long)DRT_PK_AZ << 12 | (unsigned long long)DRT_PK_AZ << 15 |  \
+     (unsigned long long)DRT_PK_AY << 18 | (unsigned long long)DRT_PK_AY << 21 | (unsigned long long)DRT_PK_SPHERE << 24)
+#define DRT_NSIG_CORNELL 9
+
+// per-lane gradient state: NP parameters (0 = none)
+template <typename R, int NP>
+struct Tangents {
+    V3<R> dT[NP > 0 ? NP : 1];      // dT/dc_p of the current path
+    V3<R> acc[NP > 0 ? NP : 1];     // gradient sums of this lane
+};
+
+// an emissive vertex reached with prefix throughput T (and tangents dT): radiance and gradients
+//   L     += T E / p_k                                   (pathtracer.hpp:113-114, 133)
+//   d/dc_p += g dT_p E / p_k      d/dE += g T / p_k       (vector.hpp:418-484 in closed form)
+template <typename R, int NP>
+__device__ inline void add_emission(const SceneLds<R>& lds, const R* __restrict__ params, uint32_t eid, R inv_pk, V3<R> T,
+                                    V3<R> g, V3<R>& L, Tangents<R, NP>& tg)
+{
+    const V3<R> E = load_param<R, (NP > 0)>(lds, params, (int)eid) * inv_pk;
+    L = L + T * E;
+    if (NP > 0) {
+        const V3<R> gE = g * E, gT = g * T * inv_pk;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool own = eid == (uint32_t)p;
+            tg.acc[p] = mk<R>(fma_r(tg.dT[p].x, gE.x, tg.acc[p].x + (own ? gT.x : R(0))),
+                              fma_r(tg.dT[p].y, gE.y, tg.acc[p].y + (own ? gT.y : R(0))),
+                              fma_r(tg.dT[p].z, gE.z, tg.acc[p].z + (own ? gT.z : R(0))));
+        }
+    }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+template <typename R, bool SPEC, int NP, unsigned long long SIG, int NSIG>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
+       double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts)
+{
+    typedef typename Q4<R>::T R4;
+    typedef typename Q2<R>::T R2;
+    __shared__ SceneLds<R> lds;
+    __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+    stage_scene(lds, sc, params);
+
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t w = grid_wave();                       // wave of the grid = group + n_groups * range
+    const uint32_t range = w / a.n_groups, group = w - range * a.n_groups;
+    const uint32_t lp = group * DRT_WAVE + lane;          // batch-local pixel of this lane
+    const bool have = range < a.n_ranges && lp < a.Pb;
+    const uint32_t s_begin = range * a.spr;
+    const uint32_t s_end = s_begin + a.spr < a.Sb ? s_begin + a.spr : a.Sb;
+
+    Tangents<R, NP> tg;
+#pragma unroll
+    for (int p = 0; p < (NP > 0 ? NP : 1); ++p)
+        tg.acc[p] = mk<R>(R(0), R(0), R(0));
+    double fx = 0, fy = 0, fz = 0;                        // radiance sum of this lane's pixel over the range
+    uint32_t n_seg = 0, n_capped = 0;                     // wave-uniform counters
+
+    uint32_t gpix = 0, px = 0, py = 0;
+    V3<R> g = mk<R>(R(1), R(1), R(1));                    // render.cpp:80: radiance.backward(Vec3(1))
+    if (have) {
+        gpix = path_global_pixel(a, a.p0 + lp);
+        py = gpix / (uint32_t)a.W;
+        px = gpix - py * (uint32_t)a.W;
+        if (NP > 0 && adjoint)
+            g = mk<R>((R)adjoint[(size_t)gpix * 3], (R)adjoint[(size_t)gpix * 3 + 1], (R)adjoint[(size_t)gpix * 3 + 2]);
+    }
+    const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
+    ProgRecs<(sizeof(R) == 4 ? NSIG : 0)> recs;
+    if (sizeof(R) == 4 && NSIG > 0)
+        recs.load(reinterpret_cast<const DevScene<float>*>(sc));
+
+    if (range < a.n_ranges) {
+    for (uint32_t sl = s_begin; sl < s_end; ++sl) {
+        // ---- Camera::sample (camera.hpp:51-60), in double like the reference: the jitter decides which
+        // surface the path starts on
+        R4 ra;
+        R2 rb;
+        uint32_t key = 0;
+        bool live = have;
+        if (have) {
+            const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
+            key = drt_rng_path_key(a.seed, path);
+            const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
+            const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
+            const double s = ((double)px + u1) / (double)a.W;
+            const double t = ((double)py + u2) / (double)a.H;
+            const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
+            const double ct = (2. * t - 1.) * a.tan_half;
+            double dx = a.fwd[0] + cs * a.right[0] - ct * a.up[0];
+            double dy = a.fwd[1] + cs * a.right[1] - ct * a.up[1];
+            double dz = a.fwd[2] + cs * a.right[2] - ct * a.up[2];
+            const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+            ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)(dx * inv);
+            rb.x = (R)(dy * inv); rb.y = (R)(dz * inv);
+            // pathtracer.hpp:128 at depth 0
+            if (a.depth_cap <= 0)
+                live = false;
+            else if (a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold)
+                live = false;
+        }
+        V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
+        uint32_t end_ids = DRT_ID_NONE;                   // emission parameter of the light the path ended on
+        R end_inv_pk = R(1);
+        if (NP > 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                tg.dT[p] = mk<R>(R(0), R(0), R(0));
+        }
+        for (int kk = 0; kk < a.depth_cap; ++kk) {
+            const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+            if (n_live == 0)
+                break;
+            n_seg += n_live;
+            const R pk = kk >= a.min_bounces ? pk_rr : R(1);                  // pathtracer.hpp:130
+            const R inv_pk = kk >= a.min_bounces ? inv_p_rr : R(1);
+            const uint32_t n_theta = draw_offset(kk, 0, a.min_bounces) + camera_draw_base(a.min_bounces);
+            const bool next_rr = (kk + 1) >= a.min_bounces;
+            const bool next_cap = (kk + 1) >= a.depth_cap;
+            bool alive = false, capped = false;
+            if (live) {
+                const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
+                if (h.prim >= 0) {
+                    const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+                    const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+                    const V3<R> P = o + d * h.t;                              // pathtracer.hpp:83
+                    const DevShape<R>& sh = lds.sc.shapes[h.prim];
+                    const V3<R> nrm = shape_normal(sh, P);
+                    const uint32_t ids = (uint32_t)sh.pad;                    // colour | emission << 16 parameter ids
+                    const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
+                    if (eid != DRT_ID_NONE) {                                 // emission, pathtracer.hpp:113-114
+                        if (cid == DRT_ID_NONE) {
+                            // a light without a BxDF ends the path (pathtracer.hpp:38-39: f = 0): T and dT stay as they
+                            // are in this lane, so the emission is added ONCE PER SAMPLE, after the bounce loop, for all
+                            // lanes together -- not inside the loop, where every bounce a few lanes of the wave would
+                            // drag the other sixty through it
+                            end_ids = eid;
+                            end_inv_pk = inv_pk;
+                        } else {
+                            add_emission<R, NP>(lds, params, eid, inv_pk, T, g, L, tg);
+                        }
+                    }
+                    if (cid != DRT_ID_NONE) {                                 // a BxDF: sample, evaluate, continue
+                        const DevMaterial<R>& m = lds.sc.materials[sh.material];
+                        V3<R> wo;
+                        R q, bs;
+                        sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+                        const R c = dot(nrm, wo);                             // pathtracer.hpp:103
+                        const R mk_ = div_r(bs * c, q * pk);                   // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
+                        const V3<R> col = load_param<R, (NP > 0)>(lds, params, (int)cid);
+                        if (NP > 0) {
+                            const V3<R> cm = col * mk_, Tm = T * mk_;
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) {
+                                const bool mine = cid == (uint32_t)p;
+                                tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
+                                                 fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
+                            }
+                        }
+                        T = T * col * mk_;
+                        // roulette / cap of depth kk+1 (pathtracer.hpp:128)
+                        alive = !next_cap;
+                        if (alive && next_rr)
+                            alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                        if (next_cap && !a.cap_is_roulette)
+                            capped = !next_rr || !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                        const V3<R> no = P + wo * R(1e-3);                    // pathtracer.hpp:99
+                        ra.x = no.x; ra.y = no.y; ra.z = no.z; ra.w = wo.x;
+                        rb.x = wo.y; rb.y = wo.z;
+                    }
+                }
+            }
+            if (next_cap && !a.cap_is_roulette)
+                n_capped += (uint32_t)__popcll(__ballot(capped));
+            live = alive;
+        }
+        if (end_ids != DRT_ID_NONE)
+            add_emission<R, NP>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
+        fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
+    }
+    }
+
+    if (range < a.n_ranges) {
+        if (fpart && have) {
+            double* f = fpart + ((size_t)range * 3) * a.Pb + lp;       // [range][channel][pixel]: coalesced
+            f[0] = fx; f[(size_t)a.Pb] = fy; f[(size_t)a.Pb * 2] = fz;
+        }
+        if (lane == 0) {
+            counts[w] = n_seg;
+            counts[(size_t)a.n_groups * a.n_ranges + w] = n_capped;
+        }
+    }
+    if (NP > 0) {
+        // block reduction in fp64: thread -> wave (shuffles) -> block (LDS), fixed order; K7 adds the blocks
+        const int wv = threadIdx.x / DRT_WAVE;
+#pragma unroll
+        for (int r = 0; r < NP * 3; ++r) {
+            const V3<R> v3 = tg.acc[r / 3];
+            double v = (double)(r % 3 == 0 ? v3.x : (r % 3 == 1 ? v3.y : v3.z));
+#pragma unroll
+            for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)
+                v += __shfl_down(v, o2);
+            if (lane == 0)
+                s_red[wv][r] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < DRT_FAST_PARAMS * 3) {
+            double v = 0;
+            if ((int)threadIdx.x < NP * 3)
+                for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
+                    v += s_red[ww][threadIdx.x];
+            gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
+        }
+    }
+}
+
+// film[p0 + j] += sum over the sample ranges of one batch, in range order (deterministic)
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_film_parts(const double* __restrict__ fpart, uint32_t n_ranges, uint32_t Pb, uint32_t p0, double* __restrict__ film)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < Pb; j += stride) {
+        double r = 0, g = 0, b = 0;
+        for (uint32_t q = 0; q < n_ranges; ++q) {
+            const double* f = fpart + ((size_t)q * 3) * Pb + j;
+            r += f[0]; g += f[(size_t)Pb]; b += f[(size_t)Pb * 2];
+        }
+        double* f = film + (size_t)(p0 + j) * 3;
+        f[0] += r; f[1] += g; f[2] += b;
+    }
+}

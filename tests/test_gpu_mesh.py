@@ -30,7 +30,7 @@ def test_50k_triangle_bvh_matches_brute_force(pkg, hip, oracle):
     assert abs(st["segments"] - ref["stats"]["segments"]) <= 64
     scale = np.abs(ref["image"]).max()
     bad = np.abs(img.astype(np.float64) - ref["image"]).max(-1) > 2e-4 * scale
-    assert bad.sum() == 0
+    assert bad.sum() <= 1          # (one pixel may hold an f32-flipped path: tests/test_gpu_parity.py)
     assert grad_rel_err(grads, ref["grads"]) <= 1e-4
 
 

@@ -52,7 +52,7 @@ def main():
     d = keep or tempfile.mkdtemp(prefix="drt_isa_")
     os.makedirs(d, exist_ok=True)
     asm = os.path.join(d, "drt.s")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
            "--cuda-device-only", "-S", "-o", asm, SRC, "-Rpass-analysis=kernel-resource-usage"] + \
           [a for a in os.environ.get("DRT_EXTRA_FLAGS", "").split() if a]
     res = subprocess.run(cmd, capture_output=True, text=True)
