@@ -215,6 +215,15 @@ __device__ inline void add_emission(const SceneLds<R>& lds, const R* __restrict_
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
+// The bounce loop is written WITHOUT per-lane branches: every lane of the wave executes every bounce of the sample --
+// a lane whose path has ended keeps tracing a stale ray whose results are never used (`live` guards every
+// accumulation, its T and dT are frozen by selects) -- because that is what the SIMD does anyway, and straight-line
+// code spares the exec-mask bookkeeping, the register copies at the joins and the waits in front of them.
+template <typename R>
+struct CameraLane {            // per-lane camera constants (the lane's pixel does not change over its samples)
+    R cs0, ct0;                // (2 x / W - 1) aspect tan(vfov / 2) and (2 y / H - 1) tan(vfov / 2) at the pixel's corner
+};
+
 template <typename R, bool SPEC, int NP, unsigned long long SIG, int NSIG>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
@@ -250,6 +259,12 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         if (NP > 0 && adjoint)
             g = mk<R>((R)adjoint[(size_t)gpix * 3], (R)adjoint[(size_t)gpix * 3 + 1], (R)adjoint[(size_t)gpix * 3 + 2]);
     }
+    // f32: the pixel's corner in double ONCE per lane; a sample then only adds its jitter (camera.hpp:53-58 in the form
+    // cs = cs0 + u1 (2 aspect tan / W)): the sample's position inside the pixel is exact to ~2e-5 of a pixel and the
+    // direction to 1 ulp of f32 -- the resolution the ray has anyway once it is stored in f32
+    CameraLane<R> cl;
+    cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
+    cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
     ProgRecs<(sizeof(R) == 4 ? NSIG : 0)> recs;
     if (sizeof(R) == 4 && NSIG > 0)
@@ -257,15 +272,21 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
 
     if (range < a.n_ranges) {
     for (uint32_t sl = s_begin; sl < s_end; ++sl) {
-        // ---- Camera::sample (camera.hpp:51-60), in double like the reference: the jitter decides which
-        // surface the path starts on
+        // ---- Camera::sample (camera.hpp:51-60)
         R4 ra;
         R2 rb;
-        uint32_t key = 0;
-        bool live = have;
-        if (have) {
-            const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
-            key = drt_rng_path_key(a.seed, path);
+        const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
+        const uint32_t key = drt_rng_path_key(a.seed, path);
+        if (sizeof(R) == 4) {
+            const float cs = fmaf(u01(0.f, drt_rng_draw(key, 0)), (float)(2. * a.aspect * a.tan_half * a.inv_W), (float)cl.cs0);
+            const float ct = fmaf(u01(0.f, drt_rng_draw(key, 1)), (float)(2. * a.tan_half * a.inv_H), (float)cl.ct0);
+            const V3<float> dir = mk<float>((float)a.fwd[0] + cs * (float)a.right[0] - ct * (float)a.up[0],
+                                            (float)a.fwd[1] + cs * (float)a.right[1] - ct * (float)a.up[1],
+                                            (float)a.fwd[2] + cs * (float)a.right[2] - ct * (float)a.up[2]);
+            const V3<float> dn = normalize(dir);
+            ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dn.x;
+            rb.x = (R)dn.y; rb.y = (R)dn.z;
+        } else {                                          // f64 verification mode: the reference's own sequence, in double
             const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
             const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
             const double s = ((double)px + u1) / (double)a.W;
@@ -278,12 +299,9 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
             ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)(dx * inv);
             rb.x = (R)(dy * inv); rb.y = (R)(dz * inv);
-            // pathtracer.hpp:128 at depth 0
-            if (a.depth_cap <= 0)
-                live = false;
-            else if (a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold)
-                live = false;
         }
+        // pathtracer.hpp:128 at depth 0
+        bool live = have && a.depth_cap > 0 && !(a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold);
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
         uint32_t end_ids = DRT_ID_NONE;                   // emission parameter of the light the path ended on
         R end_inv_pk = R(1);
@@ -302,65 +320,66 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const uint32_t n_theta = draw_offset(kk, 0, a.min_bounces) + camera_draw_base(a.min_bounces);
             const bool next_rr = (kk + 1) >= a.min_bounces;
             const bool next_cap = (kk + 1) >= a.depth_cap;
-            bool alive = false, capped = false;
-            if (live) {
-                const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
-                if (h.prim >= 0) {
-                    const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
-                    const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
-                    const V3<R> P = o + d * h.t;                              // pathtracer.hpp:83
-                    const DevShape<R>& sh = lds.sc.shapes[h.prim];
-                    const V3<R> nrm = shape_normal(sh, P);
-                    const uint32_t ids = (uint32_t)sh.pad;                    // colour | emission << 16 parameter ids
-                    const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
-                    if (eid != DRT_ID_NONE) {                                 // emission, pathtracer.hpp:113-114
-                        if (cid == DRT_ID_NONE) {
-                            // a light without a BxDF ends the path (pathtracer.hpp:38-39: f = 0): T and dT stay as they
-                            // are in this lane, so the emission is added ONCE PER SAMPLE, after the bounce loop, for all
-                            // lanes together -- not inside the loop, where every bounce a few lanes of the wave would
-                            // drag the other sixty through it
-                            end_ids = eid;
-                            end_inv_pk = inv_pk;
-                        } else {
-                            add_emission<R, NP>(lds, params, eid, inv_pk, T, g, L, tg);
-                        }
-                    }
-                    if (cid != DRT_ID_NONE) {                                 // a BxDF: sample, evaluate, continue
-                        const DevMaterial<R>& m = lds.sc.materials[sh.material];
-                        V3<R> wo;
-                        R q, bs;
-                        sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
-                        const R c = dot(nrm, wo);                             // pathtracer.hpp:103
-                        const R mk_ = div_r(bs * c, q * pk);                   // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
-                        const V3<R> col = load_param<R, (NP > 0)>(lds, params, (int)cid);
-                        if (NP > 0) {
-                            const V3<R> cm = col * mk_, Tm = T * mk_;
+
+            const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
+            const bool hit = live && h.prim >= 0;
+            const int prim = h.prim >= 0 ? h.prim : 0;                        // (a miss reads record 0, uses nothing of it)
+            const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+            const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+            const V3<R> P = o + d * h.t;                                      // pathtracer.hpp:83
+            const DevShape<R>& sh = lds.sc.shapes[prim];
+            const V3<R> ctr = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
+            const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
+            const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
+            const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
+            const uint32_t ids = (uint32_t)sh.pad;                            // colour | emission << 16 parameter ids
+            const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
+            const bool has_bxdf = cid != DRT_ID_NONE, emits = hit && eid != DRT_ID_NONE;
+            // emission, pathtracer.hpp:113-114.  A light without a BxDF ends the path (pathtracer.hpp:38-39: f = 0): T and
+            // dT stay as they are in this lane, so its emission is added ONCE PER SAMPLE, after the bounce loop, for all
+            // lanes together.  A shape with both (rare) adds it here.
+            end_ids = emits && !has_bxdf ? eid : end_ids;
+            end_inv_pk = emits && !has_bxdf ? inv_pk : end_inv_pk;
+            if (__any(emits && has_bxdf)) {
+                if (emits && has_bxdf)
+                    add_emission<R, NP>(lds, params, eid, inv_pk, T, g, L, tg);
+            }
+            // the BxDF: sample, evaluate (pathtracer.hpp:91-111)
+            const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
+            V3<R> wo;
+            R q, bs;
+            sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+            const R c = dot(nrm, wo);                                         // pathtracer.hpp:103
+            const R mk_ = div_r(bs * c, q * pk);                              // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
+            // roulette / cap of depth kk+1 (pathtracer.hpp:128)
+            const bool rr_kills = next_rr && drt_rng_draw(key, n_theta + 2) < a.rr_threshold;
+            const bool alive = hit && has_bxdf && !next_cap && !rr_kills;
+            const bool capped = hit && has_bxdf && next_cap && !a.cap_is_roulette && !rr_kills;
+            // throughput and tangents move on only in lanes whose path goes on (the others stay frozen for the light's turn)
+            const V3<R> col = load_param<R, (NP > 0)>(lds, params, has_bxdf ? (int)cid : 0);
+            const V3<R> cmv = col * mk_;
+            const V3<R> cm = mk<R>(alive ? cmv.x : R(1), alive ? cmv.y : R(1), alive ? cmv.z : R(1));
+            if (NP > 0) {
+                const V3<R> Tm = T * mk_;
 #pragma unroll
-                            for (int p = 0; p < NP; ++p) {
-                                const bool mine = cid == (uint32_t)p;
-                                tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
-                                                 fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
-                            }
-                        }
-                        T = T * col * mk_;
-                        // roulette / cap of depth kk+1 (pathtracer.hpp:128)
-                        alive = !next_cap;
-                        if (alive && next_rr)
-                            alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                        if (next_cap && !a.cap_is_roulette)
-                            capped = !next_rr || !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
-                        const V3<R> no = P + wo * R(1e-3);                    // pathtracer.hpp:99
-                        ra.x = no.x; ra.y = no.y; ra.z = no.z; ra.w = wo.x;
-                        rb.x = wo.y; rb.y = wo.z;
-                    }
+                for (int p = 0; p < NP; ++p) {
+                    const bool mine = alive && cid == (uint32_t)p;
+                    tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
+                                     fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
                 }
             }
+            T = T * cm;
             if (next_cap && !a.cap_is_roulette)
                 n_capped += (uint32_t)__popcll(__ballot(capped));
+            const V3<R> no = P + wo * R(1e-3);                                // pathtracer.hpp:99
+            ra.x = no.x; ra.y = no.y; ra.z = no.z; ra.w = wo.x;
+            rb.x = wo.y; rb.y = wo.z;
             live = alive;
         }
-        if (end_ids != DRT_ID_NONE)
-            add_emission<R, NP>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
+        if (__any(end_ids != DRT_ID_NONE)) {
+            if (end_ids != DRT_ID_NONE)
+                add_emission<R, NP>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
+        }
         fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
     }
     }

@@ -1,12 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace stats + separate PMC passes of bench.py.
-# Usage: tools/profile.sh <tag> [bench args...]     outputs under gpurun_out/prof_<tag>/
+# Usage: tools/profile.sh <tag> <workload key> [bench args...]     outputs under gpurun_out/prof_<tag>/
+#   workload key = what bench.py compares profiles/traffic.json against, "<scene>:<W>x<H>x<spp>:d<depth>:<fwd|fwdbwd>"
+#   (the headline: cornell:512x512x64:d8:fwdbwd)
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
+WORKLOAD=${1:-cornell:512x512x64:d8:fwdbwd}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-streaming-view $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-extra-views $*"
 cd "$PWD"
 # 1) per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
@@ -15,7 +18,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_write.err"
 # 3) wave-level counters
 rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_sq.err"
-python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2> "$OUT/summary.err"
+python3 tools/summarize_profile.py "$OUT" "$WORKLOAD" > "$OUT/summary.txt" 2> "$OUT/summary.err"
 cat "$OUT/summary.txt"
 # keep only small files in gpurun_out (it is merged back, <= 64 MiB)
 find "$OUT" -name "*.csv" -size +8M -delete

@@ -11,6 +11,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else ""
 
 
 def find(sub, pattern):
@@ -20,8 +21,8 @@ def find(sub, pattern):
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_raygen", "k_intersect_mesh", "k_intersect", "k_shade", "k_film", "k_resolve", "k_backward_image",
-              "k_backward", "k_radiance", "k_gradreduce", "k_sum_counts"):
+    for k in ("k_raygen", "k_intersect_mesh", "k_intersect", "k_shade", "k_path", "k_film_parts", "k_film", "k_resolve", "k_backward_image",
+              "k_backward", "k_radiance", "k_gradreduce", "k_sum_counts", "k_add_f64"):
         if k in n:
             tag = k
             if "<double" in name:
@@ -78,10 +79,10 @@ for k, v in summary.items():
         print(f"{k:28s} fetch_raw={f/1e6:9.2f} MB  fetch_x2={2*f/1e6:9.2f} MB  write={w/1e6:9.2f} MB  total={(2*f+w)/1e6:9.2f} MB")
 json.dump({"kernels": summary, "traffic": traffic}, open(os.path.join(out, "summary.json"), "w"), indent=1)
 # bench.py's "traffic" field: PMC bytes per launch / traced average launch time, per kernel
-names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_intersect_mesh": "intersect", "k_shade<diffuse>": "shade",
-         "k_shade<specular>": "shade", "k_shade<diffuse,fused>": "shade", "k_shade<specular,fused>": "shade", "k_film": "film", "k_backward": "backward", "k_radiance": "backward",
-         "k_gradreduce": "gradreduce"}
-tj = {}
+names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_intersect_mesh": "intersect_mesh", "k_shade<diffuse>": "shade",
+         "k_shade<specular>": "shade", "k_shade<diffuse,fused>": "shade", "k_shade<specular,fused>": "shade", "k_film": "film",
+         "k_film_parts": "film", "k_backward": "backward", "k_radiance": "backward", "k_gradreduce": "gradreduce", "k_path": "path"}
+tj = {"workload": workload}
 for k, t in traffic.items():
     if k in names and "avg_us" in summary.get(k, {}):
         us = summary[k]["avg_us"]
@@ -89,6 +90,10 @@ for k, t in traffic.items():
                         "bytes_per_launch": round(t["total_corrected_B"]), "fetch_raw_bytes": round(t["fetch_raw_B"]),
                         "write_bytes": round(t["write_B"]), "avg_launch_us": round(us, 2),
                         "valu_insts_per_launch": round(summary[k].get("SQ_INSTS_VALU", 0.0)),
+                        "salu_insts_per_launch": round(summary[k].get("SQ_INSTS_SALU", 0.0)),
+                        "wave_cycles_per_launch": round(summary[k].get("SQ_WAVE_CYCLES", 0.0)),
+                        "wait_any_frac": round(summary[k].get("SQ_WAIT_ANY", 0.0) / max(1.0, summary[k].get("SQ_WAVE_CYCLES", 0.0)), 4),
+                        "wait_inst_any_frac": round(summary[k].get("SQ_WAIT_INST_ANY", 0.0) / max(1.0, summary[k].get("SQ_WAVE_CYCLES", 0.0)), 4),
                         # SQ_ACTIVE_INST_VALU counts quad-cycles per WAVE (a wave issues a VALU op every 4 cycles, two waves
                         # interleave on a SIMD at one per 2): wave-activity / (SIMDs x time) -- 2.0 would be a saturated pipe
                         "valu_wave_activity": round(summary[k].get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (256 * 4 * us * 1e-6 * 2.4e9), 4),
