@@ -62,6 +62,7 @@ struct drt_hip_ctx {
 
     bool has_scene = false;
     bool has_specular = false;
+    int max_colour_param = -1;            // largest parameter index that is some material's colour (device numbering)
     bool prog_ok = false;                 // k_path's intersection program covers the scene (drt_path.h)
     unsigned long long prog_kinds = 0;
     int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)
@@ -303,6 +304,20 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         ds.prog_kinds |= (unsigned long long)kind << (3 * i);
         for (int j = 0; j < 4; ++j)
             ds.prog[i][j] = rec[j];
+    }
+    if (ds.prog_ok) {                       // the kind-sorted copy (stable: scene order inside a kind)
+        int n = 0;
+        for (int k = 0; k < 5; ++k) {
+            ds.kind_begin[k] = n;
+            for (int i = 0; i < s->n_shapes; ++i)
+                if ((int)((ds.prog_kinds >> (3 * i)) & 7ull) == k) {
+                    for (int j = 0; j < 4; ++j)
+                        ds.sorted[n][j] = ds.prog[i][j];
+                    ds.sorted_shape[n++] = i;
+                }
+        }
+        for (int k = 5; k < 8; ++k)
+            ds.kind_begin[k] = n;
     }
     params.assign((size_t)ds.n_params * 3, R(1));
     for (size_t i = 0; i < (size_t)s->n_params * 3; ++i)
@@ -604,20 +619,22 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 static const bool sig_env = !(getenv("DRT_HIP_PATH_SIG") && atoi(getenv("DRT_HIP_PATH_SIG")) == 0);
                 const bool cornell_sig = sig_env && sizeof(R) == 4 && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
-#define DRT_LAUNCH_PATH(SPEC, NP, SIG, NSIG)                                                                          \
-    hipLaunchKernelGGL((k_path<R, SPEC, NP, SIG, NSIG>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, pa, d_scene, \
+#define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
+    hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, pa, d_scene, \
                        d_params, d_adjoint, gpart, fpart, counts)
-#define DRT_LAUNCH_PATH_SIG(SPEC, NP)                                                  \
-    do {                                                                               \
-        if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, DRT_SIG_CORNELL, DRT_NSIG_CORNELL); \
-        else DRT_LAUNCH_PATH(SPEC, NP, 0ull, 0);                                       \
+#define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
+    do {                                                                                   \
+        if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, NC, DRT_SIG_CORNELL, DRT_NSIG_CORNELL); \
+        else DRT_LAUNCH_PATH(SPEC, NP, NC, 0ull, 0);                                       \
     } while (0)
+                // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
+                const bool three = ctx->max_colour_param < 3;
                 if (backward) {
-                    if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 4);
-                    else DRT_LAUNCH_PATH_SIG(false, 4);
+                    if (ctx->has_specular) { if (three) DRT_LAUNCH_PATH_SIG(true, 4, 3); else DRT_LAUNCH_PATH_SIG(true, 4, 4); }
+                    else { if (three) DRT_LAUNCH_PATH_SIG(false, 4, 3); else DRT_LAUNCH_PATH_SIG(false, 4, 4); }
                 } else {
-                    if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 0);
-                    else DRT_LAUNCH_PATH_SIG(false, 0);
+                    if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 0, 0);
+                    else DRT_LAUNCH_PATH_SIG(false, 0, 0);
                 }
 #undef DRT_LAUNCH_PATH_SIG
 #undef DRT_LAUNCH_PATH
@@ -1082,6 +1099,9 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     const int n_dev_params = hf->n_params;   // user parameters + internal constants
     ctx->prog_ok = hf->prog_ok != 0;
     ctx->prog_kinds = hf->prog_kinds;
+    ctx->max_colour_param = -1;
+    for (int i = 0; i < hf->n_materials; ++i)
+        ctx->max_colour_param = std::max(ctx->max_colour_param, hf->materials[i].param);
     delete hf;
     delete hd;
     if (rc != DRT_OK)

@@ -682,9 +682,8 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
         return;
     }
     r1 = r1 < 1u ? 1u : (r1 > 2147483646u ? 2147483646u : r1);
-    const R u2 = u01(R(0), r2);
     R sphi, cphi;
-    sincospi_r(R(2) * u2, &sphi, &cphi);                       // phi = 2 pi u2
+    sincos_2pi_u31(r2, &sphi, &cphi);                          // phi = 2 pi u2
     V3<R> tg, bt;
     make_frame(nrm, tg, bt);
     if (!SPEC || m.type == DRT_BXDF_DIFFUSE) {

@@ -101,9 +101,16 @@ __device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d
 // NSIG shapes): the NSIG records are loaded ONCE per wave, before the sample loop, and stay in scalar registers --
 // the loop body then contains no scalar load, no wait and no branch for the scene at all.  SIG == 0: kinds and
 // records are read from the scene inside the loop (uniform branches on the kind mask; scalar loads).
+struct ProgLds {               // the kind-sorted program in LDS (scenes whose kinds are not compiled in)
+    float4 rec[DRT_PROG_MAX];
+    int shape[DRT_PROG_MAX];
+    int kind_begin[8];
+};
+
 template <int NSIG>
 struct ProgRecs {
     float4 r[NSIG > 0 ? NSIG : 1];
+    const ProgLds* lds;
     __device__ inline void load(const DevScene<float>* __restrict__ sc)
     {
 #pragma unroll
@@ -132,31 +139,24 @@ __device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restri
             else prog_test<DRT_PK_SPHERE>(r, s, o, d, inv_d, tmin, prim);
         }
     } else {
-        const int n = sc->n_shapes;
-        const unsigned long long kinds = sc->prog_kinds;
-#pragma unroll
-        for (int s = 0; s < DRT_PROG_MAX; ++s) {
-            if (s < n) {
-                const float4 r = *reinterpret_cast<const float4*>(sc->prog[s]);
-                const int kind = (int)((kinds >> (3 * s)) & 7ull);
-                if (kind == DRT_PK_AX) {
-                    asm volatile("" ::: "memory");       // (keeps the uniform branch a branch: see closest_hit_n)
-                    prog_test<DRT_PK_AX>(r, s, o, d, inv_d, tmin, prim);
-                } else if (kind == DRT_PK_AY) {
-                    asm volatile("" ::: "memory");
-                    prog_test<DRT_PK_AY>(r, s, o, d, inv_d, tmin, prim);
-                } else if (kind == DRT_PK_AZ) {
-                    asm volatile("" ::: "memory");
-                    prog_test<DRT_PK_AZ>(r, s, o, d, inv_d, tmin, prim);
-                } else if (kind == DRT_PK_PLANE) {
-                    asm volatile("" ::: "memory");
-                    prog_test<DRT_PK_PLANE>(r, s, o, d, inv_d, tmin, prim);
-                } else {
-                    asm volatile("" ::: "memory");
-                    prog_test<DRT_PK_SPHERE>(r, s, o, d, inv_d, tmin, prim);
-                }
-            }
+        // kinds not compiled in: the records sorted by kind (upload), one counted loop per kind -- no branch on the kind,
+        // no scalar load: every lane reads the SAME record from LDS (a broadcast read), the next record is requested
+        // while the current one is tested.  Inside a kind the scene order is kept, so the first shape wins ties
+        // (pathtracer.hpp:80); an exact tie between shapes of DIFFERENT kinds goes to the kind tested first (planes
+        // before spheres) -- t values from two different formulas agreeing in all 32 bits; the f64 mode keeps the
+        // literal loop.
+        const ProgLds& pl = *recs.lds;
+#define DRT_KIND_LOOP(K)                                                              \
+        for (int i = pl.kind_begin[K]; i < pl.kind_begin[K + 1]; ++i) {               \
+            const float4 r = pl.rec[i];                                               \
+            prog_test<K>(r, pl.shape[i], o, d, inv_d, tmin, prim);                    \
         }
+        DRT_KIND_LOOP(DRT_PK_AX)
+        DRT_KIND_LOOP(DRT_PK_AY)
+        DRT_KIND_LOOP(DRT_PK_AZ)
+        DRT_KIND_LOOP(DRT_PK_PLANE)
+        DRT_KIND_LOOP(DRT_PK_SPHERE)
+#undef DRT_KIND_LOOP
     }
     HitRec<float> h;
     h.t = tmin;
@@ -186,19 +186,21 @@ __device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __rest
      (unsigned long long)DRT_PK_AY << 18 | (unsigned long long)DRT_PK_AY << 21 | (unsigned long long)DRT_PK_SPHERE << 24)
 #define DRT_NSIG_CORNELL 9
 
-// per-lane gradient state: NP parameters (0 = none)
-template <typename R, int NP>
+// per-lane gradient state: NP parameters (0 = none), of which only the first NC can be a BxDF's colour (the others are
+// emission-only parameters: their tangent is identically 0 and is not carried -- the reference's scene has three
+// albedos and one emission, render.cpp:26-29)
+template <typename R, int NP, int NC>
 struct Tangents {
-    V3<R> dT[NP > 0 ? NP : 1];      // dT/dc_p of the current path
+    V3<R> dT[NC > 0 ? NC : 1];      // dT/dc_p of the current path
     V3<R> acc[NP > 0 ? NP : 1];     // gradient sums of this lane
 };
 
 // an emissive vertex reached with prefix throughput T (and tangents dT): radiance and gradients
 //   L     += T E / p_k                                   (pathtracer.hpp:113-114, 133)
 //   d/dc_p += g dT_p E / p_k      d/dE += g T / p_k       (vector.hpp:418-484 in closed form)
-template <typename R, int NP>
+template <typename R, int NP, int NC>
 __device__ inline void add_emission(const SceneLds<R>& lds, const R* __restrict__ params, uint32_t eid, R inv_pk, V3<R> T,
-                                    V3<R> g, V3<R>& L, Tangents<R, NP>& tg)
+                                    V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
 {
     const V3<R> E = load_param<R, (NP > 0)>(lds, params, (int)eid) * inv_pk;
     L = L + T * E;
@@ -207,9 +209,11 @@ __device__ inline void add_emission(const SceneLds<R>& lds, const R* __restrict_
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const bool own = eid == (uint32_t)p;
-            tg.acc[p] = mk<R>(fma_r(tg.dT[p].x, gE.x, tg.acc[p].x + (own ? gT.x : R(0))),
-                              fma_r(tg.dT[p].y, gE.y, tg.acc[p].y + (own ? gT.y : R(0))),
-                              fma_r(tg.dT[p].z, gE.z, tg.acc[p].z + (own ? gT.z : R(0))));
+            const V3<R> a0 = mk<R>(tg.acc[p].x + (own ? gT.x : R(0)), tg.acc[p].y + (own ? gT.y : R(0)), tg.acc[p].z + (own ? gT.z : R(0)));
+            if (p < NC)
+                tg.acc[p] = mk<R>(fma_r(tg.dT[p].x, gE.x, a0.x), fma_r(tg.dT[p].y, gE.y, a0.y), fma_r(tg.dT[p].z, gE.z, a0.z));
+            else
+                tg.acc[p] = a0;
         }
     }
 }
@@ -224,7 +228,7 @@ struct CameraLane {            // per-lane camera constants (the lane's pixel do
     R cs0, ct0;                // (2 x / W - 1) aspect tan(vfov / 2) and (2 y / H - 1) tan(vfov / 2) at the pixel's corner
 };
 
-template <typename R, bool SPEC, int NP, unsigned long long SIG, int NSIG>
+template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts)
@@ -243,7 +247,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     const uint32_t s_begin = range * a.spr;
     const uint32_t s_end = s_begin + a.spr < a.Sb ? s_begin + a.spr : a.Sb;
 
-    Tangents<R, NP> tg;
+    Tangents<R, NP, NC> tg;
 #pragma unroll
     for (int p = 0; p < (NP > 0 ? NP : 1); ++p)
         tg.acc[p] = mk<R>(R(0), R(0), R(0));
@@ -267,8 +271,20 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
     ProgRecs<(sizeof(R) == 4 ? NSIG : 0)> recs;
+    __shared__ ProgLds s_prog;
+    recs.lds = &s_prog;
     if (sizeof(R) == 4 && NSIG > 0)
         recs.load(reinterpret_cast<const DevScene<float>*>(sc));
+    if (sizeof(R) == 4 && NSIG == 0) {
+        const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
+        if (threadIdx.x < DRT_PROG_MAX) {
+            s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
+            s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
+        }
+        if (threadIdx.x < 8)
+            s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
+        __syncthreads();
+    }
 
     if (range < a.n_ranges) {
     for (uint32_t sl = s_begin; sl < s_end; ++sl) {
@@ -305,9 +321,9 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
         uint32_t end_ids = DRT_ID_NONE;                   // emission parameter of the light the path ended on
         R end_inv_pk = R(1);
-        if (NP > 0) {
+        if (NC > 0) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NC; ++p)
                 tg.dT[p] = mk<R>(R(0), R(0), R(0));
         }
         for (int kk = 0; kk < a.depth_cap; ++kk) {
@@ -342,7 +358,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             end_inv_pk = emits && !has_bxdf ? inv_pk : end_inv_pk;
             if (__any(emits && has_bxdf)) {
                 if (emits && has_bxdf)
-                    add_emission<R, NP>(lds, params, eid, inv_pk, T, g, L, tg);
+                    add_emission<R, NP, NC>(lds, params, eid, inv_pk, T, g, L, tg);
             }
             // the BxDF: sample, evaluate (pathtracer.hpp:91-111)
             const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
@@ -359,10 +375,10 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const V3<R> col = load_param<R, (NP > 0)>(lds, params, has_bxdf ? (int)cid : 0);
             const V3<R> cmv = col * mk_;
             const V3<R> cm = mk<R>(alive ? cmv.x : R(1), alive ? cmv.y : R(1), alive ? cmv.z : R(1));
-            if (NP > 0) {
+            if (NC > 0) {
                 const V3<R> Tm = T * mk_;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
+                for (int p = 0; p < NC; ++p) {
                     const bool mine = alive && cid == (uint32_t)p;
                     tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
                                      fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
@@ -378,7 +394,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         }
         if (__any(end_ids != DRT_ID_NONE)) {
             if (end_ids != DRT_ID_NONE)
-                add_emission<R, NP>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
+                add_emission<R, NP, NC>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
         }
         fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
     }
