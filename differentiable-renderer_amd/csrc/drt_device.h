@@ -103,17 +103,46 @@ struct DevBvh {
     const typename Q4<R>::T* tri_c;
     const typename Q4<R>::T* tri_shade;
     uint32_t n_nodes, n_top, n_tris, pad;
+    R lo[3], hi[3];                     // bounds of all triangles (padded like the node boxes): K2's analytic pass uses
+                                        // them to hand only the rays that can reach a triangle to the BVH walk
 };
 #define DRT_BVH_NONE 0xFFFFFFFFu
 #define DRT_BVH_LEAF 0x80000000u
+#ifndef DRT_BVH_LDS_NODES
 #define DRT_BVH_LDS_NODES 128        // 8 KB of LDS per block: the breadth-first top of the tree
+#endif
 #define DRT_BVH_STACK 32             // per-lane traversal stack in LDS (4-wide depth <= 10, <= 3 pushes a level)
 #define DRT_BVH_REFILL 16            // idle lanes needed before the wave pulls new rays from its stream
 #ifndef DRT_BVH_DESCEND_MIN
-#define DRT_BVH_DESCEND_MIN 20       // the interior-node loop runs while at least this many lanes descend
+#define DRT_BVH_DESCEND_MIN 32       // the interior-node loop runs while at least this many lanes descend (sweep: 28..40 flat)
 #endif
 
 typedef float drt_f2 __attribute__((ext_vector_type(2)));
+
+// read-once streams: non-temporal loads (they go through the caches without claiming room in them)
+typedef float drt_f4 __attribute__((ext_vector_type(4)));
+typedef double drt_d2 __attribute__((ext_vector_type(2)));
+typedef double drt_d4 __attribute__((ext_vector_type(4)));
+__device__ inline float4 nt_load(const float4* p)
+{
+    const drt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const drt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline float2 nt_load(const float2* p)
+{
+    const drt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const drt_f2*>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ inline double4 nt_load(const double4* p)
+{
+    const drt_d4 v = __builtin_nontemporal_load(reinterpret_cast<const drt_d4*>(p));
+    return make_double4(v.x, v.y, v.z, v.w);
+}
+__device__ inline double2 nt_load(const double2* p)
+{
+    const drt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const drt_d2*>(p));
+    return make_double2(v.x, v.y);
+}
 
 #define DRT_PI 3.14159265358979323846
 #define DRT_RAND_MAX_D 2147483647.0

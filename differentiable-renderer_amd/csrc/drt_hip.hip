@@ -57,6 +57,7 @@ struct RenderJob {
 struct drt_hip_ctx {
     int device = 0;
     int n_cu = 256;
+    int mesh_blocks_per_cu = 4;           // resident blocks of k_intersect_mesh per CU (occupancy query): its persistent grid
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -79,7 +80,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart,
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, cand, cand_count,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -217,6 +218,20 @@ int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_
     out->n_nodes = (uint32_t)b.nodes.size();
     out->n_top = b.top;
     out->n_tris = (uint32_t)tris.size();
+    // the box around everything, as the root's (padded) child boxes give it, rounded outwards in R
+    for (int a = 0; a < 3; ++a) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int c = 0; c < drt_bvh::kWidth; ++c)
+            if (!b.nodes.empty() && b.nodes[0].child[c] != drt_bvh::kLeaf) {
+                lo = std::min(lo, b.nodes[0].lo[c][a]);
+                hi = std::max(hi, b.nodes[0].hi[c][a]);
+            }
+        R rl = (R)lo, rh = (R)hi;
+        if ((double)rl > lo) rl = std::nextafter(rl, (R)-INFINITY);
+        if ((double)rh < hi) rh = std::nextafter(rh, (R)INFINITY);
+        out->lo[a] = rl;
+        out->hi[a] = rh;
+    }
     return DRT_OK;
 }
 
@@ -465,6 +480,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const uint32_t path_ranges = (Sb + path_spr - 1) / path_spr;
     const size_t path_waves = (size_t)path_groups * path_ranges;
 
+    // the rays the BVH walk has to see: one dense list per wave of k_intersect's persistent grid (+ the walk's list counter)
+    const uint32_t k2_waves = (uint32_t)grid_for(ctx, N) * (DRT_BLOCK / DRT_WAVE);
+    const uint32_t cand_cap = (uint32_t)(((((size_t)max_regions << (region_shift - 6)) + k2_waves - 1) / k2_waves) * DRT_WAVE);
     int rc;
     ChainState<R> cs;
     memset(&cs, 0, sizeof cs);
@@ -479,6 +497,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         if ((rc = ensure(ctx, ctx->ray_id[i], N * sizeof(uint2))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
+    if (ctx->has_mesh) {
+        if ((rc = ensure(ctx, ctx->cand, (size_t)k2_waves * cand_cap * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->cand_count, ((size_t)k2_waves + 1) * sizeof(uint32_t))) != DRT_OK) return rc;
+    }
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
     if (gimg_param >= 0)
         if ((rc = ensure(ctx, ctx->gpath, N * sizeof(R4))) != DRT_OK) return rc;
@@ -678,22 +700,6 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->units[DRT_K_RAYGEN] += a.n_paths;
             }
 
-            // fused launches take every ray through shade_nb bounces in registers (1, 2, 4 or 8)
-            // The tape walk in place: the first launch takes every path from the eye to its end (depth cap <= one
-            // tape chunk), so each lane walks its own path's records out of LDS -- no tape, no K6 / k_radiance.
-            // Forward-only renders do (their walk is light: 1.70 -> 1.54 ms on config 2).  The gradient walk in place
-            // works too but needs 168 VGPRs (3 waves per SIMD instead of 5) and loses to the separate K6
-            // (1.97 vs 1.71 ms): DRT_HIP_INLINE_WALK=2 opts in, =0 switches both off.
-            static const int walk_env = getenv("DRT_HIP_INLINE_WALK") ? atoi(getenv("DRT_HIP_INLINE_WALK")) : 1;
-            int walk = DRT_WALK_NONE;
-            if (walk_env > 0 && camera_fused && bounces_from(0) == D && D <= DRT_TAPE_CHUNK && !unbiased && gimg_param < 0 &&
-                !getenv("DRT_HIP_DUMP_PATH")) {
-                if (backward && ctx->n_params <= 4 && walk_env >= 2)
-                    walk = DRT_WALK_GRADIENTS;
-                else if (!backward && film)
-                    walk = DRT_WALK_RADIANCE;
-            }
-            int walk_blocks = 0;
             unsigned long long read_rows = 0, written_rows = 0;   // queue rows shade launches start from / end on
             for (int k = 0, lc = 0, nbk = 1, next_poll = DRT_POLL_EVERY; k < D; k += nbk, ++lc) {
                 const int cur = lc & 1, nxt = cur ^ 1;
@@ -717,13 +723,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if (!fused) {
                     if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                       ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                                       ra[cur], rb[cur], hit, counts + (size_t)k * max_regions, bvh,
+                                       ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (uint32_t*)ctx->cand_count.p, cand_cap);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_INTERSECT]++;
                     if (ctx->has_mesh) {   // continues from the analytic hit: (t, primitive) refined by the BVH walk
                         if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT_MESH)) != DRT_OK) return rc;
-                        hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                           bvh, ra[cur], rb[cur], hit, counts + (size_t)k * max_regions);
+                        const int gm = (int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu);
+                        hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                           bvh, ra[cur], rb[cur], hit, (const uint32_t*)ctx->cand.p, (uint32_t*)ctx->cand_count.p, cand_cap,
+                                           (uint32_t)gp * (DRT_BLOCK / DRT_WAVE));
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT_MESH]++;
                     }
@@ -745,22 +754,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                        d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,      \
                        ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
                     if (fused && camera_fused && k == 0) {
-#define DRT_LAUNCH_CAMERA(SPEC, WALK)                                                                                    \
-    hipLaunchKernelGGL((k_shade<R, SPEC, true, true, WALK>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,        \
-                       d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, ck,    \
-                       (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit, d_adjoint, \
-                       gpart, film ? lacc : (R4*)nullptr)
-                        walk_blocks = gs;
-                        if (walk == DRT_WALK_GRADIENTS) {
-                            if (ctx->has_specular) DRT_LAUNCH_CAMERA(true, DRT_WALK_GRADIENTS);
-                            else DRT_LAUNCH_CAMERA(false, DRT_WALK_GRADIENTS);
-                        } else if (walk == DRT_WALK_RADIANCE) {
-                            if (ctx->has_specular) DRT_LAUNCH_CAMERA(true, DRT_WALK_RADIANCE);
-                            else DRT_LAUNCH_CAMERA(false, DRT_WALK_RADIANCE);
-                        } else {
-                            if (ctx->has_specular) DRT_LAUNCH_CAMERA(true, DRT_WALK_NONE);
-                            else DRT_LAUNCH_CAMERA(false, DRT_WALK_NONE);
-                        }
+#define DRT_LAUNCH_CAMERA(SPEC)                                                                                       \
+    hipLaunchKernelGGL((k_shade<R, SPEC, true, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,         \
+                       d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, ck, \
+                       (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit)
+                        if (ctx->has_specular) DRT_LAUNCH_CAMERA(true);
+                        else DRT_LAUNCH_CAMERA(false);
 #undef DRT_LAUNCH_CAMERA
                     } else if (fused) {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
@@ -832,10 +831,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         HitRec<R>* sv_hit = k == s && fused ? cs.nx_hit : (HitRec<R>*)nullptr;
                         if (!fused) {
                             hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                               ra[cur], rb[cur], hit, ck);
+                                               ra[cur], rb[cur], hit, ck, bvh,
+                                               ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (uint32_t*)ctx->cand_count.p, cand_cap);
                             if (ctx->has_mesh)
-                                hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                                   bvh, ra[cur], rb[cur], hit, ck);
+                                hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
+                                                   ctx->stream, a, d_scene, bvh, ra[cur], rb[cur], hit, (const uint32_t*)ctx->cand.p,
+                                                   (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gp * (DRT_BLOCK / DRT_WAVE));
                             st->launches[DRT_K_INTERSECT]++;
                         }
                         if (k == s && !fused)
@@ -875,14 +876,6 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (chains_done)
                         break;
                 }
-            } else if (backward && D > 0 && walk == DRT_WALK_GRADIENTS) {
-                // the shade launch has walked every tape in place: only its per-block partial sums are left
-                if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart,
-                                   walk_blocks, n_fast, grad);
-                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
-                st->launches[DRT_K_GRADREDUCE]++;
-                st->units[DRT_K_GRADREDUCE] += (uint64_t)walk_blocks;
             } else if (backward && D > 0) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
 #define DRT_LAUNCH_BWD(NP)                                                                              \
@@ -901,7 +894,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->launches[DRT_K_GRADREDUCE]++;
                 st->units[DRT_K_GRADREDUCE] += (uint64_t)gp;
             }
-            else if (D > 0 && film && walk != DRT_WALK_RADIANCE) {
+            else if (D > 0 && film) {
                 // forward only: radiance of every path from its tape
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                 hipLaunchKernelGGL(k_radiance<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params,
@@ -986,6 +979,16 @@ int drt_hip_create(int device_id, drt_hip_ctx** out)
         delete ctx;
         return DRT_ERR_HIP;
     }
+    {   // the BVH walk is a persistent kernel whose waves own strided streams of rays: its grid must be exactly what
+        // is resident at once (more blocks would run as a second round behind the first, at half the occupancy)
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_intersect_mesh<float>, DRT_BLOCK, 0) == hipSuccess && nb > 0)
+            ctx->mesh_blocks_per_cu = nb;
+        (void)hipGetLastError();
+        if (const char* e = getenv("DRT_HIP_MESH_BLOCKS_PER_CU"))
+            if (atoi(e) > 0)
+                ctx->mesh_blocks_per_cu = atoi(e);
+    }
     *out = ctx;
     return DRT_OK;
 }
@@ -1007,7 +1010,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->fpart, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->fpart, &ctx->cand, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
@@ -1740,6 +1743,19 @@ int drt_hip_synchronize(drt_hip_ctx* ctx)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return DRT_OK;
 }
+
+#ifdef DRT_BVH_STATS
+// debug build only: read and clear the traversal counters of k_intersect_mesh (drt_kernels.h)
+extern "C" int drt_hip_debug_bvh_stats(unsigned long long* out8)
+{
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bvh_stats), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    unsigned long long zero[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), zero, sizeof zero);
+    return 0;
+}
+#endif
 
 const char* drt_hip_last_error(drt_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

@@ -358,11 +358,18 @@ __device__ inline uint32_t chunk_slot(const BatchArgs& a, const uint32_t* __rest
     return off < cnt ? (w << a.region_shift) + off : 0xFFFFFFFFu;
 }
 
+// Scenes with a mesh: the analytic pass also decides which rays the BVH walk has to see at all -- those that reach the
+// box around all triangles before their analytic hit.  In a room with one object that is a quarter of the rays; the
+// others would only drag the walk's lanes through refills (measured: 13 of 64 lanes busy per node visit, 3 per leaf).
+// Every wave of this kernel appends its candidates (wave ballot + prefix rank, no atomics) to ONE dense list of its
+// own -- span [list * cand_cap, ...) of `cand`, length in cand_count[list] -- and the walk's waves pull whole lists
+// from a device-wide counter: dense lanes from the first node on, and no wave is stuck with a stream of hard rays.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
             const typename Q2<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
-            const uint32_t* __restrict__ counts_k)
+            const uint32_t* __restrict__ counts_k, DevBvh<R> bvh, uint32_t* __restrict__ cand,
+            uint32_t* __restrict__ cand_count, uint32_t cand_cap)
 {
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
@@ -371,7 +378,11 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     const uint32_t n_chunks = a.n_regions << (a.region_shift - 6);
     const int n_shapes = sc->n_shapes;
     constexpr int NR = DRT_K2_RAYS;
-    for (uint32_t c = grid_wave(); c < n_chunks; c += NR * n_waves) {
+    const uint32_t gw = grid_wave();
+    uint32_t n_cand = 0;                                        // length of this wave's candidate list
+    if (cand && blockIdx.x == 0 && threadIdx.x == 0)
+        cand_count[n_waves] = 0;                                // the walk's list counter (it runs after this kernel)
+    for (uint32_t c = gw; c < n_chunks; c += NR * n_waves) {
         uint32_t slot[NR];
         R4 ra[NR];
         R2 rb[NR];
@@ -388,7 +399,29 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
         for (int r = 0; r < NR; ++r)
             if (slot[r] != 0xFFFFFFFFu)
                 hit[slot[r]] = h[r];
+        if (cand) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const uint32_t cr = c + (uint32_t)r * n_waves;
+                if (cr >= n_chunks)
+                    continue;                                   // (wave-uniform)
+                bool reach = false;
+                if (slot[r] != 0xFFFFFFFFu) {
+                    const V3<R> o = mk<R>(ra[r].x, ra[r].y, ra[r].z), d = mk<R>(ra[r].w, rb[r].x, rb[r].y);
+                    const V3<R> inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+                    R tn;
+                    reach = box_hit(mk<R>(bvh.lo[0], bvh.lo[1], bvh.lo[2]), mk<R>(bvh.hi[0], bvh.hi[1], bvh.hi[2]), o, inv_d, h[r].t, tn);
+                }
+                uint32_t n_reach;
+                const uint32_t rank = wave_rank(reach, n_reach);
+                if (reach)
+                    cand[(size_t)gw * cand_cap + n_cand + rank] = slot[r];
+                n_cand += n_reach;
+            }
+        }
     }
+    if (cand && lane == 0)
+        cand_count[gw] = n_cand;
 }
 
 // ---- K2 (scenes with triangle meshes) -----------------------------------------------------------
@@ -404,11 +437,20 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
 //     meet again ("while-while"), so triangle tests run with many lanes active.
 // Exact ties keep the primitive that comes first in the flattened scene, like the reference's
 // linear scan (pathtracer.hpp:80): (t, flat index) is compared lexicographically.
+#ifdef DRT_BVH_STATS
+// debug build only (tools/): [0] rays, [1] node visits served from LDS, [2] from memory, [3] leaf visits, [4] triangle tests
+__device__ unsigned long long g_bvh_stats[8];
+#define DRT_STAT(i, n) atomicAdd(&g_bvh_stats[i], (unsigned long long)(n))
+#else
+#define DRT_STAT(i, n)
+#endif
+
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                  const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
-                 HitRec<R>* hit, const uint32_t* __restrict__ counts_k)
+                 HitRec<R>* hit, const uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
+                 uint32_t n_lists)
 {
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
@@ -421,14 +463,13 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     __syncthreads();
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const uint32_t cpr_shift = a.region_shift - 6;
-    const uint32_t n_chunks = a.n_regions << cpr_shift;
     const int n_shapes = sc->n_shapes;
 
-    // the wave's stream: chunks next_chunk, next_chunk + n_waves, ...; the current chunk's rays are
-    // slots [cur_base + cur_off, cur_base + cur_cnt)
-    uint32_t next_chunk = grid_wave(), cur_base = 0, cur_cnt = 0, cur_off = 0;
+    // the wave's stream: whole candidate lists (k_intersect), pulled from the device-wide counter cand_count[n_lists]
+    // (one returning atomic per list of ~64 rays: far from the ~88 / us a single address sustains); the current
+    // list's rays are cand[cur_base + cur_off .. cur_base + cur_cnt)
+    uint32_t cur_base = 0, cur_cnt = 0, cur_off = 0;
+    bool dry = false;                                           // no list left
 
     bool active = false;
     uint32_t slot = 0, cur = DRT_BVH_NONE, best_flat = 0xFFFFFFFFu;
@@ -439,18 +480,23 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     for (;;) {
         // ---- refill idle lanes from the stream
         if ((uint32_t)__popcll(__ballot(!active)) >= a.bvh_refill) {
+            if ((threadIdx.x & 63) == 0) DRT_STAT(7, 1);          // (stats: refill events)
             bool want = !active;
             for (;;) {
                 if (cur_off >= cur_cnt) {
-                    if (next_chunk >= n_chunks)
+                    if (dry)
                         break;
-                    const uint32_t w = next_chunk >> cpr_shift;
-                    const uint32_t off = (next_chunk - (w << cpr_shift)) * DRT_WAVE;
-                    const uint32_t cnt = __builtin_amdgcn_readfirstlane(counts_k[w]);
-                    cur_base = (w << a.region_shift) + off;
-                    cur_cnt = cnt > off ? (cnt - off < DRT_WAVE ? cnt - off : DRT_WAVE) : 0;
+                    uint32_t list = 0;
+                    if ((tid & (DRT_WAVE - 1)) == 0)
+                        list = atomicAdd(cand_count + n_lists, 1u);
+                    list = __builtin_amdgcn_readfirstlane(list);
+                    if (list >= n_lists) {
+                        dry = true;
+                        break;
+                    }
+                    cur_base = list * cand_cap;
+                    cur_cnt = __builtin_amdgcn_readfirstlane(cand_count[list]);
                     cur_off = 0;
-                    next_chunk += n_waves;
                     continue;
                 }
                 const uint64_t wmask = __ballot(want);
@@ -460,13 +506,14 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
                 if (want && rank < avail) {
-                    slot = cur_base + cur_off + rank;
-                    const R4 ra = ray_a[slot];
-                    const R2 rb = ray_b[slot];
+                    slot = cand[cur_base + cur_off + rank];
+                    // the ray stream is read once: non-temporal, so that it does not push the BVH out of the XCD's L2
+                    const R4 ra = nt_load(ray_a + slot);
+                    const R2 rb = nt_load(ray_b + slot);
                     const HitRec<R> h0 = hit[slot];             // closest analytic shape (k_intersect)
                     o = mk<R>(ra.x, ra.y, ra.z);
                     d = mk<R>(ra.w, rb.x, rb.y);
-                    inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+                    inv_d = mk<R>(div_r(R(1), d.x), div_r(R(1), d.y), div_r(R(1), d.z));   // (f32: v_rcp; the boxes are padded)
                     tmin = h0.t;
                     prim = h0.prim;
                     best_flat = h0.prim >= 0 ? (uint32_t)sc->flat[h0.prim] : 0xFFFFFFFFu;
@@ -474,6 +521,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     sp = 0;
                     want = false;
                     active = true;
+                    DRT_STAT(0, 1);
                 }
                 cur_off += n_want < avail ? n_want : avail;
             }
@@ -491,9 +539,11 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             if ((uint32_t)__popcll(dmask) < a.bvh_descend_min &&
                 __ballot(active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) != 0)
                 break;
+            if ((threadIdx.x & 63) == 0) DRT_STAT(5, 1);          // (stats: interior wave-iterations)
             if (!descending)
                 continue;
             uint4 w0, w1, w2, w3;
+            DRT_STAT(cur < n_lds ? 1 : 2, 1);
             if (cur < n_lds) {
                 w0 = s_node[cur][0]; w1 = s_node[cur][1]; w2 = s_node[cur][2]; w3 = s_node[cur][3];
             } else {
@@ -532,8 +582,11 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
         // ---- leaves
+        if ((threadIdx.x & 63) == 0) DRT_STAT(6, 1);              // (stats: outer wave-iterations)
         if (active && (cur & DRT_BVH_LEAF) && cur != DRT_BVH_NONE) {
             const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, count = cur & 7u;
+            DRT_STAT(3, 1);
+            DRT_STAT(4, count);
             // all triangles of the leaf (<= kMaxLeaf = 4) are requested before the first is tested:
             // one round trip to L2 per leaf instead of one per triangle
             R4 ta[4], tb[4], tcc[4];
@@ -943,29 +996,6 @@ __device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ 
     return mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1], (R)adjoint[(size_t)gp * 3 + 2]);
 }
 
-// Forward-only: the radiance of a path of at most DRT_TAPE_CHUNK vertices from its records, deepest
-// vertex first (the walk of k_radiance on one chunk).
-template <typename R>
-__device__ inline V3<R> radiance_of_chunk(const BatchArgs& a, const SceneLds<R>& lds, const R* __restrict__ params,
-                                         const TapeRec<R>* trs, int K, R inv_p_rr)
-{
-    V3<R> L = mk<R>(R(0), R(0), R(0));
-#pragma unroll
-    for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
-        if (j < K) {
-            const uint32_t cid = trs[j].ids & 0xFFFFu, eid = trs[j].ids >> 16;
-            const R inv_pk = j >= a.min_bounces ? inv_p_rr : R(1);
-            V3<R> Lk = mk<R>(R(0), R(0), R(0));
-            if (eid != DRT_ID_NONE)
-                Lk = load_param(lds, params, (int)eid) * inv_pk;
-            if (cid != DRT_ID_NONE)
-                Lk = Lk + load_param(lds, params, (int)cid) * (L * trs[j].m);
-            L = Lk;
-        }
-    }
-    return L;
-}
-
 // next region >= w this wave shades; CAM: depth 0, region w holds its share of the batch's paths
 template <bool CAM>
 __device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __restrict__ counts_k, uint32_t w,
@@ -987,15 +1017,8 @@ __device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __res
 // segment.  Used whenever nothing else needs the hit records (no mesh, no unbiased chain vertices).
 // CAM (fused launches that start at depth 0, every path alive there): the camera ray is generated in
 // place -- K1 folded in too: nothing is read from the queue, the row of depth 0 is written here.
-// WALK (camera launches that take every path from the eye to its end, depth cap <= DRT_TAPE_CHUNK): the
-// tape never leaves the CU -- each lane keeps its path's records in an LDS column and walks them as
-// soon as the path has ended: DRT_WALK_RADIANCE = the radiance of the path (forward-only renders),
-// DRT_WALK_GRADIENTS = K6 in place (<= 4 parameters: register accumulators, the block reduction of
-// k_backward at the end of the kernel).  No tape, no vertex counts, no K6 / k_radiance launch.
-#define DRT_WALK_NONE 0
-#define DRT_WALK_RADIANCE 1
-#define DRT_WALK_GRADIENTS 2
-template <typename R, bool SPEC, bool FUSED, bool CAM = false, int WALK = DRT_WALK_NONE>
+// (A launch that takes every path from the eye to its end needs neither queue nor tape: that is k_path, drt_path.h.)
+template <typename R, bool SPEC, bool FUSED, bool CAM = false>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
@@ -1007,9 +1030,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         const typename Q4<R>::T* __restrict__ tri_shade,
         int seg_start, const uint32_t* __restrict__ draw_base,
         typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
-        HitRec<R>* __restrict__ save_hit,
-        const float* __restrict__ adjoint = nullptr, double* __restrict__ gpart = nullptr,
-        typename Q4<R>::T* __restrict__ lacc = nullptr)
+        HitRec<R>* __restrict__ save_hit)
 {
     // nb > 1 (FUSED only): the launch takes every ray through nb bounces -- depths k .. k+nb-1 -- in
     // registers; only the survivors of the LAST one are compacted and written back.  Lanes whose
@@ -1020,11 +1041,6 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     __shared__ SceneLds<R> lds;
-    __shared__ TapeRec<R> s_tape[WALK ? DRT_TAPE_CHUNK : 1][WALK ? DRT_BLOCK : 1];
-    __shared__ double s_red[WALK == DRT_WALK_GRADIENTS ? DRT_BLOCK / DRT_WAVE : 1][DRT_FAST_PARAMS * 3];
-    GradAcc<R, 4> ga;
-    if (WALK == DRT_WALK_GRADIENTS)
-        ga.init(nullptr);
     stage_scene(lds, sc, params);
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
@@ -1035,9 +1051,8 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
 
     uint32_t cnt;
     uint32_t w = next_region<CAM>(a, counts_k, grid_wave(), n_waves, cnt);
-    if (!WALK && w >= a.n_regions)
+    if (w >= a.n_regions)
         return;
-    if (w < a.n_regions) {              // (a WALK launch ends with a block-wide reduction: no early exit)
     uint32_t off = 0, running = 0;
     ShadeIn<R> cur, nxt;
     bool have = lane < cnt;
@@ -1062,7 +1077,6 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         }
 
         bool alive = false, live = have;
-        int k_lane = 0;                                        // WALK: vertices of this lane's path
         R4 ra = cur.ra, na;
         R2 rb = cur.rb, nb2;
         const uint32_t pid = cur.rid.x, key = cur.rid.y;
@@ -1138,17 +1152,10 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                         nb2.x = wo.y; nb2.y = wo.z;
                     }
                 }
-                if (WALK) {
-                    if (write_tape)
-                        s_tape[it][threadIdx.x] = tr;          // own column: written and read by this lane only
-                    if (ended)
-                        k_lane = (int)n_vertices;
-                } else {
-                    if (write_tape)
-                        tape_kk[pid] = tr;
-                    if (ended)
-                        nv[pid] = n_vertices;
-                }
+                if (write_tape)
+                    tape_kk[pid] = tr;
+                if (ended)
+                    nv[pid] = n_vertices;
             }
             if (next_cap && !a.cap_is_roulette) {                  // row D of the counts: paths the cap cut short
                 const uint32_t n_cap = (uint32_t)__popcll(__ballot(capped));
@@ -1166,26 +1173,6 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
             ra = na;
             rb = nb2;
             live = alive;
-        }
-        if (WALK && have) {
-            // the path has ended inside this launch: walk its records now
-            TapeRec<R> first[DRT_TAPE_CHUNK];
-#pragma unroll
-            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
-                first[j] = s_tape[j][threadIdx.x];
-            V3<R> L0 = mk<R>(R(0), R(0), R(0));
-            if (k_lane > 0) {
-                if (WALK == DRT_WALK_GRADIENTS)
-                    L0 = backward_path<R, true>(a, lds, params, (const TapeRec<R>*)nullptr, N, pid, k_lane,
-                                               path_seed<R>(a, adjoint, pid), inv_p_rr, ga, nullptr, nullptr, first);
-                else
-                    L0 = radiance_of_chunk<R>(a, lds, params, first, k_lane, inv_p_rr);
-            }
-            if (lacc) {
-                R4 o4;
-                o4.x = L0.x; o4.y = L0.y; o4.z = L0.z; o4.w = R(0);
-                lacc[pid] = o4;
-            }
         }
         uint32_t n_alive;
         const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
@@ -1211,28 +1198,6 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         w = nw;
         off = noff;
         cnt = ncnt;
-    }
-    }
-    if (WALK == DRT_WALK_GRADIENTS) {
-        // block reduction in fp64, as in k_backward: thread -> wave (shuffles) -> block (LDS), fixed order
-        const int wv = threadIdx.x / DRT_WAVE;
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            double v = ga.get(nullptr, r);
-#pragma unroll
-            for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)
-                v += __shfl_down(v, o2);
-            if (lane == 0)
-                s_red[wv][r] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < DRT_FAST_PARAMS * 3) {
-            double v = 0;
-            if (threadIdx.x < 12)
-                for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
-                    v += s_red[ww][threadIdx.x];
-            gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
-        }
     }
 }
 
@@ -1308,7 +1273,7 @@ k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float
     }
 }
 
-// ---- K6 (kernel; the tape walk and the accumulators it uses are defined before K3, which can run them in place) ----
+// ---- K6 (kernel; the tape walk and the accumulators it uses are defined above) ----
 template <typename R, int NP>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : 1)
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Traversal statistics of k_intersect_mesh from a -DDRT_BVH_STATS build of the library (debug only):
+node visits (LDS / memory), leaf visits and triangle tests per ray.  Usage: tools/bvh_stats.py build/lib_stats.so [scene]"""
+import ctypes as C, os, sys
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+pkg = e.load_package()
+lib_path = os.path.abspath(sys.argv[1])
+scene = pkg.scene_by_name(sys.argv[2] if len(sys.argv) > 2 else "mesh160x160")
+r = pkg.HipRenderer(0, lib_path=lib_path)
+r.upload_scene(scene)
+cam = pkg.cornell_camera(512, 512)
+rp = pkg.RenderParams(spp=8, min_bounces=8, absorb=1.0, seed=1)
+out = (C.c_ulonglong * 8)()
+r.lib.drt_hip_debug_bvh_stats(out)
+_, _, st = r.render(cam, rp, backward=True)
+r.lib.drt_hip_debug_bvh_stats(out)
+rays, lds, mem, leaves, tris = out[0], out[1], out[2], out[3], out[4]
+print(f"rays {rays}  (segments {st['segments']})")
+print(f"per ray: node visits from LDS {lds / rays:.2f}, from memory {mem / rays:.2f}, leaf visits {leaves / rays:.2f}, triangle tests {tris / rays:.2f}")
+print(f"wave level: interior iterations {out[5]}, outer iterations {out[6]}, refill events {out[7]}; lanes busy per interior iteration {(lds + mem) / max(1, out[5]):.1f} of 64, "
+      f"leaf lanes per outer iteration {leaves / max(1, out[6]):.1f}")
+print(f"16-byte lane accesses per ray: nodes {4 * mem / rays:.1f} + triangles {3 * tris / rays:.1f} + ray/hit 3")
