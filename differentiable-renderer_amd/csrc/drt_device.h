@@ -272,7 +272,7 @@ __device__ inline bool tri_intersect(V3<R> v0, V3<R> e1, V3<R> e2, V3<R> o, V3<R
     const R det = dot(e1, pvec);
     if (det == R(0))
         return false;
-    const R inv = R(1) / det;
+    const R inv = div_r(R(1), det);           // (f32: v_rcp)
     const V3<R> tvec = o - v0;
     const R u = dot(tvec, pvec) * inv;
     if (u < R(0) || u > R(1))

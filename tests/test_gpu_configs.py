@@ -1,0 +1,88 @@
+"""BASELINE.json configs 4 and 5 at the share ONE of their 8 GPUs renders (what `bench.py --config 4|5` times):
+the full-size f32 render is checked through size-independent properties, and single image rows of it are checked
+against the fp64 oracle (rows are independent: RNG keys depend on (pixel, sample) only), exactly in the f64 device
+mode and to the stated f32 tolerances."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def grad_rel_err(got, want):
+    return float(np.abs(got - want).max() / np.abs(want).max())
+
+
+def one_row(rp, row, height, **kw):
+    """render parameters that select image row `row` only (bands of one row dealt to `height` shards)"""
+    return dataclasses.replace(rp, shard=row, n_shards=height, band_rows=1, **kw)
+
+
+@pytest.mark.timeout(900)
+def test_config4_share_1024x1024x32_mesh(pkg, hip, oracle):
+    """config 4: 1024 x 1024, 256 spp over 8 GPUs = 32 spp per GPU, 50,880-triangle mesh in the box, fwd+bwd."""
+    scene = pkg.scene_by_name("mesh160x160")
+    cam = pkg.cornell_camera(1024, 1024)
+    rp = pkg.RenderParams(spp=32, min_bounces=8, absorb=1.0, seed=1)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    assert st["paths"] == 1024 * 1024 * 32 and st["kernels"]["intersect_mesh"]["launches"] == 8 * st["batches"]
+    assert np.isfinite(img).all() and np.isfinite(grads).all()
+    e = scene.param_names.index("emission")
+    total = img.astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[e] * np.array(scene.params[e]), total, rtol=5e-6)    # linear in the emission
+    # a row through the mesh against the oracle's brute-force triangle loop (2 spp: 1.4e4 rays x 50,880 triangles)
+    row = 560
+    rr = one_row(rp, row, 1024, spp=2)
+    ref = oracle.render(scene, cam, rr, backward=True)
+    i64, g64, s64 = hip.render(cam, rr, backward=True, f64=True)
+    assert s64["segments"] == ref["stats"]["segments"]
+    assert grad_rel_err(g64, ref["grads"]) < 1e-9
+    np.testing.assert_allclose(i64[row], ref["image"][row].astype(np.float32), rtol=2e-7, atol=1e-12)
+    i32, g32, s32 = hip.render(cam, rr, backward=True)
+    assert abs(s32["segments"] - ref["stats"]["segments"]) <= 64
+    assert grad_rel_err(g32, ref["grads"]) <= 1e-4
+    bad = np.abs(i32[row].astype(np.float64) - ref["image"][row]).max(-1) > 2e-4 * np.abs(ref["image"][row]).max()
+    assert bad.sum() <= 1
+    # the same row of the full render is that row rendered alone at 32 spp (shards tile the frame bit for bit)
+    alone, _, _ = hip.render(cam, one_row(rp, row, 1024), backward=True)
+    np.testing.assert_array_equal(alone[row], img[row])
+
+
+@pytest.mark.timeout(900)
+def test_config5_share_2048x2048_depth16_specular(pkg, hip, oracle):
+    """config 5: 2048 x 2048, depth 16, diffuse + specular (1024 spp over 8 GPUs = 128 per GPU; 8 spp here -- the
+    per-sample work is what the test exercises, bench.py --config 5 runs the 128)."""
+    scene = pkg.scene_by_name("cornell_specular")
+    cam = pkg.cornell_camera(2048, 2048)
+    rp = pkg.RenderParams(spp=8, min_bounces=16, absorb=1.0, seed=1)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    assert st["paths"] == 2048 * 2048 * 8 and st["segments"] > 10 * st["paths"]
+    assert st["kernels"]["path"]["launches"] == 1                     # the whole depth-16 path in one launch
+    assert np.isfinite(img).all() and np.isfinite(grads).all()
+    e = scene.param_names.index("emission")
+    total = img.astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[e] * np.array(scene.params[e]), total, rtol=5e-6)
+    # two rows (one through the specular sphere) against the oracle
+    for row in (1024, 1500):
+        rr = one_row(rp, row, 2048)
+        ref = oracle.render(scene, cam, rr, backward=True)
+        i64, g64, s64 = hip.render(cam, rr, backward=True, f64=True)
+        assert s64["segments"] == ref["stats"]["segments"]
+        assert grad_rel_err(g64, ref["grads"]) < 1e-9
+        np.testing.assert_allclose(i64[row], ref["image"][row].astype(np.float32), rtol=2e-7, atol=1e-12)
+        np.testing.assert_array_equal(img[row], hip.render(cam, rr, backward=True)[0][row])
+        i32, g32, s32 = hip.render(cam, rr, backward=True)
+        assert abs(s32["segments"] - ref["stats"]["segments"]) <= 64
+        assert grad_rel_err(g32, ref["grads"]) <= 1e-4
+        scale = np.abs(ref["image"][row]).max()
+        bad = np.abs(i32[row].astype(np.float64) - ref["image"][row]).max(-1) > 2e-4 * scale
+        assert bad.sum() <= 1
+    # the queue wavefront (one launch per bounce) traces the same paths up to f32-flipped decisions (its closest-hit
+    # arithmetic is not k_path's): segment counts within 1e-6, values to f32 rounding
+    q_img, q_grads, q_st = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True)
+    assert abs(q_st["segments"] - st["segments"]) <= 1e-6 * st["segments"] and q_st["kernels"]["shade"]["launches"] == 16 * q_st["batches"]
+    assert grad_rel_err(q_grads, grads) < 2e-5
+    np.testing.assert_allclose(q_img, img, rtol=2e-4, atol=1e-5)

@@ -486,11 +486,12 @@ def test_results_do_not_depend_on_bounces_per_launch(pkg, hip, scene_name, b, p,
     ref = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, unbiased=unbiased)
     for nb in (0, 2, 3, 8):
         got = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=nb), backward=True, unbiased=unbiased)
-        assert got[2]["segments"] == ref[2]["segments"]
         if nb == 0 and got[2]["kernels"]["path"]["launches"]:
+            assert abs(got[2]["segments"] - ref[2]["segments"]) <= 64      # (its f32 closest-hit arithmetic is its own)
             np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-7)
             np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=1e-6 * np.abs(ref[1]).max())
             continue
+        assert got[2]["segments"] == ref[2]["segments"]
         np.testing.assert_array_equal(got[0], ref[0])
         np.testing.assert_array_equal(got[1], ref[1])
         overridden = os.environ.get("DRT_HIP_SHADE_BOUNCES") or os.environ.get("DRT_HIP_FUSE") == "0"   # debug knobs win
