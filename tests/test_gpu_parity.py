@@ -332,10 +332,9 @@ def test_unbiased_backward_matches_reference(pkg, hip, name):
     assert grad_rel_err(grads, g["grads"]) < 1e-9
     np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
     img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, unbiased=True)
-    assert abs(st["segments"] - int(g["segments"])) <= max(64, int(5e-4 * int(g["segments"])))
-    # a flipped decision in one of the ~10 suffix paths of a sample changes that sample's
-    # contribution: allow one sample's worth on these few-thousand-path fixtures
-    assert grad_rel_err(grads, g["grads"]) <= 2e-3
+    assert abs(st["segments"] - int(g["segments"])) <= 64
+    # measured on the six fixtures (profiles/r02_parity_report.txt): <= 3.5e-6, no flipped path; the bound is 3 x that
+    assert grad_rel_err(grads, g["grads"]) <= 1e-5
     # deterministic
     img2, grads2, _ = hip.render(cam, rp, backward=True, adjoint=adjoint, unbiased=True)
     np.testing.assert_array_equal(grads, grads2)
