@@ -67,6 +67,15 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def load_distributed():
+    """differentiable-renderer_amd/distributed.py (the directory name has a hyphen)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("drt_distributed", os.path.join(ROOT, "differentiable-renderer_amd", "distributed.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _oracle_shard(args):
     """Worker of the all-cores CPU figure: one row-band shard of the sample, in its own process."""
     import __graft_entry__ as entry
@@ -160,21 +169,11 @@ def main():
     reduce_mode = None
     if use_dist and backward:
         reduce_mode = a.reduce
-        if reduce_mode == "library":
-            uid = [pkg.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            try:
-                r.comm_init(uid[0], rank, world)
-            except pkg.DrtHipError as e:            # e.g. --same-gpu: RCCL refuses two ranks on one device
-                if rank == 0:
-                    print(f"bench.py: in-library communicator unavailable ({e}); reducing with torch.distributed", file=sys.stderr)
-                reduce_mode = "torch"
-            ok = torch.tensor([1 if reduce_mode == "library" else 0], device=dev if a.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if reduce_mode == "library":
-                    r.comm_destroy()
-                reduce_mode = "torch"
+        if reduce_mode == "library" and not load_distributed().join_library_communicator(r, pkg):
+            # e.g. --same-gpu: RCCL refuses two ranks on one device
+            if rank == 0:
+                print("bench.py: in-library communicator unavailable; reducing with torch.distributed", file=sys.stderr)
+            reduce_mode = "torch"
     flags = (pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0) | (pkg.RENDER_ALLREDUCE if reduce_mode == "library" else 0)
     rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
                           shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
@@ -262,14 +261,17 @@ def main():
              "raygen": paths, "film": paths, "gradreduce": 0}
     # fused shade: tape 8 B/segment + 32 B per ray read from / written to the queue (the library counts both);
     # unfused (mesh scenes): ray 24 + id 8 + hit 8 read, ray 24 + id 8 + tape 8 written;
-    # k_path: a path lives in registers from the eye to its end: 16 B of radiance per PATH is all it moves;
+    # k_path: a path lives in registers from the eye to its end; the launch writes 24 B per pixel and sample range,
+    # 192 B per block (gradient partials) and 8 B per wave (counters): stats["path_bytes"], ~0.2 B per segment;
     # k_intersect_mesh: ray 24 + hit 8 read, hit 8 written (the BVH itself is L2 / Infinity-Cache resident)
     seg = max(1, segments)
     bpu = {"intersect": 32.0, "intersect_mesh": 40.0,
            "shade": 80.0 if kernel_launches["intersect"] else
                     (8.0 if kernel_launches["backward"] else 16.0 * paths / seg) + 32.0 * queue_rays / seg,
-           "path": 16.0 * paths / seg,
-           "backward": 8.0, "raygen": 32.0, "film": 16.0, "gradreduce": 0.0}
+           "path": stats.get("path_bytes", 0) / seg,
+           "backward": 8.0, "raygen": 32.0, "gradreduce": 0.0,
+           # K5 reads 16 B of radiance per path; behind k_path it reads the per-range pixel sums that launch wrote
+           "film": stats.get("path_bytes", 0) / max(1, paths) if kernel_launches["path"] else 16.0}
     per_kernel = {}
     for k in pkg.KERNEL_NAMES:
         ms = kernel_ms[k] / n_prof

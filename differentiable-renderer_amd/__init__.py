@@ -91,13 +91,13 @@ class HipStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double * K_COUNT),
                 ("launches", C.c_uint64 * K_COUNT), ("units", C.c_uint64 * K_COUNT),
                 ("queue_rays_read", C.c_uint64), ("queue_rays_written", C.c_uint64),
-                ("capped_paths", C.c_uint64), ("bvh_bytes", C.c_uint64)]
+                ("capped_paths", C.c_uint64), ("bvh_bytes", C.c_uint64), ("path_bytes", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {"paths": int(self.paths), "segments": int(self.segments),
              "batches": int(self.batches), "ms_total": float(self.ms_total), "kernels": {},
              "queue_rays_read": int(self.queue_rays_read), "queue_rays_written": int(self.queue_rays_written),
-             "capped_paths": int(self.capped_paths), "bvh_bytes": int(self.bvh_bytes)}
+             "capped_paths": int(self.capped_paths), "bvh_bytes": int(self.bvh_bytes), "path_bytes": int(self.path_bytes)}
         for k, name in enumerate(KERNEL_NAMES):
             d["kernels"][name] = {"ms": float(self.ms_kernel[k]), "launches": int(self.launches[k]),
                                   "units": int(self.units[k])}

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "drt_hip.h"
+#include "drt_sincos.h"
 
 #define DRT_MAX_SHAPES 64
 #define DRT_MAX_MATERIALS 64
@@ -192,26 +193,7 @@ __device__ inline double pow_weight_r(double x, double y) { return pow(x, y); }
 __device__ inline double pow_r(double x, double y) { return pow(x, y); }
 __device__ inline void sincospi_r(float x, float* s, float* c) { sincospif(x, s, c); }
 __device__ inline void sincospi_r(double x, double* s, double* c) { sincospi(x, s, c); }
-// sin and cos of phi = 2 pi u for the 31-bit draw r, u = r / RAND_MAX (bxdf.hpp:73,110).
-// f32: the reduction is done on the INTEGER -- quadrant q = round(4 r / 2^31), remainder xi = r - q 2^29 in
-// [-2^28, 2^28], x = xi 2 pi / 2^31 in [-pi/4, pi/4] -- so no precision is lost before the polynomials (the float u
-// carries 24 of the draw's 31 bits, this keeps 29) and none of sincospif's general range reduction and special cases
-// is executed: 24 instead of 38 VALU.  2^31 stands for RAND_MAX = 2^31 - 1: an angle error of 3e-9 rad, 20x below
-// f32 resolution.  Cephes' minimax polynomials for |x| <= pi/4 (~1 ulp).  f64: sincospi of 2 u, correctly rounded.
-__device__ inline void sincos_2pi_u31(uint32_t r, float* s, float* c)
-{
-    const uint32_t q = (r + 0x10000000u) >> 29;                    // 0..4
-    const int32_t xi = (int32_t)(r - (q << 29));
-    const float x = (float)xi * 2.9258361585343192e-09f;           // 2 pi / 2^31
-    const float z = x * x;
-    const float sp = x + x * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
-    const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
-    const bool swap = (q & 1u) != 0;
-    const float ss = swap ? cp : sp, cc = swap ? sp : cp;
-    // quadrant 0: (s, c); 1: (c, -s); 2: (-s, -c); 3: (-c, s); 4 = 0
-    *s = __uint_as_float(__float_as_uint(ss) ^ ((q & 2u) << 30));
-    *c = __uint_as_float(__float_as_uint(cc) ^ (((q + 1u) & 2u) << 30));
-}
+// sin and cos of phi = 2 pi u for the 31-bit draw r, f32: drt_sincos.h (also compiled on the host by its known-answer test)
 __device__ inline void sincos_2pi_u31(uint32_t r, double* s, double* c) { sincospi(2.0 * ((double)r / DRT_RAND_MAX_D), s, c); }
 template <typename R> __device__ inline V3<R> normalize(V3<R> a) { return a * rsqrt_r(dot(a, a)); }
 // vector.hpp:602-606

@@ -662,6 +662,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #undef DRT_LAUNCH_PATH
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_PATH]++;
+                st->path_bytes += (film ? (uint64_t)pa.n_ranges * a.Pb * 3 * sizeof(double) : 0) +
+                                  (backward ? (uint64_t)gpath * DRT_FAST_PARAMS * 3 * sizeof(double) : 0) + 2 * n_waves * sizeof(uint32_t);
                 hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts, (uint32_t)(2 * n_waves),
                                    (unsigned long long*)ctx->segtotal.p, (uint32_t)n_waves, 0ull, 0ull, 1u);
                 if (backward) {
@@ -1521,6 +1523,7 @@ static int render_group(drt_hip_ctx* g, const drt_camera_desc* cam, const drt_re
             st.queue_rays_read += mstats[i].queue_rays_read;
             st.queue_rays_written += mstats[i].queue_rays_written;
             st.capped_paths += mstats[i].capped_paths;
+            st.path_bytes += mstats[i].path_bytes;
             for (int k = 0; k < DRT_K_COUNT; ++k) {
                 st.units[k] += mstats[i].units[k];
                 if (mstats[i].ms_kernel[k] > st.ms_kernel[k])

@@ -1,8 +1,13 @@
-"""Pixel sharding across the GPUs of one node: one process per GPU (torch.distributed, backend
-"nccl" = RCCL over xGMI on ROCm, "gloo" on CPU for tests).  Every (pixel, sample) path is
+"""Pixel sharding across the GPUs of one node: one process per GPU.  Every (pixel, sample) path is
 independent (/root/reference/src/render.cpp:72-81); the only cross-rank state is the P x 3
 parameter-gradient accumulator (vector.hpp:185-188), summed with ONE all-reduce per render.
-Image rows are disjoint per rank and need no collective."""
+Image rows are disjoint per rank and need no collective.
+
+The all-reduce itself lives behind the C ABI (libdrt_hip.so links RCCL: drt_hip_comm_init_rank +
+DRT_RENDER_ALLREDUCE); the launcher's job is only to hand rank 0's 128-byte communicator id to the
+other ranks -- join_library_communicator() does that over whatever torch.distributed group the job
+already has (nccl or gloo).  allreduce_grads() is the same sum done by torch.distributed: used by the
+CPU tests (gloo, the oracle standing in for the device) and as bench.py's --reduce torch A/B."""
 from __future__ import annotations
 
 import dataclasses
@@ -15,6 +20,27 @@ def shard_params(rp, rank: int, world: int, band_rows: Optional[int] = None):
     """RenderParams of `rank`: interleaved row bands so depth imbalance averages out."""
     return dataclasses.replace(rp, shard=rank if world > 1 else 0, n_shards=max(1, world),
                                band_rows=band_rows or rp.band_rows)
+
+
+def join_library_communicator(renderer, pkg, group=None) -> bool:
+    """Give `renderer` (a HipRenderer of this rank) its rank in a communicator spanning the ranks of `group`.
+    Collective.  -> True when every rank joined (renders may then carry RENDER_ALLREDUCE), False -- and no rank
+    keeps a communicator -- when any of them could not (e.g. two test ranks on one device)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = [pkg.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    joined = True
+    try:
+        renderer.comm_init(uid[0], rank, world)
+    except pkg.DrtHipError:
+        joined = False
+    ok = torch.tensor([1 if joined else 0], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0 and joined:
+        renderer.comm_destroy()
+    return int(ok.item()) == 1
 
 
 def allreduce_grads(grads, group=None):

@@ -188,6 +188,8 @@ typedef struct drt_hip_stats {
     uint64_t capped_paths;          /* paths still alive when they reached max_depth (cut short: 0 when the cap is
                                        the roulette's own certain kill, absorb == 1 at min_bounces) */
     uint64_t bvh_bytes;             /* mesh scenes: bytes of the BVH (nodes + triangle records) the walk reads from */
+    uint64_t path_bytes;            /* k_path launches: the bytes they write (per-range pixel sums, per-block gradient
+                                       partials, per-wave counters) -- everything that kernel moves through HBM */
 } drt_hip_stats;
 
 typedef struct drt_hip_ctx drt_hip_ctx;

@@ -56,3 +56,15 @@ def test_bvh_builder_and_node_encoding_known_answers(tmp_path):
                    check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.strip().endswith("ok"), out
+
+
+def test_integer_reduced_sincos_known_answers(tmp_path):
+    """csrc/drt_sincos.h (the f32 sin/cos of phi = 2 pi u that every BxDF sample uses on the device) compiled for
+    the host: a sweep of the 31-bit draw range against libm in double, max abs error < 2e-7, exact at 0 and 1/2."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sincos_kat")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", os.path.join(root, "tests", "cpp", "sincos_kat.cpp"),
+                    "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().endswith("ok"), out
