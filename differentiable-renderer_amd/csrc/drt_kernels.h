@@ -751,11 +751,10 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
         // relative accuracy where the literal form cancels, without a double-precision pow.
         R ct, st, x_half = R(0);
         if (sizeof(R) == 4) {
-            const float u = u01(0.f, r1), w = one_minus_u01(0.f, r1);
-            const float lu = w < 0.5f ? log1pf(-w) : logf(u);
-            const float x = lu * (2.0f / ((float)m.exponent + 2.0f));
-            ct = (R)sqrt_r(expf(x));
-            st = (R)sqrt_r(-expm1f(x));
+            // (drt_sincos.h: hardware exp2 / log2 and short series instead of libm's expf / logf / log1pf / expm1f)
+            const float x = drt_log_u31(r1) * (2.0f / ((float)m.exponent + 2.0f));
+            ct = (R)sqrt_r(drt_exp_nonpos(x));
+            st = (R)sqrt_r(drt_one_minus_exp(x));
             x_half = (R)(0.5f * x);
         } else {
             const double c2 = pow((double)r1 / DRT_RAND_MAX_D, 2.0 / ((double)m.exponent + 2.0));
@@ -768,7 +767,7 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
             hv = reflect(hv, nrm);
         wo = reflect(wi, hv);
         // pdf: cos^(e+1) = exp((e+1) * log(cos)), and log(cos) = x / 2 is already known in f32
-        q = m.norm * (sizeof(R) == 4 ? (R)expf((float)((m.exponent + R(1)) * x_half)) : pow_r(ct, m.exponent + R(1))) * st;
+        q = m.norm * (sizeof(R) == 4 ? (R)drt_exp_nonpos((float)((m.exponent + R(1)) * x_half)) : pow_r(ct, m.exponent + R(1))) * st;
         // bxdf.hpp:91-104 re-derives the half vector as normalize(dir_in + dir_out).  That sum is
         // 2 (h . wi) h: when h is nearly perpendicular to wi it cancels, and in f32 it can cancel
         // to exactly 0 (-> NaN; seen once per ~3e7 paths at depth 12).  f32 therefore uses the

@@ -1,4 +1,8 @@
-// drt_sincos.h -- sin and cos of phi = 2 pi u for the 31-bit draw r, u = r / RAND_MAX (bxdf.hpp:73,110), in f32.
+// drt_sincos.h -- the f32 transcendentals of BxDF sampling, written for the hardware's 1-ulp v_exp_f32 / v_log_f32
+// instead of libm's multi-branch expf / logf / log1pf / expm1f (30-60 VALU each), host + device so that
+// tests/cpp/sincos_kat.cpp can sweep them against libm in double.
+//
+// (1) sin and cos of phi = 2 pi u for the 31-bit draw r, u = r / RAND_MAX (bxdf.hpp:73,110).
 //
 // The reduction is done on the INTEGER -- quadrant q = round(4 r / 2^31), remainder xi = r - q 2^29 in
 // [-2^28, 2^28], x = xi 2 pi / 2^31 in [-pi/4, pi/4] -- so no precision is lost before the polynomials (the float u
@@ -33,4 +37,37 @@ DRT_SC_HD void sincos_2pi_u31(uint32_t r, float* s, float* c)
     // quadrant 0: (s, c); 1: (c, -s); 2: (-s, -c); 3: (-c, s); 4 = 0
     *s = drt_bits_to_float(drt_float_to_bits(ss) ^ ((q & 2u) << 30));
     *c = drt_bits_to_float(drt_float_to_bits(cc) ^ (((q + 1u) & 2u) << 30));
+}
+
+// (2) The specular lobe's theta (bxdf.hpp:106-113): cos^2 = u^(2/(e+2)) = exp(x), sin^2 = 1 - exp(x), x = log(u) 2/(e+2).
+// log(u) for u = r / RAND_MAX: near u = 1 it is formed from the EXACT integer w = (RAND_MAX - r) / RAND_MAX as the
+// series of log1p(-w) (six terms, relative error < 3e-9 for w < 1/16) -- the float u would have lost w's low bits --
+// elsewhere as ln2 * v_log_f32(u).  1 - exp(x) likewise: the series of -expm1(x) for |x| < 1/16, 1 - exp2 elsewhere.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DRT_HW_LOG2(x) __builtin_amdgcn_logf(x)
+#define DRT_HW_EXP2(x) __builtin_amdgcn_exp2f(x)
+#else
+#include <math.h>
+#define DRT_HW_LOG2(x) log2f(x)
+#define DRT_HW_EXP2(x) exp2f(x)
+#endif
+
+DRT_SC_HD float drt_log_u31(uint32_t r)              // log(r / RAND_MAX), 1 <= r <= RAND_MAX - 1
+{
+    const float w = (float)(2147483647u - r) * 4.656612875245797e-10f;
+    if (w < 0.0625f)
+        return -w * (1.f + w * (0.5f + w * (0.33333334f + w * (0.25f + w * (0.2f + w * 0.16666667f)))));
+    return 0.6931471805599453f * DRT_HW_LOG2((float)r * 4.656612875245797e-10f);
+}
+
+DRT_SC_HD float drt_exp_nonpos(float x)              // exp(x), x <= 0
+{
+    return DRT_HW_EXP2(x * 1.4426950408889634f);
+}
+
+DRT_SC_HD float drt_one_minus_exp(float x)           // 1 - exp(x), x <= 0, to full relative accuracy
+{
+    if (x > -0.0625f)
+        return -x * (1.f + x * (0.5f + x * (0.16666667f + x * (0.041666668f + x * 0.008333334f))));
+    return 1.f - DRT_HW_EXP2(x * 1.4426950408889634f);
 }

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <initializer_list>
 
 int main()
 {
@@ -21,7 +22,21 @@ int main()
     const bool ends = s == 0.f && c == 1.f;
     sincos_2pi_u31(1073741824u, &s, &c);                 // half a turn: (0, -1)
     const bool half = std::fabs(s) < 1e-7f && c == -1.f;
-    std::printf("max abs error %.3e at r = %u\n", worst, at);
-    if (worst < 2e-7 && ends && half) { std::printf("ok\n"); return 0; }
+    std::printf("sin/cos: max abs error %.3e at r = %u\n", worst, at);
+    // the specular lobe's helpers: log(u), exp(x), 1 - exp(x) against libm in double (relative errors)
+    double e_log = 0, e_exp = 0, e_ome = 0;
+    for (uint64_t r = 1; r < 2147483647ull; r += (r < 200000 || r > 2147283647ull) ? 1 : 4099) {
+        const double lu = std::log((double)r / 2147483647.0);
+        e_log = std::fmax(e_log, std::fabs(drt_log_u31((uint32_t)r) - lu) / std::fabs(lu));
+        for (double e : {1.0, 30.0, 80.0}) {
+            const float x = (float)(lu * 2.0 / (e + 2.0));
+            e_exp = std::fmax(e_exp, std::fabs(drt_exp_nonpos(x) - std::exp((double)x)) / std::exp((double)x));
+            const double ome = -std::expm1((double)x);
+            if (ome > 0)
+                e_ome = std::fmax(e_ome, std::fabs(drt_one_minus_exp(x) - ome) / ome);
+        }
+    }
+    std::printf("log(u): max rel error %.3e; exp(x): %.3e; 1 - exp(x): %.3e\n", e_log, e_exp, e_ome);
+    if (worst < 2e-7 && ends && half && e_log < 2e-6 && e_exp < 2e-6 && e_ome < 3e-6) { std::printf("ok\n"); return 0; }
     return 1;
 }
