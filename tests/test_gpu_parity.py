@@ -511,3 +511,45 @@ def test_forward_only_image_equals_the_image_of_a_gradient_render(pkg, hip, f64)
         both, g1, st1 = hip.render(cam, rp, backward=True, f64=f64)
         assert g0 is None and st0["segments"] == st1["segments"]
         np.testing.assert_array_equal(fwd, both)
+
+
+def test_path_kernel_corner_cases(pkg, hip, oracle):
+    """k_path (the one-launch path kernel) beyond the fixtures: several batches (pixels and samples both cut) equal one
+    batch; roulette at depth 0 under a small max_depth; a forward-only render of a scene with more than 4 parameters
+    (no tangents, parameters from LDS or memory) and its run-time intersection program -- against the oracle."""
+    import dataclasses
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(100, 60)
+    rp = pkg.RenderParams(spp=12, min_bounces=5, absorb=1.0, seed=21)
+    hip.upload_scene(scene)
+    one = hip.render(cam, rp, backward=True)
+    assert one[2]["kernels"]["path"]["launches"] == 1 and one[2]["batches"] == 1
+    for batch in (100 * 60 * 5 + 7, 1234):
+        many = hip.render(cam, dataclasses.replace(rp, batch_paths=batch), backward=True)
+        assert many[2]["batches"] > 1 and many[2]["kernels"]["path"]["launches"] == many[2]["batches"]
+        assert many[2]["segments"] == one[2]["segments"]
+        np.testing.assert_allclose(many[0], one[0], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(many[1], one[1], rtol=1e-7)
+    # roulette from depth 0 on, paths cut at 4 vertices: k_path's depth-0 roulette and its capped-path count
+    rp0 = pkg.RenderParams(spp=6, min_bounces=0, absorb=0.15, seed=5, max_depth=4)
+    ref = oracle.render(scene, cam, rp0, backward=True)
+    img, grads, st = hip.render(cam, rp0, backward=True, f64=True)
+    assert st["kernels"]["path"]["launches"] == 1 and st["segments"] == ref["stats"]["segments"] and st["capped_paths"] > 0
+    assert grad_rel_err(grads, ref["grads"]) < 1e-9
+    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    img, grads, st = hip.render(cam, rp0, backward=True)
+    check_f32(img, grads, st["segments"], ref["image"], ref["grads"], ref["stats"]["segments"], n_paths=100 * 60 * 6)
+    # more than 4 parameters: forward-only goes through k_path (run-time program, no tangents), backward through the tape
+    rscene = pkg.random_scene(3, specular=False)
+    assert rscene.n_params > 4
+    rcam = pkg.Camera(64, 48).look_at((0.1, 0.0, -0.2), (0, 0.2, 1))
+    rrp = pkg.RenderParams(spp=6, min_bounces=5, absorb=1.0, seed=17)
+    rref = oracle.render(rscene, rcam, rrp, backward=True)
+    hip.upload_scene(rscene)
+    fwd, _, fst = hip.render(rcam, rrp, backward=False, f64=True)
+    assert fst["kernels"]["path"]["launches"] == 1 and fst["segments"] == rref["stats"]["segments"]
+    np.testing.assert_allclose(fwd, rref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    both, g, bst = hip.render(rcam, rrp, backward=True, f64=True)
+    assert bst["kernels"]["path"]["launches"] == 0 and grad_rel_err(g, rref["grads"]) < 1e-9
+    f32, _, fst32 = hip.render(rcam, rrp, backward=False)
+    check_f32(f32, None, fst32["segments"], rref["image"], None, rref["stats"]["segments"], heavy_tailed=True)

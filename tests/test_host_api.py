@@ -169,9 +169,9 @@ def test_app_mirror_front_sphere_on_the_device(app, tmp_path):
 
 @pytest.mark.gpu
 def test_app_multi_device_path_and_unbiased_flag(app, tmp_path):
-    """The C++ glue's multi-device split (one host thread + one context per entry of --devices),
-    exercised with two contexts on the same GPU: rows dealt to both, gradients summed on the host.
-    Also the --unbiased flag end to end."""
+    """The C++ glue's multi-device path (--devices a,b: ONE group context, drt_hip_create_group), exercised with
+    device 0 listed twice: the library deals the rows to both members and sums their gradients itself (on-device
+    add + the all-reduce of the leaders' communicator).  Also the --unbiased flag end to end."""
     one = sh([app, "-o", str(tmp_path / "a.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "3", "-p", "0.3", "--backward"])
     two = sh([app, "-o", str(tmp_path / "b.exr"), "-x", "64", "-y", "48", "-n", "8", "-b", "3", "-p", "0.3", "--backward",
               "--devices", "0,0"])
