@@ -89,11 +89,12 @@ __device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d
         const float bh = dot(oc, d);
         const float cc = dot(oc, oc) - r.w * r.w;
         const float disc = bh * bh - cc;
-        const float sq = __builtin_amdgcn_sqrtf(disc > 0.f ? disc : 0.f);
-        const float t1 = -bh - sq, t2 = sq - bh;
-        const float t = t1 > 0.f ? t1 : t2;
-        if (disc >= 0.f)
-            prog_accept(t, s, tmin, prim);
+        if (disc >= 0.f) {                   // (NaN fails, as in the reference; the branch-free form -- sqrt of a negative
+                                             // = NaN, which fails `t > 0` -- was measured 4 % slower)
+            const float sq = __builtin_amdgcn_sqrtf(disc);
+            const float t1 = -bh - sq, t2 = sq - bh;
+            prog_accept(t1 > 0.f ? t1 : t2, s, tmin, prim);
+        }
     }
 }
 
