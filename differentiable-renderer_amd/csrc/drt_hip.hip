@@ -537,7 +537,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         const size_t path_blocks = (path_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE);
         if (use_path && path_blocks > blocks)
             blocks = path_blocks;
-        if ((rc = ensure(ctx, ctx->gpart, blocks * DRT_FAST_PARAMS * 3 * sizeof(double))) != DRT_OK) return rc;
+        // rows per block: 24 for the register paths (<= 8 parameters), else one per parameter channel (LDS accumulators)
+        const size_t rows = ctx->n_params <= DRT_FAST_PARAMS ? (size_t)DRT_FAST_PARAMS * 3
+                                                             : (size_t)std::min(ctx->n_params, DRT_LDS_PARAMS) * 3;
+        if ((rc = ensure(ctx, ctx->gpart, blocks * rows * sizeof(double))) != DRT_OK) return rc;
     }
 
     BatchArgs a;
@@ -581,6 +584,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     double* grad = (double*)ctx->grad.p;
     double* gpart = (double*)ctx->gpart.p;
     const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
+    // gradient partials: gpart[block][g_stride], rows [0, g_rows) are reduced over the blocks by K7
+    const bool g_general = ctx->n_params > DRT_FAST_PARAMS;
+    const int g_rows = g_general ? std::min(ctx->n_params, DRT_LDS_PARAMS) * 3 : n_fast * 3;
+    const int g_stride = g_general ? g_rows : DRT_FAST_PARAMS * 3;
 
     // Bounces per fused launch (at most 8).  Inside a launch the lanes of ended paths idle -- cheap next
     // to the queue traffic saved, measured: even at absorb = 0.5 four bounces per launch beat one --
@@ -669,7 +676,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if (backward) {
                     if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart,
-                                       gpath, n_fast, grad);
+                                       gpath, n_fast * 3, grad, DRT_FAST_PARAMS * 3);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_GRADREDUCE]++;
                     st->units[DRT_K_GRADREDUCE] += (uint64_t)gpath;
@@ -864,16 +871,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                     if (ctx->n_params <= 4)
                         hipLaunchKernelGGL((k_adj_accumulate<R, 4>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
-                                           d_scene, d_params, tape, nv, cs, gpart, grad);
+                                           d_scene, d_params, tape, nv, cs, gpart, grad, g_rows, g_stride);
                     else if (ctx->n_params <= 8)
                         hipLaunchKernelGGL((k_adj_accumulate<R, 8>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
-                                           d_scene, d_params, tape, nv, cs, gpart, grad);
+                                           d_scene, d_params, tape, nv, cs, gpart, grad, g_rows, g_stride);
                     else
                         hipLaunchKernelGGL((k_adj_accumulate<R, 0>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
-                                           d_scene, d_params, tape, nv, cs, gpart, grad);
+                                           d_scene, d_params, tape, nv, cs, gpart, grad, g_rows, g_stride);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_BACKWARD]++;
-                    hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast, grad);
+                    hipLaunchKernelGGL(k_gradreduce, dim3(g_rows > 0 ? g_rows : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, g_rows, grad, g_stride);
                     st->launches[DRT_K_GRADREDUCE]++;
                     if (chains_done)
                         break;
@@ -882,7 +889,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
 #define DRT_LAUNCH_BWD(NP)                                                                              \
     hipLaunchKernelGGL((k_backward<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params, \
-                       tape, nv, d_adjoint, gpart, grad, film ? lacc : (R4*)nullptr)
+                       tape, nv, d_adjoint, gpart, grad, film ? lacc : (R4*)nullptr, g_rows, g_stride)
                 if (ctx->n_params <= 4) DRT_LAUNCH_BWD(4);
                 else if (ctx->n_params <= 8) DRT_LAUNCH_BWD(8);
                 else DRT_LAUNCH_BWD(0);
@@ -890,8 +897,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_BACKWARD]++;
                 if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_gradreduce, dim3(n_fast > 0 ? n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, n_fast,
-                                   grad);
+                hipLaunchKernelGGL(k_gradreduce, dim3(g_rows > 0 ? g_rows : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, g_rows,
+                                   grad, g_stride);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_GRADREDUCE]++;
                 st->units[DRT_K_GRADREDUCE] += (uint64_t)gp;

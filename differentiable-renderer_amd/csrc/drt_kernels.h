@@ -898,28 +898,63 @@ struct GradAccF32 {
 template <> struct GradAcc<float, 4> : GradAccF32<4> {};
 template <> struct GradAcc<float, 8> : GradAccF32<8> {};
 
+// General case (any number of parameters): ONE set of fp64 accumulators per block in LDS, row = param * 3 + channel
+// for the first DRT_LDS_PARAMS parameters, updated with LDS atomics (ds_add_f64; lanes that add to the same row
+// serialise inside the LDS, which costs ~5x the register path but involves no other CU).  The first version used
+// fp64 GLOBAL atomics on the gradient vector for ids >= 8: every thread of the chip adding to the same few
+// addresses -- 117 ms instead of 0.4 for a mesh with seven per-face albedos.  Parameters beyond DRT_LDS_PARAMS (none
+// in practice: a scene has at most 64 materials and 64 emitters) still go to the gradient vector directly.
+// The pointer travels through the accumulator interface as R (*)[DRT_BLOCK]; it points at DRT_LDS_PARAMS * 3 doubles.
 template <typename R>
 struct GradAcc<R, 0> {
     __device__ inline void init(R (*acc)[DRT_BLOCK])
     {
-#pragma unroll
-        for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r)
-            acc[r][threadIdx.x] = R(0);
+        double* blk = reinterpret_cast<double*>(acc);
+        for (int r = threadIdx.x; r < DRT_LDS_PARAMS * 3; r += DRT_BLOCK)
+            blk[r] = 0.0;                        // (visible to the block after stage_scene's barrier)
     }
     __device__ inline void add(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
     {
-        if (id < DRT_FAST_PARAMS) {
-            acc[id * 3 + 0][threadIdx.x] += v.x;
-            acc[id * 3 + 1][threadIdx.x] += v.y;
-            acc[id * 3 + 2][threadIdx.x] += v.z;
-        } else {
-            atomicAdd(&grad[id * 3 + 0], (double)v.x);
-            atomicAdd(&grad[id * 3 + 1], (double)v.y);
-            atomicAdd(&grad[id * 3 + 2], (double)v.z);
-        }
+        double* dst = id < DRT_LDS_PARAMS ? reinterpret_cast<double*>(acc) + id * 3 : grad + id * 3;
+        atomicAdd(dst + 0, (double)v.x);
+        atomicAdd(dst + 1, (double)v.y);
+        atomicAdd(dst + 2, (double)v.z);
     }
-    __device__ inline double get(R (*acc)[DRT_BLOCK], int row) const { return (double)acc[row][threadIdx.x]; }
+    __device__ inline double get(R (*)[DRT_BLOCK], int) const { return 0.0; }
 };
+
+// end of a gradient kernel: this block's sums -> gpart[block][row_stride] (fixed-order reduction over blocks: K7)
+template <typename R, int NP>
+__device__ inline void flush_grad_block(GradAcc<R, NP>& ga, R (*acc)[DRT_BLOCK], double (*red)[DRT_FAST_PARAMS * 3],
+                                        double* __restrict__ gpart, int n_rows, int row_stride)
+{
+    if (NP == 0) {
+        __syncthreads();
+        const double* blk = reinterpret_cast<const double*>(acc);
+        for (int r = threadIdx.x; r < n_rows; r += DRT_BLOCK)
+            gpart[(size_t)blockIdx.x * row_stride + r] = blk[r];
+        return;
+    }
+    // thread registers -> wave (shuffles) -> block (LDS), fp64, fixed order
+    const int lane = threadIdx.x & (DRT_WAVE - 1), wave = threadIdx.x / DRT_WAVE;
+#pragma unroll
+    for (int r = 0; r < (NP > 0 ? NP * 3 : 1); ++r) {
+        double v = ga.get(acc, r);
+#pragma unroll
+        for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
+            v += __shfl_down(v, off);
+        if (lane == 0)
+            red[wave][r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < DRT_FAST_PARAMS * 3) {
+        double v = 0;
+        if ((int)threadIdx.x < NP * 3)
+            for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
+                v += red[w][threadIdx.x];
+        gpart[(size_t)blockIdx.x * row_stride + threadIdx.x] = v;
+    }
+}
 
 // The walk of ONE path's tape (see the K6 comment above); every gradient contribution is handed
 // to acc.add(acc_lds, grad, parameter id, value).
@@ -1278,12 +1313,13 @@ __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : 1
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
            const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad,
-           typename Q4<R>::T* __restrict__ lacc)
+           typename Q4<R>::T* __restrict__ lacc, int n_rows, int row_stride)
 {
     typedef typename Q4<R>::T R4;
     constexpr bool SMALL = NP > 0;
     __shared__ SceneLds<R> lds;
-    __shared__ R acc[NP > 0 ? 1 : DRT_FAST_PARAMS * 3][DRT_BLOCK];
+    __shared__ double acc_d[NP > 0 ? 1 : DRT_LDS_PARAMS * 3];          // NP == 0: the block's accumulators (GradAcc<R, 0>)
+    R (*acc)[DRT_BLOCK] = reinterpret_cast<R(*)[DRT_BLOCK]>(acc_d);
     __shared__ double red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
     GradAcc<R, NP> ga;
     ga.init(acc);
@@ -1313,25 +1349,7 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
         }
     }
 
-    // block reduction in fp64: thread columns -> wave (shuffles) -> block (LDS), fixed order
-    const int lane = threadIdx.x & (DRT_WAVE - 1), wave = threadIdx.x / DRT_WAVE;
-#pragma unroll
-    for (int r = 0; r < (NP > 0 ? NP * 3 : DRT_FAST_PARAMS * 3); ++r) {
-        double v = ga.get(acc, r);
-#pragma unroll
-        for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
-            v += __shfl_down(v, off);
-        if (lane == 0)
-            red[wave][r] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < DRT_FAST_PARAMS * 3) {
-        double v = 0;
-        if ((int)threadIdx.x < (NP > 0 ? NP * 3 : DRT_FAST_PARAMS * 3))
-            for (int w = 0; w < DRT_BLOCK / DRT_WAVE; ++w)
-                v += red[w][threadIdx.x];
-        gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
-    }
+    flush_grad_block<R, NP>(ga, acc, red, gpart, n_rows, row_stride);
 }
 
 // Forward-only renders: the radiance of every path from its tape, deepest vertex first --
@@ -1632,12 +1650,13 @@ template <typename R, int NP>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
                  const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv, ChainState<R> cs,
-                 double* __restrict__ gpart, double* __restrict__ grad)
+                 double* __restrict__ gpart, double* __restrict__ grad, int n_rows, int row_stride)
 {
     typedef typename Q4<R>::T R4;
     constexpr bool SMALL = NP > 0;
     __shared__ SceneLds<R> lds;
-    __shared__ R acc[NP > 0 ? 1 : DRT_FAST_PARAMS * 3][DRT_BLOCK];
+    __shared__ double acc_d[NP > 0 ? 1 : DRT_LDS_PARAMS * 3];
+    R (*acc)[DRT_BLOCK] = reinterpret_cast<R(*)[DRT_BLOCK]>(acc_d);
     __shared__ double red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
     GradAcc<R, NP> ga;
     ga.init(acc);
@@ -1686,38 +1705,21 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
         }
     }
 
-    const int lane = threadIdx.x & (DRT_WAVE - 1), wave = threadIdx.x / DRT_WAVE;
-#pragma unroll
-    for (int q = 0; q < (NP > 0 ? NP * 3 : DRT_FAST_PARAMS * 3); ++q) {
-        double v = ga.get(acc, q);
-#pragma unroll
-        for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
-            v += __shfl_down(v, off);
-        if (lane == 0)
-            red[wave][q] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < DRT_FAST_PARAMS * 3) {
-        double v = 0;
-        if ((int)threadIdx.x < (NP > 0 ? NP * 3 : DRT_FAST_PARAMS * 3))
-            for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
-                v += red[ww][threadIdx.x];
-        gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
-    }
+    flush_grad_block<R, NP>(ga, acc, red, gpart, n_rows, row_stride);
 }
 
 // ---- K7 ---------------------------------------------------------------------------------------
 // grad[p] += sum over blocks of gpart[block][p] in a fixed order (deterministic); one block per row p
 __global__ void __launch_bounds__(DRT_BLOCK)
-k_gradreduce(const double* __restrict__ gpart, int n_blocks, int n_fast, double* __restrict__ grad)
+k_gradreduce(const double* __restrict__ gpart, int n_blocks, int n_rows, double* __restrict__ grad, int row_stride)
 {
     __shared__ double red[DRT_BLOCK];
     const int p = blockIdx.x;
-    if (p >= n_fast * 3)
+    if (p >= n_rows)
         return;
     double v = 0;
     for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
-        v += gpart[(size_t)b * (DRT_FAST_PARAMS * 3) + p];
+        v += gpart[(size_t)b * row_stride + p];
     red[threadIdx.x] = v;
     __syncthreads();
     for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
