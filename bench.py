@@ -79,10 +79,10 @@ def load_distributed():
 def _oracle_shard(args):
     """Worker of the all-cores CPU figure: one row-band shard of the sample, in its own process."""
     import __graft_entry__ as entry
-    scene_name, w, h, spp, depth, backward, shard, n_shards = args
+    scene_name, w, h, spp, min_b, absorb, backward, shard, n_shards = args
     pkg = entry.load_package()
     oracle = entry.load_oracle()
-    rp = pkg.RenderParams(spp=spp, min_bounces=depth, absorb=1.0, seed=1, shard=shard, n_shards=n_shards, band_rows=4)
+    rp = pkg.RenderParams(spp=spp, min_bounces=min_b, absorb=absorb, seed=1, shard=shard, n_shards=n_shards, band_rows=4)
     r = oracle.render(pkg.scene_by_name(scene_name), pkg.cornell_camera(w, h), rp, backward=backward)
     return r["stats"]["segments"]
 
@@ -98,6 +98,10 @@ def parse_args(argv):
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel PER GPU")
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--scene", default="", help="cornell | cornell_specular | mesh<lat>x<lon>[f<n>] | random<seed>")
+    ap.add_argument("--absorb", type=float, default=1.0,
+                    help="roulette absorption probability (the reference's -p; 1 = every path ends at --depth, the configs' setting)")
+    ap.add_argument("--min-bounces", type=int, default=0,
+                    help="the reference's -b; default = --depth.  '--absorb 0.5 --min-bounces 1' = the reference's own defaults")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--unbiased", action="store_true", help="backward with the unbiased integration operator")
     ap.add_argument("--batch-paths", type=int, default=0)
@@ -123,7 +127,9 @@ def parse_args(argv):
     a.depth = a.depth or cfg["depth"]
     a.scene = a.scene or cfg["scene"]
     a.forward_only = a.forward_only or cfg["forward_only"]
-    a.is_config = all(getattr(a, k) == v for k, v in cfg.items() if k != "name")
+    a.min_bounces = a.min_bounces or a.depth
+    a.roulette = a.absorb < 1.0
+    a.is_config = all(getattr(a, k) == v for k, v in cfg.items() if k != "name") and not a.roulette and a.min_bounces == a.depth
     a.config_name = cfg["name"] if a.is_config else "custom"
     return a
 
@@ -175,7 +181,7 @@ def main():
                 print("bench.py: in-library communicator unavailable; reducing with torch.distributed", file=sys.stderr)
             reduce_mode = "torch"
     flags = (pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0) | (pkg.RENDER_ALLREDUCE if reduce_mode == "library" else 0)
-    rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.depth, absorb=1.0, seed=1,
+    rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.min_bounces, absorb=a.absorb, seed=1,
                           shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
                           flags=flags, bounces_per_launch=a.bounces_per_launch)
 
@@ -286,7 +292,9 @@ def main():
     # workload named in it): quoted only for that very workload
     pmc = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    workload_key = f"{a.scene}:{a.width}x{a.height}x{a.spp}:d{a.depth}:{'fwd' if a.forward_only else 'fwdbwd'}"
+    depth_text = f"roulette from bounce {a.min_bounces} with absorption {a.absorb:g}" if a.roulette else f"depth {a.depth}"
+    depth_key = f"rr{a.absorb:g}b{a.min_bounces}" if a.roulette else f"d{a.depth}"
+    workload_key = f"{a.scene}:{a.width}x{a.height}x{a.spp}:{depth_key}:{'fwd' if a.forward_only else 'fwdbwd'}"
     if os.path.exists(tpath) and not a.unbiased and a.bounces_per_launch == 0:
         try:
             tj = json.load(open(tpath))
@@ -382,7 +390,7 @@ def main():
         # their sample is a handful of pixels)
         pw, ph, ps = 32, 32, 1
         t1 = time.perf_counter()
-        pilot = oracle.render(scene, pkg.cornell_camera(pw, ph), pkg.RenderParams(spp=ps, min_bounces=a.depth, absorb=1.0, seed=1),
+        pilot = oracle.render(scene, pkg.cornell_camera(pw, ph), pkg.RenderParams(spp=ps, min_bounces=a.min_bounces, absorb=a.absorb, seed=1),
                               backward=backward)
         rate = pilot["stats"]["segments"] / max(1e-6, time.perf_counter() - t1)      # rays / s
         per_path = pilot["stats"]["segments"] / (pw * ph * ps)
@@ -394,14 +402,14 @@ def main():
             f = (budget_paths / (cw * ch)) ** 0.5
             cw, ch, cs = max(8, int(cw * f)), max(8, int(ch * f)), 1
         ccam = pkg.cornell_camera(cw, ch)
-        crp = pkg.RenderParams(spp=cs, min_bounces=a.depth, absorb=1.0, seed=1)
+        crp = pkg.RenderParams(spp=cs, min_bounces=a.min_bounces, absorb=a.absorb, seed=1)
         t1 = time.perf_counter()
         ref = oracle.render(scene, ccam, crp, backward=backward)
         dt = time.perf_counter() - t1
         cpu_baseline = {"value": round(ref["stats"]["segments"] / dt * 1e-6, 3), "unit": "Mray/s",
                         "cores": 1, "kind": "port",
                         "sample": f"same scene, frame {cw}x{ch} of {a.width}x{a.height}, {cs} of the {a.spp} spp, "
-                                  f"depth {a.depth}, {'fwd+bwd' if backward else 'fwd'}: "
+                                  f"{depth_text}, {'fwd+bwd' if backward else 'fwd'}: "
                                   f"{ref['stats']['segments']} rays in {dt:.1f} s (fp64 C restatement, 1 thread)"}
         # parity of this very workload's gradients against the CPU restatement (same RNG keys): run the
         # device once more on the sample's frame and spp
@@ -414,7 +422,7 @@ def main():
             # processes, each rendering its interleaved row bands of the same sample
             import multiprocessing as mp
             n = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
-            jobs = [(a.scene, cw, ch, cs, a.depth, backward, i, n) for i in range(n)]
+            jobs = [(a.scene, cw, ch, cs, a.min_bounces, a.absorb, backward, i, n) for i in range(n)]
             with mp.get_context("spawn").Pool(n) as pool:
                 # start the workers and load the checker in each of them before the clock starts
                 pool.map(_oracle_shard, [(a.scene, 16, 16, 1, 1, False, 0, 1)] * n, chunksize=1)
@@ -428,7 +436,7 @@ def main():
     # pageable host memory over PCIe): reported beside `value`, never as `value`
     host_buffers = None
     if extra:
-        hrp = pkg.RenderParams(spp=a.spp, min_bounces=a.depth, absorb=1.0, seed=1, batch_paths=a.batch_paths)
+        hrp = pkg.RenderParams(spp=a.spp, min_bounces=a.min_bounces, absorb=a.absorb, seed=1, batch_paths=a.batch_paths)
         n_host = max(1, min(a.steps, 5))
         r.render(cam, hrp, backward=backward, unbiased=a.unbiased and backward)
         t3 = time.perf_counter()
@@ -450,13 +458,13 @@ def main():
         else:
             par = "1 GPU"
         line = {
-            "metric": f"Mray/s ({what}), {'Cornell' if a.scene.startswith('cornell') else a.scene} {a.width}x{a.height} @{a.spp}spp depth {a.depth}",
+            "metric": f"Mray/s ({what}), {'Cornell' if a.scene.startswith('cornell') else a.scene} {a.width}x{a.height} @{a.spp}spp {depth_text}",
             "value": round(value, 2), "unit": "Mray/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.config_name}; scene '{a.scene}' (cornell box of render.cpp:26-59"
                                    f"{' + procedural mesh' if a.scene.startswith('mesh') else ''}) {a.width}x{a.height}, "
-                                   f"{a.spp} spp per GPU, depth {a.depth} (-b {a.depth} -p 1), "
+                                   f"{a.spp} spp per GPU, {depth_text} (-b {a.min_bounces} -p {a.absorb:g}), "
                                    f"{'fwd + radiative-backprop gradients of ' + str(scene.n_params) + ' parameters' if backward else 'fwd only'}",
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
                        "parallelism": par, "batches_per_step": stats["batches"],

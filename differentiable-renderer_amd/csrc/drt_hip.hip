@@ -418,21 +418,30 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const bool can_fuse = fuse_env && !ctx->has_mesh;
     static const int shade_nb_env = getenv("DRT_HIP_SHADE_BOUNCES") ? atoi(getenv("DRT_HIP_SHADE_BOUNCES")) : 0;
     // ---- k_path (drt_path.h): the whole path in one launch, in registers.  Taken when the scene is analytic,
-    // the estimator the biased one, at most 4 parameters want gradients, and enough lanes stay busy to the end:
+    // the estimator the biased one and at most 4 parameters want gradients.  Two forms: lanes in lockstep (all at
+    // the same depth; a lane whose path ended idles to the end of the sample) when most lanes stay busy to the end --
     // ~7 % of the paths end per bounce on a miss or a light, the roulette removes `absorb` of the rest from
-    // min_bounces on; a launch whose lanes would idle more than 60 % of the time (roulette-terminated paths under
-    // the default cap of 64) goes through the queues instead, where survivors are compacted between launches.
+    // min_bounces on -- and the regenerating form (a lane whose path ended starts its next sample at once) otherwise:
+    // roulette-terminated paths under the default cap of 64, the reference's own defaults (-b 1 -p 0.5).
     static const int path_env = getenv("DRT_HIP_PATH") ? atoi(getenv("DRT_HIP_PATH")) : 1;
     bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && !unbiased && gimg_param < 0 && D > 0 &&
                     (!backward || ctx->n_params <= 4) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
                     !getenv("DRT_HIP_DUMP_PATH");
-    if (use_path && path_env < 2) {
-        double alive = 1.0, busy = 0.0;
+    static const int regen_env = getenv("DRT_HIP_PATH_REGEN") ? atoi(getenv("DRT_HIP_PATH_REGEN")) : -1;
+    bool path_regen = regen_env > 0;
+    if (use_path && regen_env < 0) {
+        // lockstep: a wave runs until the longest of its 64 paths ends (~ the depth where 1 path in 64 is left);
+        // regenerating: every lane runs the mean path length, at ~1.4 x the instructions per bounce (measured on
+        // config 3, where both apply: 1.20 against 0.88 ms)
+        double alive = 1.0, mean_len = 0.0;
+        int longest = D;
         for (int k = 0; k < D; ++k) {
-            busy += alive;
+            mean_len += alive;
             alive *= 0.93 * ((k + 1) >= rp->min_bounces ? 1.0 - rp->absorb : 1.0);
+            if (alive < 1.0 / 64 && longest == D)
+                longest = k + 1;
         }
-        use_path = busy / D >= 0.4;
+        path_regen = 1.4 * mean_len < (double)longest;
     }
     uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
     if (use_path && rp->batch_paths <= 0)
@@ -469,7 +478,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const uint32_t path_groups = (Pb + DRT_WAVE - 1) / DRT_WAVE;
     uint32_t path_spr = 1;
     {
-        const uint64_t target = (uint64_t)ctx->n_cu * 64;
+        // (regenerating lanes balance themselves over their sample range: longer ranges, fewer waves)
+        const uint64_t target = (uint64_t)ctx->n_cu * (path_regen ? 32 : 64);
         const uint64_t want = (target + path_groups - 1) / path_groups;
         path_spr = (uint32_t)(Sb / (want ? want : 1));
         if (const char* e = getenv("DRT_HIP_PATH_SPR"))
@@ -633,6 +643,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 pa.n_groups = (a.Pb + DRT_WAVE - 1) / DRT_WAVE;
                 pa.min_bounces = a.min_bounces; pa.depth_cap = a.depth_cap; pa.cap_is_roulette = a.cap_is_roulette;
                 pa.rr_threshold = a.rr_threshold; pa.seed = a.seed;
+                static const int regen_min_env = getenv("DRT_HIP_PATH_REGEN_MIN") ? atoi(getenv("DRT_HIP_PATH_REGEN_MIN")) : 8;
+                pa.regen_min = (uint32_t)(regen_min_env < 1 ? 1 : regen_min_env);
                 pa.p_rr = 1.0 - rp->absorb;
                 pa.inv_p_rr = rp->absorb < 1.0 ? 1.0 / (1.0 - rp->absorb) : 0.0;   // (never used when every path ends at min_bounces)
                 for (int i = 0; i < 3; ++i) {
@@ -649,8 +661,14 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 const bool cornell_sig = sig_env && sizeof(R) == 4 && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
-    hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, pa, d_scene, \
-                       d_params, d_adjoint, gpart, fpart, counts)
+    do {                                                                                                                 \
+        if (path_regen)                                                                                                  \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts);                                 \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts);                                 \
+    } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
     do {                                                                                   \
         if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, NC, DRT_SIG_CORNELL, DRT_NSIG_CORNELL); \

@@ -45,6 +45,7 @@ struct PathArgs {
     // integrator
     int32_t min_bounces, depth_cap, cap_is_roulette;
     uint32_t rr_threshold, seed;
+    uint32_t regen_min;             // regenerating form: idle lanes it takes to run the camera code (see k_path)
     double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
     // camera
     double eye[3], fwd[3], right[3], up[3];
@@ -219,17 +220,121 @@ __device__ inline void add_emission(const SceneLds<R>& lds, const R* __restrict_
     }
 }
 
-// ---- the kernel -----------------------------------------------------------------------------------
-// The bounce loop is written WITHOUT per-lane branches: every lane of the wave executes every bounce of the sample --
-// a lane whose path has ended keeps tracing a stale ray whose results are never used (`live` guards every
-// accumulation, its T and dT are frozen by selects) -- because that is what the SIMD does anyway, and straight-line
-// code spares the exec-mask bookkeeping, the register copies at the joins and the waits in front of them.
 template <typename R>
 struct CameraLane {            // per-lane camera constants (the lane's pixel does not change over its samples)
     R cs0, ct0;                // (2 x / W - 1) aspect tan(vfov / 2) and (2 y / H - 1) tan(vfov / 2) at the pixel's corner
 };
 
+// ---- one bounce of one path (every lane executes it; `live` says whether the lane's path is still going) -----------
+// pk, inv_pk, n_theta, next_rr, next_cap describe the depth of the vertex: wave-uniform scalars in the fixed-depth
+// kernel (all lanes at the same depth), per-lane values in the regenerating one.  On return: ra/rb = the next ray,
+// T/dT moved on iff `alive`; `on_light` = the path ended on a light without BxDF (pathtracer.hpp:38-39: f = 0) whose
+// emission parameter is `light` -- the caller adds that emission (the fixed-depth kernel once per sample, after its
+// bounce loop, for all lanes together; the regenerating kernel when the lane's path ends).
 template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG>
+__device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
+                                   const R* __restrict__ params, const ProgRecs<(sizeof(R) == 4 ? NSIG : 0)>& recs, uint32_t key,
+                                   R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
+                                   typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
+                                   bool& alive, bool& capped, bool& on_light, uint32_t& light)
+{
+    const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
+    const bool hit = live && h.prim >= 0;
+    const int prim = h.prim >= 0 ? h.prim : 0;                        // (a miss reads record 0, uses nothing of it)
+    const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
+    const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
+    const V3<R> P = o + d * h.t;                                      // pathtracer.hpp:83
+    const DevShape<R>& sh = lds.sc.shapes[prim];
+    const V3<R> ctr = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
+    const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
+    const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
+    const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
+    const uint32_t ids = (uint32_t)sh.pad;                            // colour | emission << 16 parameter ids
+    const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
+    const bool has_bxdf = cid != DRT_ID_NONE, emits = hit && eid != DRT_ID_NONE;
+    // emission, pathtracer.hpp:113-114: a shape with BxDF AND emitter (rare) adds it here, a pure light is the caller's
+    on_light = emits && !has_bxdf;
+    light = eid;
+    if (__any(emits && has_bxdf)) {
+        if (emits && has_bxdf)
+            add_emission<R, NP, NC>(lds, params, eid, inv_pk, T, g, L, tg);
+    }
+    // the BxDF: sample, evaluate (pathtracer.hpp:91-111)
+    const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
+    V3<R> wo;
+    R q, bs;
+    sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+    const R c = dot(nrm, wo);                                         // pathtracer.hpp:103
+    const R mk_ = div_r(bs * c, q * pk);                              // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
+    // roulette / cap of the next depth (pathtracer.hpp:128)
+    const bool rr_kills = next_rr && drt_rng_draw(key, n_theta + 2) < a.rr_threshold;
+    alive = hit && has_bxdf && !next_cap && !rr_kills;
+    capped = hit && has_bxdf && next_cap && !a.cap_is_roulette && !rr_kills;
+    // throughput and tangents move on only in lanes whose path goes on (the others stay frozen for the light's turn)
+    const V3<R> col = load_param<R, (NP > 0)>(lds, params, has_bxdf ? (int)cid : 0);
+    const V3<R> cmv = col * mk_;
+    const V3<R> cm = mk<R>(alive ? cmv.x : R(1), alive ? cmv.y : R(1), alive ? cmv.z : R(1));
+    if (NC > 0) {
+        const V3<R> Tm = T * mk_;
+#pragma unroll
+        for (int p = 0; p < NC; ++p) {
+            const bool mine = alive && cid == (uint32_t)p;
+            tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
+                             fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
+        }
+    }
+    T = T * cm;
+    const V3<R> no = P + wo * R(1e-3);                                // pathtracer.hpp:99
+    ra.x = no.x; ra.y = no.y; ra.z = no.z; ra.w = wo.x;
+    rb.x = wo.y; rb.y = wo.z;
+}
+
+// Camera::sample (camera.hpp:51-60) of sample `sl` of the lane's pixel
+template <typename R>
+__device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& cl, uint32_t gpix, uint32_t px, uint32_t py, uint32_t sl,
+                                       typename Q4<R>::T& ra, typename Q2<R>::T& rb)
+{
+    const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
+    const uint32_t key = drt_rng_path_key(a.seed, path);
+    if (sizeof(R) == 4) {
+        const float cs = fmaf(u01(0.f, drt_rng_draw(key, 0)), (float)(2. * a.aspect * a.tan_half * a.inv_W), (float)cl.cs0);
+        const float ct = fmaf(u01(0.f, drt_rng_draw(key, 1)), (float)(2. * a.tan_half * a.inv_H), (float)cl.ct0);
+        const V3<float> dir = mk<float>((float)a.fwd[0] + cs * (float)a.right[0] - ct * (float)a.up[0],
+                                        (float)a.fwd[1] + cs * (float)a.right[1] - ct * (float)a.up[1],
+                                        (float)a.fwd[2] + cs * (float)a.right[2] - ct * (float)a.up[2]);
+        const V3<float> dn = normalize(dir);
+        ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dn.x;
+        rb.x = (R)dn.y; rb.y = (R)dn.z;
+    } else {                                          // f64 verification mode: the reference's own sequence, in double
+        const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
+        const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
+        const double s = ((double)px + u1) / (double)a.W;
+        const double t = ((double)py + u2) / (double)a.H;
+        const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
+        const double ct = (2. * t - 1.) * a.tan_half;
+        double dx = a.fwd[0] + cs * a.right[0] - ct * a.up[0];
+        double dy = a.fwd[1] + cs * a.right[1] - ct * a.up[1];
+        double dz = a.fwd[2] + cs * a.right[2] - ct * a.up[2];
+        const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)(dx * inv);
+        rb.x = (R)(dy * inv); rb.y = (R)(dz * inv);
+    }
+    return key;
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+// The bounce loop is written WITHOUT per-lane branches: every lane of the wave executes every bounce of the sample --
+// a lane whose path has ended keeps tracing a stale ray whose results are never used (`live` guards every
+// accumulation, its T and dT are frozen by selects) -- because that is what the SIMD does anyway, and straight-line
+// code spares the exec-mask bookkeeping, the register copies at the joins and the waits in front of them.
+// REGEN = false: all lanes of a wave trace their pixel's sample s at the same time and stand at the same depth (scalar
+// depth bookkeeping; lanes whose path ended idle to the end of the sample: fine when paths end at a fixed depth).
+// REGEN = true: every lane is on its own -- when its path ends (the roulette of pathtracer.hpp:128 ends paths at any
+// depth) it starts its next sample at once, so no lane waits for the longest path of the wave: per-lane depth
+// bookkeeping, the camera code runs whenever some lane starts over, the light's emission is added when the lane's
+// path ends.  ~35 % more instructions per bounce, but roulette-terminated renders (the reference's defaults, -b 1
+// -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
+template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG, bool REGEN = false>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts)
@@ -287,36 +392,11 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         __syncthreads();
     }
 
-    if (range < a.n_ranges) {
+    if (range < a.n_ranges && !REGEN) {
     for (uint32_t sl = s_begin; sl < s_end; ++sl) {
-        // ---- Camera::sample (camera.hpp:51-60)
         R4 ra;
         R2 rb;
-        const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
-        const uint32_t key = drt_rng_path_key(a.seed, path);
-        if (sizeof(R) == 4) {
-            const float cs = fmaf(u01(0.f, drt_rng_draw(key, 0)), (float)(2. * a.aspect * a.tan_half * a.inv_W), (float)cl.cs0);
-            const float ct = fmaf(u01(0.f, drt_rng_draw(key, 1)), (float)(2. * a.tan_half * a.inv_H), (float)cl.ct0);
-            const V3<float> dir = mk<float>((float)a.fwd[0] + cs * (float)a.right[0] - ct * (float)a.up[0],
-                                            (float)a.fwd[1] + cs * (float)a.right[1] - ct * (float)a.up[1],
-                                            (float)a.fwd[2] + cs * (float)a.right[2] - ct * (float)a.up[2]);
-            const V3<float> dn = normalize(dir);
-            ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dn.x;
-            rb.x = (R)dn.y; rb.y = (R)dn.z;
-        } else {                                          // f64 verification mode: the reference's own sequence, in double
-            const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
-            const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
-            const double s = ((double)px + u1) / (double)a.W;
-            const double t = ((double)py + u2) / (double)a.H;
-            const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
-            const double ct = (2. * t - 1.) * a.tan_half;
-            double dx = a.fwd[0] + cs * a.right[0] - ct * a.up[0];
-            double dy = a.fwd[1] + cs * a.right[1] - ct * a.up[1];
-            double dz = a.fwd[2] + cs * a.right[2] - ct * a.up[2];
-            const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
-            ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)(dx * inv);
-            rb.x = (R)(dy * inv); rb.y = (R)(dz * inv);
-        }
+        const uint32_t key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
         // pathtracer.hpp:128 at depth 0
         bool live = have && a.depth_cap > 0 && !(a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold);
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
@@ -337,60 +417,17 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const uint32_t n_theta = draw_offset(kk, 0, a.min_bounces) + camera_draw_base(a.min_bounces);
             const bool next_rr = (kk + 1) >= a.min_bounces;
             const bool next_cap = (kk + 1) >= a.depth_cap;
-
-            const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
-            const bool hit = live && h.prim >= 0;
-            const int prim = h.prim >= 0 ? h.prim : 0;                        // (a miss reads record 0, uses nothing of it)
-            const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
-            const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
-            const V3<R> P = o + d * h.t;                                      // pathtracer.hpp:83
-            const DevShape<R>& sh = lds.sc.shapes[prim];
-            const V3<R> ctr = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
-            const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
-            const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
-            const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
-            const uint32_t ids = (uint32_t)sh.pad;                            // colour | emission << 16 parameter ids
-            const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
-            const bool has_bxdf = cid != DRT_ID_NONE, emits = hit && eid != DRT_ID_NONE;
-            // emission, pathtracer.hpp:113-114.  A light without a BxDF ends the path (pathtracer.hpp:38-39: f = 0): T and
-            // dT stay as they are in this lane, so its emission is added ONCE PER SAMPLE, after the bounce loop, for all
-            // lanes together.  A shape with both (rare) adds it here.
-            end_ids = emits && !has_bxdf ? eid : end_ids;
-            end_inv_pk = emits && !has_bxdf ? inv_pk : end_inv_pk;
-            if (__any(emits && has_bxdf)) {
-                if (emits && has_bxdf)
-                    add_emission<R, NP, NC>(lds, params, eid, inv_pk, T, g, L, tg);
-            }
-            // the BxDF: sample, evaluate (pathtracer.hpp:91-111)
-            const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
-            V3<R> wo;
-            R q, bs;
-            sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
-            const R c = dot(nrm, wo);                                         // pathtracer.hpp:103
-            const R mk_ = div_r(bs * c, q * pk);                              // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
-            // roulette / cap of depth kk+1 (pathtracer.hpp:128)
-            const bool rr_kills = next_rr && drt_rng_draw(key, n_theta + 2) < a.rr_threshold;
-            const bool alive = hit && has_bxdf && !next_cap && !rr_kills;
-            const bool capped = hit && has_bxdf && next_cap && !a.cap_is_roulette && !rr_kills;
-            // throughput and tangents move on only in lanes whose path goes on (the others stay frozen for the light's turn)
-            const V3<R> col = load_param<R, (NP > 0)>(lds, params, has_bxdf ? (int)cid : 0);
-            const V3<R> cmv = col * mk_;
-            const V3<R> cm = mk<R>(alive ? cmv.x : R(1), alive ? cmv.y : R(1), alive ? cmv.z : R(1));
-            if (NC > 0) {
-                const V3<R> Tm = T * mk_;
-#pragma unroll
-                for (int p = 0; p < NC; ++p) {
-                    const bool mine = alive && cid == (uint32_t)p;
-                    tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
-                                     fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
-                }
-            }
-            T = T * cm;
+            bool alive, capped, on_light;
+            uint32_t light;
+            path_bounce<R, SPEC, NP, NC, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
+                                                    ra, rb, T, L, tg, alive, capped, on_light, light);
+            // A light without a BxDF ends the path: T and dT stay as they are in this lane, so its emission is added
+            // ONCE PER SAMPLE, after the bounce loop, for all lanes together -- not here, where every bounce a few lanes
+            // of the wave would drag the other sixty through it.
+            end_ids = on_light ? light : end_ids;
+            end_inv_pk = on_light ? inv_pk : end_inv_pk;
             if (next_cap && !a.cap_is_roulette)
                 n_capped += (uint32_t)__popcll(__ballot(capped));
-            const V3<R> no = P + wo * R(1e-3);                                // pathtracer.hpp:99
-            ra.x = no.x; ra.y = no.y; ra.z = no.z; ra.w = wo.x;
-            rb.x = wo.y; rb.y = wo.z;
             live = alive;
         }
         if (__any(end_ids != DRT_ID_NONE)) {
@@ -399,6 +436,75 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         }
         fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
     }
+    }
+    if (range < a.n_ranges && REGEN) {
+        uint32_t sl = s_begin, key = 0;                   // the lane's next sample; RNG key of its current path
+        int kk = 0;                                       // depth of the lane's current path
+        bool live = false;
+        R4 ra;
+        R2 rb;
+        ra.x = ra.y = ra.z = ra.w = R(0);
+        rb.x = rb.y = R(0);
+        V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
+        if (NC > 0) {
+#pragma unroll
+            for (int p = 0; p < NC; ++p)
+                tg.dT[p] = mk<R>(R(0), R(0), R(0));
+        }
+        const int first_rr = a.min_bounces > 1 ? a.min_bounces : 1;
+        for (;;) {
+            // ---- lanes without a path start their next sample -- once enough of them wait (the whole wave walks
+            // through the camera code), or as many as still run
+            const bool start = have && !live && sl < s_end;
+            const uint32_t n_idle = (uint32_t)__popcll(__ballot(start)), n_run = (uint32_t)__popcll(__ballot(live));
+            if (n_idle >= a.regen_min || (n_idle > 0 && n_idle >= n_run)) {
+                if (start) {
+                    key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+                    ++sl;
+                    kk = 0;
+                    live = a.depth_cap > 0 && !(a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold);
+                    T = mk<R>(R(1), R(1), R(1));
+                    L = mk<R>(R(0), R(0), R(0));
+                    if (NC > 0) {
+#pragma unroll
+                        for (int p = 0; p < NC; ++p)
+                            tg.dT[p] = mk<R>(R(0), R(0), R(0));
+                    }
+                }
+            }
+            const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+            if (n_live == 0) {
+                if (!__any(have && sl < s_end))
+                    break;                                // every lane is through its samples
+                continue;                                 // (all fresh paths were absorbed at depth 0)
+            }
+            n_seg += n_live;
+            // ---- one bounce, every lane at its own depth
+            const bool rr_here = kk >= a.min_bounces;
+            const R pk = rr_here ? pk_rr : R(1);                              // pathtracer.hpp:130
+            const R inv_pk = rr_here ? inv_p_rr : R(1);
+            const int rr_draws = kk - first_rr + 1;                           // roulette draws at depths 1 .. kk (draw_offset)
+            const uint32_t n_theta = 2u * (uint32_t)kk + (uint32_t)(rr_draws > 0 ? rr_draws : 0) + camera_draw_base(a.min_bounces);
+            const bool next_rr = (kk + 1) >= a.min_bounces;
+            const bool next_cap = (kk + 1) >= a.depth_cap;
+            bool alive, capped, on_light;
+            uint32_t light;
+            path_bounce<R, SPEC, NP, NC, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
+                                                    ra, rb, T, L, tg, alive, capped, on_light, light);
+            if (!a.cap_is_roulette)
+                n_capped += (uint32_t)__popcll(__ballot(capped));
+            // ---- paths that ended here hand their radiance to the pixel
+            const bool ended = live && !alive;
+            if (__any(ended)) {
+                if (ended) {
+                    if (on_light)
+                        add_emission<R, NP, NC>(lds, params, light, inv_pk, T, g, L, tg);
+                    fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
+                }
+            }
+            live = alive;
+            ++kk;
+        }
     }
 
     if (range < a.n_ranges) {

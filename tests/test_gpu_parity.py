@@ -487,7 +487,13 @@ def test_results_do_not_depend_on_bounces_per_launch(pkg, hip, scene_name, b, p,
         got = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=nb), backward=True, unbiased=unbiased)
         if nb == 0 and got[2]["kernels"]["path"]["launches"]:
             assert abs(got[2]["segments"] - ref[2]["segments"]) <= 64      # (its f32 closest-hit arithmetic is its own)
-            np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-7)
+            if "specular" in scene_name and p < 1.0:
+                # long chains of glossy bounces (depth up to 24 here) amplify the last-bit differences of the two
+                # closest-hit routines through the lobe's exponent: the stated f32 pixel bound instead of rounding
+                bad = np.abs(got[0].astype(np.float64) - ref[0]).max(-1) > PIXEL_TOL * float(np.abs(ref[0]).max())
+                assert bad.sum() <= flip_budget(160 * 96 * 6)
+            else:
+                np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-7)
             np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=1e-6 * np.abs(ref[1]).max())
             continue
         assert got[2]["segments"] == ref[2]["segments"]
@@ -511,6 +517,40 @@ def test_forward_only_image_equals_the_image_of_a_gradient_render(pkg, hip, f64)
         both, g1, st1 = hip.render(cam, rp, backward=True, f64=f64)
         assert g0 is None and st0["segments"] == st1["segments"]
         np.testing.assert_array_equal(fwd, both)
+
+
+@pytest.mark.parametrize("scene_name,b,p,max_depth,spp", [("cornell", 1, 0.5, 0, 7), ("cornell", 0, 0.3, 0, 5), ("cornell", 1, 0.5, 5, 6),
+                                                           ("cornell_specular", 3, 0.2, 0, 5), ("cornell_specular", 2, 0.35, 12, 4)])
+def test_path_kernel_regenerating_lanes(pkg, hip, oracle, scene_name, b, p, max_depth, spp):
+    """Roulette-terminated renders (the reference's defaults are -b 1 -p 0.5) take k_path's regenerating form: every
+    lane on its own depth, restarting with its next sample when its path ends.  Against the oracle: f64 mode to 1e-9
+    (same paths, same segment and capped-path counts), f32 mode within the stated bounds; frame width not a multiple
+    of the wave, sample ranges that do not divide the samples, several batches; forward-only gives the same image."""
+    import dataclasses
+    scene = pkg.scene_by_name(scene_name)
+    cam = pkg.cornell_camera(77, 45)
+    rp = pkg.RenderParams(spp=spp, min_bounces=b, absorb=p, seed=3, **({"max_depth": max_depth} if max_depth else {}))
+    ref = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True, f64=True)
+    assert st["kernels"]["path"]["launches"] == 1 and st["kernels"]["shade"]["launches"] == 0
+    assert st["segments"] == ref["stats"]["segments"]
+    assert st["capped_paths"] == ref["stats"].get("capped_paths", st["capped_paths"])
+    if max_depth in (0, 5):
+        assert (st["capped_paths"] > 0) == (max_depth == 5)
+    assert grad_rel_err(grads, ref["grads"]) < 1e-9
+    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    for batch in (77 * 45 * 2 + 5, 999):
+        many = hip.render(cam, dataclasses.replace(rp, batch_paths=batch), backward=True, f64=True)
+        assert many[2]["batches"] > 1 and many[2]["segments"] == st["segments"]
+        np.testing.assert_allclose(many[0], img, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(many[1], grads, rtol=1e-12)
+    fwd, _, fst = hip.render(cam, rp, backward=False, f64=True)
+    assert fst["segments"] == st["segments"]
+    np.testing.assert_array_equal(fwd, img)
+    img32, g32, st32 = hip.render(cam, rp, backward=True)
+    assert st32["kernels"]["path"]["launches"] == 1
+    check_f32(img32, g32, st32["segments"], ref["image"], ref["grads"], ref["stats"]["segments"], n_paths=77 * 45 * spp)
 
 
 def test_path_kernel_corner_cases(pkg, hip, oracle):
