@@ -113,6 +113,11 @@ struct DevBvh {
 #define DRT_BVH_LDS_NODES 128        // 8 KB of LDS per block: the breadth-first top of the tree
 #endif
 #define DRT_BVH_STACK 32             // per-lane traversal stack in LDS (4-wide depth <= 10, <= 3 pushes a level)
+// the walk's waves pull candidate lists from DRT_PULL_COUNTERS counters, each on a cache line of its own (one
+// address sustains only ~88 returning atomics per microsecond): counter c hands out the lists c, c + 64, c + 128, ...
+#define DRT_PULL_COUNTERS 64
+#define DRT_PULL_STRIDE 32           // words between counters (128 bytes)
+#define DRT_PULL_WORDS (DRT_PULL_STRIDE * (DRT_PULL_COUNTERS + 1))   // after the n_lists list lengths (+ alignment slack)
 #define DRT_BVH_REFILL 16            // idle lanes needed before the wave pulls new rays from its stream
 #ifndef DRT_BVH_DESCEND_MIN
 #define DRT_BVH_DESCEND_MIN 32       // the interior-node loop runs while at least this many lanes descend (sweep: 28..40 flat)

@@ -366,6 +366,21 @@ int timing_end(drt_hip_ctx* ctx, bool on)
     return DRT_OK;
 }
 
+// K2's grid in a scene with a mesh: every wave of k_intersect leaves ONE candidate list, and the BVH walk's waves pull
+// whole lists -- so the lists should be short (a wave that pulls the last list works on it alone: measured on
+// 512 x 512 x 64, 550-ray lists: 6.2 ms per step in the walk, 137-ray lists: 5.1 ms) but not nearly empty either
+// (every pull is an atomic round trip): ~8 chunks of 64 rays per wave, a quarter of them candidates.
+int k2_mesh_grid(const drt_hip_ctx* ctx, uint64_t n_paths)
+{
+    static const int per_block = getenv("DRT_HIP_K2_PATHS_PER_BLOCK") ? atoi(getenv("DRT_HIP_K2_PATHS_PER_BLOCK")) : 2048;
+    uint64_t blocks = (n_paths + (uint64_t)per_block - 1) / (uint64_t)per_block;
+    static const int max_per_cu = getenv("DRT_HIP_K2_MAX_BLOCKS_PER_CU") ? atoi(getenv("DRT_HIP_K2_MAX_BLOCKS_PER_CU")) : 32;
+    const uint64_t lo = (uint64_t)ctx->n_cu, hi = (uint64_t)ctx->n_cu * (uint64_t)max_per_cu;
+    if (blocks < lo) blocks = lo;
+    if (blocks > hi) blocks = hi;
+    return (int)blocks;
+}
+
 int grid_for(const drt_hip_ctx* ctx, uint64_t work)
 {
     uint64_t blocks = (work + DRT_BLOCK - 1) / DRT_BLOCK;
@@ -491,8 +506,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const size_t path_waves = (size_t)path_groups * path_ranges;
 
     // the rays the BVH walk has to see: one dense list per wave of k_intersect's persistent grid (+ the walk's list counter)
-    const uint32_t k2_waves = (uint32_t)grid_for(ctx, N) * (DRT_BLOCK / DRT_WAVE);
-    const uint32_t cand_cap = (uint32_t)(((((size_t)max_regions << (region_shift - 6)) + k2_waves - 1) / k2_waves) * DRT_WAVE);
+    // (list l = span [l * cand_cap, ...) of `cand`, cand_cap = the chunks one K2 wave of THIS launch sees, x 64)
+    const uint32_t k2_waves = (uint32_t)k2_mesh_grid(ctx, N) * (DRT_BLOCK / DRT_WAVE);
+    const size_t cand_words = (((size_t)max_regions << (region_shift - 6)) + k2_waves) * DRT_WAVE;
     int rc;
     ChainState<R> cs;
     memset(&cs, 0, sizeof cs);
@@ -508,8 +524,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     }
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
     if (ctx->has_mesh) {
-        if ((rc = ensure(ctx, ctx->cand, (size_t)k2_waves * cand_cap * sizeof(uint32_t))) != DRT_OK) return rc;
-        if ((rc = ensure(ctx, ctx->cand_count, ((size_t)k2_waves + 1) * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->cand, cand_words * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->cand_count, ((size_t)k2_waves + DRT_PULL_WORDS) * sizeof(uint32_t))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
     if (gimg_param >= 0)
@@ -712,6 +728,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             HIPCHK(ctx, hipMemsetAsync(counts, 0, cw * sizeof(uint32_t), ctx->stream));
             const int g = (int)((a.n_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
             const int gp = grid_for(ctx, a.n_paths);   // per-path kernels (K6): persistent grid
+            const int gk2 = ctx->has_mesh ? k2_mesh_grid(ctx, a.n_paths) : gp;   // with a mesh every K2 wave leaves one candidate list
+            const uint32_t k2w = (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE);
+            const uint32_t cand_cap = (((a.n_regions << (region_shift - 6)) + k2w - 1) / k2w) * DRT_WAVE;
 
             // K1 folded into the first shade launch when it is a fused one and every path is alive at depth 0
             static const bool cam_env = !(getenv("DRT_HIP_FUSE_CAMERA") && atoi(getenv("DRT_HIP_FUSE_CAMERA")) == 0);
@@ -749,7 +768,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 HitRec<R>* sv_hit = save_here && fused ? cs.cv_hit : (HitRec<R>*)nullptr;
                 if (!fused) {
                     if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                    hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                    hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                        ra[cur], rb[cur], hit, counts + (size_t)k * max_regions, bvh,
                                        ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (uint32_t*)ctx->cand_count.p, cand_cap);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
@@ -759,7 +778,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         const int gm = (int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu);
                         hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                            bvh, ra[cur], rb[cur], hit, (const uint32_t*)ctx->cand.p, (uint32_t*)ctx->cand_count.p, cand_cap,
-                                           (uint32_t)gp * (DRT_BLOCK / DRT_WAVE));
+                                           (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT_MESH]++;
                     }
@@ -857,13 +876,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         typename Q2<R>::T* sv_b = k == s && fused ? cs.nx_b : (typename Q2<R>::T*)nullptr;
                         HitRec<R>* sv_hit = k == s && fused ? cs.nx_hit : (HitRec<R>*)nullptr;
                         if (!fused) {
-                            hipLaunchKernelGGL(k_intersect<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                            hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                                ra[cur], rb[cur], hit, ck, bvh,
                                                ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (uint32_t*)ctx->cand_count.p, cand_cap);
                             if (ctx->has_mesh)
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
                                                    ctx->stream, a, d_scene, bvh, ra[cur], rb[cur], hit, (const uint32_t*)ctx->cand.p,
-                                                   (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gp * (DRT_BLOCK / DRT_WAVE));
+                                                   (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
                             st->launches[DRT_K_INTERSECT]++;
                         }
                         if (k == s && !fused)

@@ -364,6 +364,12 @@ __device__ inline uint32_t chunk_slot(const BatchArgs& a, const uint32_t* __rest
 // Every wave of this kernel appends its candidates (wave ballot + prefix rank, no atomics) to ONE dense list of its
 // own -- span [list * cand_cap, ...) of `cand`, length in cand_count[list] -- and the walk's waves pull whole lists
 // from a device-wide counter: dense lanes from the first node on, and no wave is stuck with a stream of hard rays.
+// the walk's pull counters live behind the n_lists list lengths, on a 128-byte boundary
+__device__ inline uint32_t* pull_counters(uint32_t* cand_count, uint32_t n_lists)
+{
+    return cand_count + ((n_lists + DRT_PULL_STRIDE - 1) / DRT_PULL_STRIDE) * DRT_PULL_STRIDE;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
@@ -380,8 +386,8 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     constexpr int NR = DRT_K2_RAYS;
     const uint32_t gw = grid_wave();
     uint32_t n_cand = 0;                                        // length of this wave's candidate list
-    if (cand && blockIdx.x == 0 && threadIdx.x == 0)
-        cand_count[n_waves] = 0;                                // the walk's list counter (it runs after this kernel)
+    if (cand && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)   // the walk's list counters (it runs after this kernel)
+        pull_counters(cand_count, n_waves)[threadIdx.x * DRT_PULL_STRIDE] = 0;
     for (uint32_t c = gw; c < n_chunks; c += NR * n_waves) {
         uint32_t slot[NR];
         R4 ra[NR];
@@ -465,11 +471,15 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     const uint32_t tid = threadIdx.x;
     const int n_shapes = sc->n_shapes;
 
-    // the wave's stream: whole candidate lists (k_intersect), pulled from the device-wide counter cand_count[n_lists]
-    // (one returning atomic per list of ~64 rays: far from the ~88 / us a single address sustains); the current
-    // list's rays are cand[cur_base + cur_off .. cur_base + cur_cnt)
+    // the wave's stream: whole candidate lists (k_intersect), pulled from DRT_PULL_COUNTERS device-wide counters (one
+    // returning atomic per list; a single address sustains only ~88 of them per microsecond, which a single counter
+    // made the floor of every launch: 0.19 ms); the current list's rays are cand[cur_base + cur_off .. cur_base + cur_cnt)
     uint32_t cur_base = 0, cur_cnt = 0, cur_off = 0;
     bool dry = false;                                           // no list left
+    bool home_dry = false;                                      // the wave's own counter has run out
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t home = (blockIdx.x * (DRT_BLOCK / DRT_WAVE) + threadIdx.x / DRT_WAVE) & (DRT_PULL_COUNTERS - 1);
+    uint32_t* const ctr = pull_counters(cand_count, n_lists);
 
     bool active = false;
     uint32_t slot = 0, cur = DRT_BVH_NONE, best_flat = 0xFFFFFFFFu;
@@ -486,11 +496,31 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 if (cur_off >= cur_cnt) {
                     if (dry)
                         break;
-                    uint32_t list = 0;
-                    if ((tid & (DRT_WAVE - 1)) == 0)
-                        list = atomicAdd(cand_count + n_lists, 1u);
-                    list = __builtin_amdgcn_readfirstlane(list);
-                    if (list >= n_lists) {
+                    // next list: from the home counter while it lasts, then from whichever counter still has lists
+                    // (every lane looks at one counter; a lost race just looks again)
+                    uint32_t list = 0xFFFFFFFFu;
+                    for (;;) {
+                        uint32_t c = home;
+                        if (home_dry) {
+                            // (a device-scope load: another XCD's L2 must not serve a stale counter -- the loop would never end)
+                            const uint32_t seen = __hip_atomic_load(ctr + lane * DRT_PULL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint64_t left = __ballot((uint64_t)seen * DRT_PULL_COUNTERS + lane < (uint64_t)n_lists);
+                            if (left == 0)
+                                break;
+                            const uint64_t rot = home ? (left >> home) | (left << (64 - home)) : left;
+                            c = (home + (uint32_t)__builtin_ctzll(rot)) & (DRT_PULL_COUNTERS - 1);
+                        }
+                        uint32_t i = 0;
+                        if (lane == 0)
+                            i = atomicAdd(ctr + c * DRT_PULL_STRIDE, 1u);
+                        i = __builtin_amdgcn_readfirstlane(i);
+                        if ((uint64_t)i * DRT_PULL_COUNTERS + c < (uint64_t)n_lists) {
+                            list = i * DRT_PULL_COUNTERS + c;
+                            break;
+                        }
+                        home_dry = true;
+                    }
+                    if (list == 0xFFFFFFFFu) {
                         dry = true;
                         break;
                     }
@@ -550,21 +580,30 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 const uint4* p = bvh.node + (size_t)cur * 4;
                 w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
             }
-            // decode the grid, then four box tests; a miss sorts to the end with t = +inf
-            const R ox = (R)__uint_as_float(w0.x), oy = (R)__uint_as_float(w0.y), oz = (R)__uint_as_float(w0.z);
-            const R sx = (R)__uint_as_float((w0.w & 0xFFu) << 23), sy = (R)__uint_as_float((w0.w & 0xFF00u) << 15),
-                    sz = (R)__uint_as_float((w0.w & 0xFF0000u) << 7);
+            // Four slab tests in the node's own grid: a bound plane at origin + q * 2^e is crossed at
+            //   t = ((origin - o) + q * 2^e) / d = A + q * B,   A = (origin - o) * inv_d,  B = 2^e * inv_d
+            // -- one conversion and one fma per plane instead of decoding the box first (fma, sub, mul) -- and the
+            // sign of d says which of a child's two planes per axis is the near one, so no min / max pairs either.
+            // Rounding moves a t by ~2^-22 (|origin - o| + q 2^e) / |d|; the boxes are padded by 1e-5 of the mesh
+            // diagonal for exactly this.  A miss sorts to the end with t = +inf.
+            const R ax = ((R)__uint_as_float(w0.x) - o.x) * inv_d.x, ay = ((R)__uint_as_float(w0.y) - o.y) * inv_d.y,
+                    az = ((R)__uint_as_float(w0.z) - o.z) * inv_d.z;
+            const R bx = (R)__uint_as_float((w0.w & 0xFFu) << 23) * inv_d.x, by = (R)__uint_as_float((w0.w & 0xFF00u) << 15) * inv_d.y,
+                    bz = (R)__uint_as_float((w0.w & 0xFF0000u) << 7) * inv_d.z;
+            const bool ngx = inv_d.x < R(0), ngy = inv_d.y < R(0), ngz = inv_d.z < R(0);
+            const uint32_t qnx = ngx ? w2.w : w2.x, qfx = ngx ? w2.x : w2.w;      // near / far plane bytes of the 4 children
+            const uint32_t qny = ngy ? w3.x : w2.y, qfy = ngy ? w2.y : w3.x;
+            const uint32_t qnz = ngz ? w3.y : w2.z, qfz = ngz ? w2.z : w3.y;
             R tc[4];
             uint32_t lc[4] = {w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const V3<R> lo = mk<R>(fma_r((R)((w2.x >> (8 * c)) & 0xFFu), sx, ox), fma_r((R)((w2.y >> (8 * c)) & 0xFFu), sy, oy),
-                                       fma_r((R)((w2.z >> (8 * c)) & 0xFFu), sz, oz));
-                const V3<R> hi = mk<R>(fma_r((R)((w2.w >> (8 * c)) & 0xFFu), sx, ox), fma_r((R)((w3.x >> (8 * c)) & 0xFFu), sy, oy),
-                                       fma_r((R)((w3.y >> (8 * c)) & 0xFFu), sz, oz));
-                R tn;
-                const bool hitc = box_hit(lo, hi, o, inv_d, tmin, tn) && lc[c] != DRT_BVH_LEAF;
-                tc[c] = hitc ? tn : (R)INFINITY;
+                const R tnx = fma_r((R)((qnx >> (8 * c)) & 0xFFu), bx, ax), tfx = fma_r((R)((qfx >> (8 * c)) & 0xFFu), bx, ax);
+                const R tny = fma_r((R)((qny >> (8 * c)) & 0xFFu), by, ay), tfy = fma_r((R)((qfy >> (8 * c)) & 0xFFu), by, ay);
+                const R tnz = fma_r((R)((qnz >> (8 * c)) & 0xFFu), bz, az), tfz = fma_r((R)((qfz >> (8 * c)) & 0xFFu), bz, az);
+                const R tn = max_r(max_r(tnx, tny), max_r(tnz, R(0)));
+                const R tf = min_r(min_r(tfx, tfy), min_r(tfz, tmin));
+                tc[c] = (tn <= tf && lc[c] != DRT_BVH_LEAF) ? tn : (R)INFINITY;
             }
             // near-to-far order: 5-comparator sorting network on (t, link)
 #define DRT_CSWAP(i, j) { const bool sw = tc[j] < tc[i]; const R tt = sw ? tc[j] : tc[i]; const R tu = sw ? tc[i] : tc[j]; \
