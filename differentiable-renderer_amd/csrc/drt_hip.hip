@@ -80,7 +80,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, cand, cand_count,
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, cand, cand_a, cand_b, cand_count,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -525,6 +525,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
     if (ctx->has_mesh) {
         if ((rc = ensure(ctx, ctx->cand, cand_words * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->cand_a, cand_words * sizeof(R4))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->cand_b, cand_words * sizeof(R4))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->cand_count, ((size_t)k2_waves + DRT_PULL_WORDS) * sizeof(uint32_t))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
@@ -770,14 +772,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                        ra[cur], rb[cur], hit, counts + (size_t)k * max_regions, bvh,
-                                       ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (uint32_t*)ctx->cand_count.p, cand_cap);
+                                       ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
+                                       (uint32_t*)ctx->cand_count.p, cand_cap);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_INTERSECT]++;
                     if (ctx->has_mesh) {   // continues from the analytic hit: (t, primitive) refined by the BVH walk
                         if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT_MESH)) != DRT_OK) return rc;
                         const int gm = (int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu);
                         hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                           bvh, ra[cur], rb[cur], hit, (const uint32_t*)ctx->cand.p, (uint32_t*)ctx->cand_count.p, cand_cap,
+                                           bvh, hit, (const uint32_t*)ctx->cand.p, (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p,
+                                           (uint32_t*)ctx->cand_count.p, cand_cap,
                                            (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT_MESH]++;
@@ -878,11 +882,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         if (!fused) {
                             hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                                ra[cur], rb[cur], hit, ck, bvh,
-                                               ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (uint32_t*)ctx->cand_count.p, cand_cap);
+                                               ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
+                                       (uint32_t*)ctx->cand_count.p, cand_cap);
                             if (ctx->has_mesh)
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
-                                                   ctx->stream, a, d_scene, bvh, ra[cur], rb[cur], hit, (const uint32_t*)ctx->cand.p,
-                                                   (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
+                                                   ctx->stream, a, d_scene, bvh, hit, (const uint32_t*)ctx->cand.p,
+                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
                             st->launches[DRT_K_INTERSECT]++;
                         }
                         if (k == s && !fused)
@@ -1056,7 +1061,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->fpart, &ctx->cand, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->fpart, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};

@@ -375,6 +375,7 @@ __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
             const typename Q2<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
             const uint32_t* __restrict__ counts_k, DevBvh<R> bvh, uint32_t* __restrict__ cand,
+            typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b,
             uint32_t* __restrict__ cand_count, uint32_t cand_cap)
 {
     typedef typename Q4<R>::T R4;
@@ -420,8 +421,18 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
                 }
                 uint32_t n_reach;
                 const uint32_t rank = wave_rank(reach, n_reach);
-                if (reach)
-                    cand[(size_t)gw * cand_cap + n_cand + rank] = slot[r];
+                if (reach) {
+                    // the candidate's record: everything the walk needs, dense and in list order -- its refill is one
+                    // coalesced round trip instead of a chain of gathers (slot -> ray, hit -> tie-break index)
+                    const size_t at = (size_t)gw * cand_cap + n_cand + rank;
+                    const uint32_t flat = h[r].prim >= 0 ? (uint32_t)sc->flat[h[r].prim] : 0xFFFFFFFFu;
+                    R4 ca, cb;
+                    ca.x = ra[r].x; ca.y = ra[r].y; ca.z = ra[r].z; ca.w = h[r].t;
+                    cb.x = ra[r].w; cb.y = rb[r].x; cb.z = rb[r].y; cb.w = pid_pack(R(0), flat);
+                    cand[at] = slot[r];
+                    cand_a[at] = ca;
+                    cand_b[at] = cb;
+                }
                 n_cand += n_reach;
             }
         }
@@ -453,9 +464,9 @@ __device__ unsigned long long g_bvh_stats[8];
 
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
-k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
-                 const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
-                 HitRec<R>* hit, const uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
+k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh, HitRec<R>* hit,
+                 const uint32_t* __restrict__ cand, const typename Q4<R>::T* __restrict__ cand_a,
+                 const typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
                  uint32_t n_lists)
 {
     typedef typename Q4<R>::T R4;
@@ -536,17 +547,17 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wmask >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)wmask, 0u));
                 if (want && rank < avail) {
-                    slot = cand[cur_base + cur_off + rank];
-                    // the ray stream is read once: non-temporal, so that it does not push the BVH out of the XCD's L2
-                    const R4 ra = nt_load(ray_a + slot);
-                    const R2 rb = nt_load(ray_b + slot);
-                    const HitRec<R> h0 = hit[slot];             // closest analytic shape (k_intersect)
-                    o = mk<R>(ra.x, ra.y, ra.z);
-                    d = mk<R>(ra.w, rb.x, rb.y);
+                    // the candidate records are read once: non-temporal, so that they do not push the BVH out of the XCD's L2
+                    const size_t at = (size_t)cur_base + cur_off + rank;
+                    slot = __builtin_nontemporal_load(cand + at);
+                    const R4 ca = nt_load(cand_a + at);
+                    const R4 cb = nt_load(cand_b + at);
+                    o = mk<R>(ca.x, ca.y, ca.z);
+                    d = mk<R>(cb.x, cb.y, cb.z);
                     inv_d = mk<R>(div_r(R(1), d.x), div_r(R(1), d.y), div_r(R(1), d.z));   // (f32: v_rcp; the boxes are padded)
-                    tmin = h0.t;
-                    prim = h0.prim;
-                    best_flat = h0.prim >= 0 ? (uint32_t)sc->flat[h0.prim] : 0xFFFFFFFFu;
+                    tmin = ca.w;                                // closest analytic shape (k_intersect)
+                    best_flat = pid_unpack(cb.w);
+                    prim = -1;                                  // (a triangle, once one wins)
                     cur = 0;            // root
                     sp = 0;
                     want = false;
@@ -653,10 +664,12 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
         if (active && cur == DRT_BVH_NONE) {
-            HitRec<R> h;
-            h.t = tmin;
-            h.prim = prim;
-            hit[slot] = h;
+            if (prim >= 0) {                                    // a triangle beat the analytic hit k_intersect recorded
+                HitRec<R> h;
+                h.t = tmin;
+                h.prim = prim;
+                hit[slot] = h;
+            }
             active = false;
         }
     }
