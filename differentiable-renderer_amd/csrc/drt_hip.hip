@@ -489,14 +489,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         --region_shift;
     const uint32_t region_size = 1u << region_shift;
     const uint32_t max_regions = (uint32_t)((N + region_size - 1) / region_size);
-    // k_path geometry: wave <-> (64 pixels, spr samples); ~4 rounds of 16 waves per CU keep the tail short
+    // k_path geometry: wave <-> (64 pixels, spr samples); enough waves for ~5-6 rounds of the 5,120 the chip holds (the
+    // tail stays short) in ranges of equal length (sweep on config 3, ms per launch: 16 samples per range 0.827,
+    // 13: 0.818, 10: 0.793, 8: 0.812, 7: 0.795, 4: 0.811)
     const uint32_t path_groups = (Pb + DRT_WAVE - 1) / DRT_WAVE;
     uint32_t path_spr = 1;
     {
         // (regenerating lanes balance themselves over their sample range: longer ranges, fewer waves)
-        const uint64_t target = (uint64_t)ctx->n_cu * (path_regen ? 32 : 64);
-        const uint64_t want = (target + path_groups - 1) / path_groups;
-        path_spr = (uint32_t)(Sb / (want ? want : 1));
+        const uint64_t target = (uint64_t)ctx->n_cu * (path_regen ? 32 : 112);
+        const uint64_t want = std::max<uint64_t>(1, (target + path_groups - 1) / path_groups);   // ranges
+        path_spr = (uint32_t)((Sb + want - 1) / want);
         if (const char* e = getenv("DRT_HIP_PATH_SPR"))
             path_spr = (uint32_t)atoi(e);
         if (path_spr < 1) path_spr = 1;
