@@ -91,3 +91,37 @@ def test_config5_share_2048x2048_depth16_specular(pkg, hip, oracle):
     assert off.mean() <= 5e-4
     m_q, m_p = q_img.astype(np.float64).mean((0, 1)), img.astype(np.float64).mean((0, 1))
     assert np.abs(m_q - m_p).max() <= 1e-5 * m_p.max()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("config", [4, 5])
+def test_full_size_config_on_one_gpu_equals_its_eight_shards(pkg, hip, config):
+    """BASELINE configs 4 (1024 x 1024 x 256 spp, 50,880-triangle mesh) and 5 (2048 x 2048 x 1024 spp, depth 16,
+    diffuse + specular) at FULL size: rendered whole on one GPU, and as the eight row-band shards the eight GPUs of
+    the node would render (each with all the samples of its rows).  The shards tile the frame bit for bit, their
+    gradients sum to the whole frame's, and radiance is linear in the emission at full size."""
+    if config == 4:
+        scene, cam = pkg.scene_by_name("mesh160x160"), pkg.cornell_camera(1024, 1024)
+        rp = pkg.RenderParams(spp=256, min_bounces=8, absorb=1.0, seed=1, band_rows=16)
+    else:
+        scene, cam = pkg.scene_by_name("cornell_specular"), pkg.cornell_camera(2048, 2048)
+        rp = pkg.RenderParams(spp=1024, min_bounces=16, absorb=1.0, seed=1, band_rows=16)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    assert st["paths"] == cam.width * cam.height * rp.spp and st["capped_paths"] == 0
+    assert np.isfinite(img).all() and np.isfinite(grads).all()
+    e = scene.param_names.index("emission")
+    total = img.astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[e] * np.array(scene.params[e]), total, rtol=5e-6)
+    tiled = np.zeros_like(img)
+    g_sum = np.zeros_like(grads)
+    segments = 0
+    for shard in range(8):
+        s_img, s_grads, s_st = hip.render(cam, dataclasses.replace(rp, shard=shard, n_shards=8), backward=True)
+        assert s_st["paths"] == st["paths"] // 8
+        tiled += s_img                                  # (rows of the other shards are zero)
+        g_sum += s_grads
+        segments += s_st["segments"]
+    assert segments == st["segments"]
+    np.testing.assert_array_equal(tiled, img)
+    np.testing.assert_allclose(g_sum, grads, rtol=1e-9)
