@@ -559,7 +559,17 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     *n_count_words = cw;
     if ((rc = ensure(ctx, ctx->counts, cw * sizeof(uint32_t))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->segtotal, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written, capped
-    HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    // a k_path launch that covers the whole frame is followed by ONE finishing launch that WRITES image, gradients and
+    // totals (k_path_finish); every other route accumulates into zeroed buffers
+    static const bool finish_env = !(getenv("DRT_HIP_PATH_FINISH") && atoi(getenv("DRT_HIP_PATH_FINISH")) == 0);
+    const bool path_finish = finish_env && use_path && Pb == n_local_pixels && Sb == (uint32_t)spp && (!film || d_out_rgb);
+    if (!path_finish) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        if (film)
+            HIPCHK(ctx, hipMemsetAsync(film, 0, (size_t)n_local_pixels * 3 * sizeof(double), ctx->stream));
+        if (backward)
+            HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double), ctx->stream));
+    }
     const int bwd_grid = grid_for(ctx, N);
     if (backward) {   // per-block partial sums: K6's persistent grid, the shade kernel's one block per 4 regions, or k_path's blocks
         const size_t shade_blocks = (max_regions + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE);
@@ -643,6 +653,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         return n;
     };
     uint64_t batch = 0;
+    bool path_finished = false;
     for (uint32_t p0 = 0; p0 < n_local_pixels; p0 += Pb) {
         for (uint32_t s0 = 0; s0 < (uint32_t)spp; s0 += Sb, ++batch) {
             a.p0 = p0; a.s0 = s0;
@@ -679,15 +690,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 // analytic scene reads its kinds from the program
                 static const bool sig_env = !(getenv("DRT_HIP_PATH_SIG") && atoi(getenv("DRT_HIP_PATH_SIG")) == 0);
                 const bool cornell_sig = sig_env && sizeof(R) == 4 && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
+                unsigned long long* ptotal = path_finish ? (unsigned long long*)ctx->segtotal.p : (unsigned long long*)nullptr;
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
     do {                                                                                                                 \
         if (path_regen)                                                                                                  \
             hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts);                                 \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                         \
         else                                                                                                             \
             hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts);                                 \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                         \
     } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
     do {                                                                                   \
@@ -709,6 +721,22 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 st->launches[DRT_K_PATH]++;
                 st->path_bytes += (film ? (uint64_t)pa.n_ranges * a.Pb * 3 * sizeof(double) : 0) +
                                   (backward ? (uint64_t)gpath * DRT_FAST_PARAMS * 3 * sizeof(double) : 0) + 2 * n_waves * sizeof(uint32_t);
+                if (path_finish) {
+                    // image, gradients and totals of the frame in one launch (timed in the film slot)
+                    const uint32_t film_blocks = film ? (uint32_t)grid_for(ctx, a.Pb) : 0u;
+                    const uint32_t grad_words = backward ? (uint32_t)ctx->n_params * 3u : 0u;
+                    const uint32_t count_blocks = (uint32_t)std::min<size_t>(64, (n_waves + DRT_BLOCK - 1) / DRT_BLOCK);
+                    if ((rc = timing_begin(ctx, timing, DRT_K_FILM)) != DRT_OK) return rc;
+                    hipLaunchKernelGGL(k_path_finish, dim3(film_blocks + grad_words + count_blocks), dim3(DRT_BLOCK), 0, ctx->stream, pa,
+                                       (const double*)fpart, d_out_rgb, film_blocks, (const double*)gpart, gpath, n_fast * 3,
+                                       DRT_FAST_PARAMS * 3, grad, grad_words, (const uint32_t*)counts, (uint32_t)n_waves,
+                                       (unsigned long long*)ctx->segtotal.p);
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                    st->launches[DRT_K_FILM]++;
+                    st->units[DRT_K_FILM] += a.n_paths;
+                    path_finished = true;
+                    continue;
+                }
                 hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, counts, (uint32_t)(2 * n_waves),
                                    (unsigned long long*)ctx->segtotal.p, (uint32_t)n_waves, 0ull, 0ull, 1u);
                 if (backward) {
@@ -985,7 +1013,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     }
     st->batches = batch;
     st->paths = total_paths;
-    if (film && d_out_rgb) {
+    if (film && d_out_rgb && !path_finished) {
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
                            a, n_local_pixels, film, d_out_rgb);
     }
@@ -1326,7 +1354,6 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     const float* d_adj = nullptr;
     if (out_rgb) {
         if ((rc = ensure(ctx, ctx->film, (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->film.p, 0, (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double), ctx->stream));
         if (j.dev_out) {
             j.d_out = out_rgb;
         } else {
@@ -1336,7 +1363,6 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     }
     if (j.backward) {
         if ((rc = ensure(ctx, ctx->grad, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double), ctx->stream));
         if (adjoint_rgb) {
             if (j.dev_out) {
                 d_adj = adjoint_rgb;
@@ -1360,6 +1386,8 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     }
     double* d_film = out_rgb ? (double*)ctx->film.p : nullptr;   // no image requested: skip K5
     rc = DRT_OK;
+    if (j.n_local_pixels == 0 && j.backward)     // (a shard without rows: render_impl, which zeroes the accumulators, is not run)
+        HIPCHK(ctx, hipMemsetAsync(ctx->grad.p, 0, (size_t)(ctx->n_params ? ctx->n_params : 1) * 3 * sizeof(double), ctx->stream));
     if (j.n_local_pixels > 0) {
         if (f64)
             rc = render_impl<double>(ctx, cam, rp, d_adj, j.d_out, j.backward, j.timing, &j.st, j.n_local_pixels,

@@ -337,8 +337,11 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG, bool REGEN = false>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
-       double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts)
+       double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
+       unsigned long long* __restrict__ total)
 {
+    if (total && blockIdx.x == 0 && threadIdx.x < 4)
+        total[threadIdx.x] = 0;                           // (the finishing kernel behind this launch adds into them)
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     __shared__ SceneLds<R> lds;
@@ -554,5 +557,69 @@ k_film_parts(const double* __restrict__ fpart, uint32_t n_ranges, uint32_t Pb, u
         }
         double* f = film + (size_t)(p0 + j) * 3;
         f[0] += r; f[1] += g; f[2] += b;
+    }
+}
+
+// ---- everything behind a k_path launch that covers the whole frame, in ONE launch --------------------------------
+// (a single-batch render otherwise enqueues three memsets and four small kernels: film sums, resolve, K7, segment
+// totals -- 30 us of launches around a 15 us k_path on a 128 x 128 x 4 frame).  Same sums in the same order as
+// k_film_parts + k_resolve, k_gradreduce and k_sum_counts, written instead of added to zeroed buffers: bitwise the same.
+//   blocks [0, film_blocks):                  out[pixel] = float(sum over the sample ranges, in range order, / spp)
+//   blocks [film_blocks, + grad_words):       grad[p] = sum over k_path's blocks of gpart[block][p], fixed order (p >= n_rows: 0)
+//   the rest:                                 total[0] += segments, total[3] += capped paths (integers; k_path zeroed them)
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_path_finish(PathArgs a, const double* __restrict__ fpart, float* __restrict__ out, uint32_t film_blocks,
+              const double* __restrict__ gpart, int n_blocks, int n_rows, int row_stride, double* __restrict__ grad, uint32_t grad_words,
+              const uint32_t* __restrict__ counts, uint32_t n_waves, unsigned long long* __restrict__ total)
+{
+    __shared__ double red[DRT_BLOCK];
+    if (blockIdx.x < film_blocks) {
+        const uint32_t stride = film_blocks * DRT_BLOCK;
+        const double inv = 1.0 / (double)a.spp;
+        for (uint32_t j = blockIdx.x * DRT_BLOCK + threadIdx.x; j < a.Pb; j += stride) {
+            double r = 0, g = 0, b = 0;
+            for (uint32_t q = 0; q < a.n_ranges; ++q) {
+                const double* f = fpart + ((size_t)q * 3) * a.Pb + j;
+                r += f[0]; g += f[(size_t)a.Pb]; b += f[(size_t)a.Pb * 2];
+            }
+            const uint32_t gp = path_global_pixel(a, a.p0 + j);
+            out[(size_t)gp * 3 + 0] = (float)(r * inv);
+            out[(size_t)gp * 3 + 1] = (float)(g * inv);
+            out[(size_t)gp * 3 + 2] = (float)(b * inv);
+        }
+        return;
+    }
+    if (blockIdx.x < film_blocks + grad_words) {
+        const int p = (int)(blockIdx.x - film_blocks);
+        double v = 0;
+        if (p < n_rows)
+            for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
+                v += gpart[(size_t)b * row_stride + p];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off)
+                red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            grad[p] = red[0];
+        return;
+    }
+    {
+        const uint32_t nb = gridDim.x - film_blocks - grad_words, me = blockIdx.x - film_blocks - grad_words;
+        unsigned long long seg = 0, cap = 0;
+        for (uint32_t i = me * DRT_BLOCK + threadIdx.x; i < n_waves; i += nb * DRT_BLOCK) {
+            seg += counts[i];
+            cap += counts[(size_t)n_waves + i];
+        }
+        for (int off = DRT_WAVE / 2; off > 0; off >>= 1) {
+            seg += __shfl_down(seg, off);
+            cap += __shfl_down(cap, off);
+        }
+        if ((threadIdx.x & (DRT_WAVE - 1)) == 0) {
+            if (seg) atomicAdd(total, seg);
+            if (cap) atomicAdd(total + 3, cap);
+        }
     }
 }

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): regenerate every file of one round's evidence from the SAME binary.
+# Usage: tools/evidence.sh <tag>      outputs under gpurun_out/evidence_<tag>/ (copy into profiles/ with tools/collect_evidence.sh)
+set -u
+T=${1:-r02}
+E=$PWD/gpurun_out/evidence_$T
+mkdir -p "$E"
+bash tools/profile.sh $T cornell:512x512x64:d8:fwdbwd > "$E/prof.log" 2>&1
+cp gpurun_out/prof_$T/traffic.json profiles/traffic.json          # bench.py quotes PMC numbers only for the workload named in it
+bash tools/profile.sh ${T}_streaming cornell:512x512x64:d8:fwdbwd --bounces-per-launch 1 >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_mesh mesh160x160:512x512x64:d8:fwdbwd --scene mesh160x160 >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_config5 cornell_specular:1024x1024x16:d16:fwdbwd --config 5 --width 1024 --height 1024 --spp 16 >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0.5 --min-bounces 1 >> "$E/prof.log" 2>&1
+python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
+python3 bench.py > "$E/bench.json" 2> "$E/bench.err"
+python3 bench.py --config 2 --no-cpu-baseline > "$E/bench_config2_fwd_only.json" 2>> "$E/bench.err"
+python3 bench.py --config 4 > "$E/bench_config4_per_gpu_share.json" 2>> "$E/bench.err"
+python3 bench.py --config 5 > "$E/bench_config5_per_gpu_share.json" 2>> "$E/bench.err"
+python3 bench.py --config 4 --spp 256 --steps 5 --warmup 1 --no-cpu-baseline --no-extra-views > "$E/bench_config4_full_size_one_gpu.json" 2>> "$E/bench.err"
+python3 bench.py --config 5 --spp 1024 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-views > "$E/bench_config5_full_size_one_gpu.json" 2>> "$E/bench.err"
+python3 bench.py --scene mesh160x160 > "$E/bench_mesh160x160_512x512x64.json" 2>> "$E/bench.err"
+python3 bench.py --absorb 0.5 --min-bounces 1 > "$E/bench_roulette_b1_p0.5.json" 2>> "$E/bench.err"
+python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-extra-views > "$E/bench_2ranks_same_gpu_plumbing.json" 2>> "$E/bench.err"
+python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
+for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_roulette; do
+  P=gpurun_out/prof_$t
+  cp $P/summary.txt "$E/${t}_rocprofv3_summary.txt"
+  cp $P/traffic.json "$E/${t}_traffic.json"
+  cp $P/bench_trace.json "$E/${t}_bench_under_rocprof.json"
+  cp $(ls $P/trace/*/*kernel_stats.csv | head -1) "$E/${t}_kernel_stats.csv"
+done
+tail -3 "$E/bench.err"
+cat "$E/bench.json" | cut -c1-400
