@@ -446,8 +446,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     bool path_regen = regen_env > 0;
     if (use_path && regen_env < 0) {
         // lockstep: a wave runs until the longest of its 64 paths ends (~ the depth where 1 path in 64 is left);
-        // regenerating: every lane runs the mean path length, at ~1.4 x the instructions per bounce (measured on
-        // config 3, where both apply: 1.20 against 0.88 ms)
+        // regenerating: every lane runs the mean path length, at ~1.4 x the cost per bounce (measured on config 3,
+        // where both apply: 1.20 against 0.88 ms) -- ~2.1 x with glossy surfaces, whose regenerating kernel needs
+        // 139 registers, 3 waves per SIMD (config 5's scene at depth 16: 5.70 against 4.37 ms)
         double alive = 1.0, mean_len = 0.0;
         int longest = D;
         for (int k = 0; k < D; ++k) {
@@ -456,7 +457,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             if (alive < 1.0 / 64 && longest == D)
                 longest = k + 1;
         }
-        path_regen = 1.4 * mean_len < (double)longest;
+        path_regen = (ctx->has_specular ? 2.1 : 1.4) * mean_len < (double)longest;
     }
     uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
     if (use_path && rp->batch_paths <= 0)

@@ -124,4 +124,6 @@ def test_full_size_config_on_one_gpu_equals_its_eight_shards(pkg, hip, config):
         segments += s_st["segments"]
     assert segments == st["segments"]
     np.testing.assert_array_equal(tiled, img)
-    np.testing.assert_allclose(g_sum, grads, rtol=1e-9)
+    # (a lane adds up the gradient terms of its sample range in f32 before the f64 block sums; the whole frame and a
+    # shard cut the 1024 samples into different ranges: equal to f32 accumulation, measured 1.2e-7)
+    np.testing.assert_allclose(g_sum, grads, rtol=2e-6)

@@ -26,6 +26,7 @@ for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_roulette; do
   P=gpurun_out/prof_$t
   cp $P/summary.txt "$E/${t}_rocprofv3_summary.txt"
   cp $P/traffic.json "$E/${t}_traffic.json"
+  cp $P/summary.json "$E/${t}_rocprofv3_summary.json"
   cp $P/bench_trace.json "$E/${t}_bench_under_rocprof.json"
   cp $(ls $P/trace/*/*kernel_stats.csv | head -1) "$E/${t}_kernel_stats.csv"
 done
