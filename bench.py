@@ -473,7 +473,12 @@ def main():
             "f64": f64_view, "fwd_only": fwd_view,
         }
         print(json.dumps(line), flush=True)
+    # teardown in the same order on every rank: the library's communicator first (all ranks are still here), then the
+    # launcher's process group, then the context
+    r.synchronize()
     if use_dist:
+        if reduce_mode == "library":
+            r.comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
     r.close()
