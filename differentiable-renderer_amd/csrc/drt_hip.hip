@@ -1229,7 +1229,25 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
             const double diag = sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) +
                                      (hi[2] - lo[2]) * (hi[2] - lo[2]));
             static_assert(drt_bvh::kStackEntries == DRT_BVH_STACK, "builder and traversal kernel disagree on the stack size");
-            const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES, 1e-5 * (diag > 0 ? diag : 1.0));
+            // Padding of the boxes: 1e-5 of the mesh diagonal, and never less than 2e-6 of the scene's extent -- the f32
+            // walk places a box plane to ~2^-22 of the distance between ray origin and node (k_intersect_mesh), and ray
+            // origins lie on the scene's surfaces; a mesh that is tiny against its room keeps conservative boxes
+            // (tools/tiny_mesh.py: no lost hit down to 1/256 of the config-4 mesh).
+            double extent = 0;
+            for (int x = 0; x < 3; ++x)
+                extent = std::max(extent, std::max(fabs(lo[x]), fabs(hi[x])));
+            for (int i = 0; i < s->n_shapes; ++i) {
+                const drt_shape_desc& sh = s->shapes[i];
+                if (sh.type == DRT_SHAPE_PLANE) {          // (the normal is not normalised, shape.hpp:58-59)
+                    const double nn = sqrt(sh.p[0] * sh.p[0] + sh.p[1] * sh.p[1] + sh.p[2] * sh.p[2]);
+                    if (nn > 0)
+                        extent = std::max(extent, fabs(sh.p[3]) / nn);
+                }
+                else if (sh.type == DRT_SHAPE_SPHERE)
+                    extent = std::max(extent, sqrt(sh.p[0] * sh.p[0] + sh.p[1] * sh.p[1] + sh.p[2] * sh.p[2]) + fabs(sh.p[3]));
+            }
+            const double pad = std::max(1e-5 * (diag > 0 ? diag : 1.0), 2e-6 * extent);
+            const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES, pad);
             if (built.stack_need > DRT_BVH_STACK)      // not even a balanced tree fits (> ~2 M triangles)
                 return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: the BVH of this mesh needs a deeper traversal stack than the device kernel has");
             if ((rc = upload_bvh<float>(ctx, built, tris, &ctx->bvh_f)) != DRT_OK) return rc;
