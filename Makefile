@@ -7,11 +7,14 @@ PKG := differentiable-renderer_amd
 LIB := $(PKG)/libdrt_hip.so
 CXX ?= g++
 HIPCC ?= hipcc
+# the EXR writer compresses (ZIP blocks) when zlib is there, writes uncompressed scan lines otherwise
+EXR_ZLIB := $(shell echo '\#include <zlib.h>' | $(CXX) -E -x c++ - >/dev/null 2>&1 && echo -DDRT_EXR_ZLIB)
+EXR_ZLIB_LIB := $(if $(EXR_ZLIB),-lz)
 
 all: lib oracle host
 
 lib: $(LIB)
-$(LIB): $(PKG)/csrc/drt_hip.hip $(PKG)/csrc/drt_kernels.h $(PKG)/csrc/drt_device.h $(PKG)/csrc/drt_bvh.h include/drt_hip.h
+$(LIB): $(PKG)/csrc/drt_hip.hip $(wildcard $(PKG)/csrc/*.h) include/drt_hip.h
 	$(HIPCC) --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude -o $@ $(PKG)/csrc/drt_hip.hip -lrccl
 
 oracle:
@@ -20,7 +23,7 @@ oracle:
 host: build/render
 build/render: src/render_hip.cpp src/args.hpp src/write.hpp $(wildcard include/drt/*.hpp) include/drt_hip.h $(LIB)
 	mkdir -p build
-	$(CXX) -O3 -std=c++17 -Iinclude -Isrc -o $@ src/render_hip.cpp -L$(PKG) -ldrt_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lpthread
+	$(CXX) -O3 -std=c++17 -Iinclude -Isrc $(EXR_ZLIB) -o $@ src/render_hip.cpp -L$(PKG) -ldrt_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lpthread $(EXR_ZLIB_LIB)
 
 clean:
 	rm -rf build $(LIB)

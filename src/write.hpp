@@ -1,16 +1,23 @@
 // write.hpp -- drt::write_exr(fname, data, width, height): same signature and pixel semantics as
 // the reference's src/write.hpp:9-26 (RGBA, 16-bit half, alpha 1, increasing-Y scan lines), but
 // self-contained: OpenEXR (branch RB-2.5 in the reference's .gitmodules) is not available here, so
-// this writes the OpenEXR 2 single-part scan-line container itself, uncompressed.  Pixel parity
-// with Imf::RgbaOutputFile, not byte parity (the reference's default is PIZ compression).
+// this writes the OpenEXR 2 single-part scan-line container itself: ZIP-compressed blocks of 16 scan lines
+// (the OpenEXR file-layout document's ZIP_COMPRESSION: byte de-interleave, delta predictor, zlib deflate) when
+// built with -DDRT_EXR_ZLIB -lz, uncompressed scan lines otherwise.  Pixel parity with Imf::RgbaOutputFile,
+// not byte parity (the reference's default is PIZ compression, a wavelet + Huffman coder of OpenEXR's own).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#ifdef DRT_EXR_ZLIB
+#include <zlib.h>
+#endif
 
 #include "drt/vector.hpp"
 
@@ -80,7 +87,14 @@ inline void write_exr(const char* fname, const Vector<T, 3>* data, std::size_t w
         v.push_back(0);
         attr(head, "channels", "chlist", v);
     }
-    { std::vector<unsigned char> v(1, 0); attr(head, "compression", "compression", v); }   // NO_COMPRESSION
+#ifdef DRT_EXR_ZLIB
+    const unsigned char compression = 3;       // ZIP_COMPRESSION: blocks of 16 scan lines
+    const size_t block_lines = 16;
+#else
+    const unsigned char compression = 0;       // NO_COMPRESSION: one scan line per block
+    const size_t block_lines = 1;
+#endif
+    { std::vector<unsigned char> v(1, compression); attr(head, "compression", "compression", v); }
     {
         std::vector<unsigned char> v;
         put_i32(v, 0); put_i32(v, 0); put_i32(v, (int32_t)width - 1); put_i32(v, (int32_t)height - 1);
@@ -93,30 +107,69 @@ inline void write_exr(const char* fname, const Vector<T, 3>* data, std::size_t w
     { std::vector<unsigned char> v; put_f32(v, 1.f); attr(head, "screenWindowWidth", "float", v); }
     head.push_back(0);
 
+    // the blocks: y of the first line, byte count, data (scan lines, each A B G R planes of halfs)
     const size_t line_bytes = width * 4 * 2;
-    const uint64_t first = head.size() + 8ull * height;
+    const size_t n_blocks = (height + block_lines - 1) / block_lines;
+    std::vector<std::vector<unsigned char>> blocks(n_blocks);
+    const uint16_t one = float_to_half(1.f);
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const size_t y0 = b * block_lines, y1 = std::min(height, y0 + block_lines);
+        std::vector<unsigned char> raw((y1 - y0) * line_bytes);
+        for (size_t y = y0; y < y1; ++y) {
+            uint16_t* line = reinterpret_cast<uint16_t*>(raw.data() + (y - y0) * line_bytes);
+            for (size_t x = 0; x < width; ++x) {
+                const Vector<T, 3>& rgb = data[y * width + x];
+                line[0 * width + x] = one;                                   // A
+                line[1 * width + x] = float_to_half((float)real(rgb[2]));  // B
+                line[2 * width + x] = float_to_half((float)real(rgb[1]));  // G
+                line[3 * width + x] = float_to_half((float)real(rgb[0]));  // R
+            }
+        }
+#ifdef DRT_EXR_ZLIB
+        // ZIP block: even bytes then odd bytes, each byte replaced by its difference to the previous one (+ 128), deflate;
+        // a block that does not shrink is stored raw (the reader tells by the size)
+        std::vector<unsigned char> tmp(raw.size());
+        {
+            unsigned char* t1 = tmp.data();
+            unsigned char* t2 = tmp.data() + (raw.size() + 1) / 2;
+            for (size_t i = 0; i < raw.size(); ++i)
+                *((i & 1) ? t2++ : t1++) = raw[i];
+            int prev = tmp[0];
+            for (size_t i = 1; i < tmp.size(); ++i) {
+                const int cur = tmp[i];
+                tmp[i] = (unsigned char)(cur - prev + (128 + 256));
+                prev = cur;
+            }
+        }
+        uLongf out_size = compressBound((uLong)tmp.size());
+        std::vector<unsigned char> packed(out_size);
+        if (compress(packed.data(), &out_size, tmp.data(), (uLong)tmp.size()) != Z_OK)
+            throw std::runtime_error("write_exr: zlib compress failed");
+        if (out_size < raw.size()) {
+            packed.resize(out_size);
+            blocks[b].swap(packed);
+        } else {
+            blocks[b].swap(raw);
+        }
+#else
+        blocks[b].swap(raw);
+#endif
+    }
+
     std::FILE* f = std::fopen(fname, "wb");
     if (!f)
         throw std::runtime_error(std::string("write_exr: cannot open ") + fname);
     std::fwrite(head.data(), 1, head.size(), f);
-    for (size_t y = 0; y < height; ++y) {
-        const uint64_t off = first + y * (8 + line_bytes);
+    uint64_t off = head.size() + 8ull * n_blocks;
+    for (size_t b = 0; b < n_blocks; ++b) {
         std::fwrite(&off, 8, 1, f);
+        off += 8 + blocks[b].size();
     }
-    std::vector<uint16_t> line(width * 4);
-    const uint16_t one = float_to_half(1.f);
-    for (size_t y = 0; y < height; ++y) {
-        for (size_t x = 0; x < width; ++x) {
-            const Vector<T, 3>& rgb = data[y * width + x];
-            line[0 * width + x] = one;                                   // A
-            line[1 * width + x] = float_to_half((float)real(rgb[2]));  // B
-            line[2 * width + x] = float_to_half((float)real(rgb[1]));  // G
-            line[3 * width + x] = float_to_half((float)real(rgb[0]));  // R
-        }
-        const int32_t yy = (int32_t)y, size = (int32_t)line_bytes;
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const int32_t yy = (int32_t)(b * block_lines), size = (int32_t)blocks[b].size();
         std::fwrite(&yy, 4, 1, f);
         std::fwrite(&size, 4, 1, f);
-        std::fwrite(line.data(), 1, line_bytes, f);
+        std::fwrite(blocks[b].data(), 1, blocks[b].size(), f);
     }
     std::fclose(f);
 }

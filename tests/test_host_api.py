@@ -17,7 +17,9 @@ def sh(cmd, **kw):
 
 
 def read_exr_half_rgba(path):
-    """Minimal reader for what src/write.hpp writes (uncompressed scan lines, HALF A,B,G,R)."""
+    """Minimal reader for what src/write.hpp writes (HALF A,B,G,R scan lines; uncompressed, or ZIP blocks of 16 lines
+    decoded per the OpenEXR layout: inflate, undo the delta predictor, re-interleave the two byte halves)."""
+    import zlib
     data = open(path, "rb").read()
     assert struct.unpack_from("<I", data, 0)[0] == 20000630 and data[4] == 2
     pos = 8
@@ -30,14 +32,30 @@ def read_exr_half_rgba(path):
     pos += 1
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
-    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
-    offsets = struct.unpack_from(f"<{h}Q", data, pos)
+    comp = attrs["compression"][1][0]
+    assert comp in (0, 3) and attrs["lineOrder"][1] == b"\0"
+    lines = 16 if comp == 3 else 1
+    n_blocks = (h + lines - 1) // lines
+    offsets = struct.unpack_from(f"<{n_blocks}Q", data, pos)
     img = np.zeros((h, w, 4), np.float32)
-    for y in range(h):
-        yy, size = struct.unpack_from("<ii", data, offsets[y])
-        assert yy == y and size == w * 8
-        line = np.frombuffer(data, dtype="<f2", count=w * 4, offset=offsets[y] + 8).reshape(4, w)
-        img[y, :, 3], img[y, :, 2], img[y, :, 1], img[y, :, 0] = line[0], line[1], line[2], line[3]
+    for b in range(n_blocks):
+        yy, size = struct.unpack_from("<ii", data, offsets[b])
+        n = min(lines, h - b * lines)
+        assert yy == b * lines
+        raw = data[offsets[b] + 8:offsets[b] + 8 + size]
+        if comp == 3 and size < n * w * 8:
+            t = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int64)
+            assert t.size == n * w * 8
+            t = (np.cumsum(np.concatenate([t[:1], t[1:] - 128])) & 0xFF).astype(np.uint8)   # undo the predictor
+            out = np.empty_like(t)
+            half = (t.size + 1) // 2
+            out[0::2], out[1::2] = t[:half], t[half:]                                        # re-interleave
+            raw = out.tobytes()
+        assert len(raw) == n * w * 8
+        block = np.frombuffer(raw, dtype="<f2").reshape(n, 4, w)
+        for i in range(n):
+            y = b * lines + i
+            img[y, :, 3], img[y, :, 2], img[y, :, 1], img[y, :, 0] = block[i, 0], block[i, 1], block[i, 2], block[i, 3]
     return img
 
 
@@ -125,6 +143,34 @@ def test_float_to_half_round_to_nearest_even(tmp_path):
     with np.errstate(over="ignore"):
         want = vals.astype(np.float16).view(np.uint16).astype(np.uint32)
     np.testing.assert_array_equal(got, want)
+
+
+def test_exr_zip_blocks_decode_to_the_uncompressed_file(tmp_path):
+    """write_exr with -DDRT_EXR_ZLIB (ZIP_COMPRESSION, blocks of 16 scan lines; the last block of a 37-line image has 5)
+    against the uncompressed writer: the same half pixels, a smaller file; a noisy image whose blocks do not shrink is
+    stored raw block by block."""
+    src = tmp_path / "w.cpp"
+    src.write_text('#include "write.hpp"\n#include <cstdlib>\n#include <vector>\n'
+                   'int main(int c, char** v){ const int W = 53, H = 37; std::vector<drt::Vector<double, 3>> img(W * H);\n'
+                   '  const bool noisy = c > 2; unsigned s = 1;\n'
+                   '  for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { s = s * 1664525u + 1013904223u;\n'
+                   '    const double n = noisy ? (s >> 8) / 16777216.0 : 0.0;\n'
+                   '    img[y * W + x] = drt::Vector<double, 3>{0.01 * x + n, 0.02 * y + 3 * n, 0.5 + 7 * n}; }\n'
+                   '  drt::write_exr(v[1], img.data(), W, H); return 0; }\n')
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "src")]
+    sh(["g++", "-O1", "-std=c++17"] + inc + [str(src), "-o", str(tmp_path / "plain")])
+    sh(["g++", "-O1", "-std=c++17", "-DDRT_EXR_ZLIB"] + inc + [str(src), "-o", str(tmp_path / "zip"), "-lz"])
+    for noisy in ([], ["noisy"]):
+        a, b = str(tmp_path / "a.exr"), str(tmp_path / "b.exr")
+        sh([str(tmp_path / "plain"), a] + noisy)
+        sh([str(tmp_path / "zip"), b] + noisy)
+        ia, ib = read_exr_half_rgba(a), read_exr_half_rgba(b)
+        np.testing.assert_array_equal(ia, ib)
+        assert ia.shape == (37, 53, 4) and (ia[..., 3] == 1).all()
+        if not noisy:
+            assert abs(float(ia[10, 20, 0]) - 0.2) < 1e-3 and os.path.getsize(b) < os.path.getsize(a) // 3
+        else:
+            assert os.path.getsize(b) <= os.path.getsize(a) + 64
 
 
 @pytest.mark.skipif(not os.path.exists(REF_APP), reason="reference sources only exist in the build container")
