@@ -202,7 +202,7 @@ class Scene:
 
 
 def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front_mirror: bool = False,
-                mirror_wall: bool = False) -> Scene:
+                mirror_wall: bool = False, per_wall: bool = False) -> Scene:
     """The hard-coded scene of /root/reference/src/render.cpp:26-59 (same order, same values).
 
     front_specular: sphere_front uses SpecularBxDF(white, 30) (render.cpp:35 creates it, the
@@ -210,7 +210,9 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front
     emissive_wall: the back plane additionally carries an emitter (a shape with BOTH a BxDF and
     an emitter: several emission terms per path).
     front_mirror / mirror_wall: sphere_front / the back plane use MirrorBxDF (unit normals only: a
-    mirror off the non-unit right wall would hand the spheres a non-unit direction)."""
+    mirror off the non-unit right wall would hand the spheres a non-unit direction).
+    per_wall: the back, front, ground and ceiling planes get albedo parameters of their own (8 parameters in all: what
+    an inverse-rendering loop over "every wall's colour" optimises)."""
     s = Scene()
     red = s.parameter((0.5, 0, 0), True, "red")                 # render.cpp:26
     green = s.parameter((0, 0.5, 0), True, "green")             # :27
@@ -234,6 +236,11 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front
     s.plane((0, 0, 1), 0, diffuse_white)                        # :44 front
     s.plane((0., 1., 0.), -3., diffuse_white)                   # :45 ground
     s.plane((0., -1., 0.), -3., diffuse_white)                  # :46 ceiling
+    if per_wall:
+        for shape, (name, col) in zip((4, 5, 6, 7), (("back", (0.6, 0.5, 0.4)), ("front", (0.4, 0.4, 0.5)),
+                                                     ("ground", (0.5, 0.55, 0.45)), ("ceiling", (0.45, 0.5, 0.55)))):
+            t, _, e, p4 = s.shapes[shape]
+            s.shapes[shape] = (t, s.diffuse(s.parameter(col, True, name)), e, p4)
     s.sphere((0., 3., 3.), 1., -1, emitter)                     # :47 light (no BxDF)
     return s
 
@@ -325,6 +332,8 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box()
     if name == "cornell_specular":
         return cornell_box(front_specular=True)
+    if name == "cornell_walls":
+        return cornell_box(per_wall=True)
     if name == "cornell_emissive_wall":
         return cornell_box(emissive_wall=True)
     if name == "cornell_mirror":

@@ -440,7 +440,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     // roulette-terminated paths under the default cap of 64, the reference's own defaults (-b 1 -p 0.5).
     static const int path_env = getenv("DRT_HIP_PATH") ? atoi(getenv("DRT_HIP_PATH")) : 1;
     bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && !unbiased && gimg_param < 0 && D > 0 &&
-                    (!backward || ctx->n_params <= 4) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
+                    (!backward || ctx->n_params <= DRT_FAST_PARAMS) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
                     !getenv("DRT_HIP_DUMP_PATH");
     static const int regen_env = getenv("DRT_HIP_PATH_REGEN") ? atoi(getenv("DRT_HIP_PATH_REGEN")) : -1;
     bool path_regen = regen_env > 0;
@@ -709,7 +709,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     } while (0)
                 // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
                 const bool three = ctx->max_colour_param < 3;
-                if (backward) {
+                if (backward && ctx->n_params > 4) {        // 5 .. 8 parameters: 24 tangent + 24 gradient registers per lane
+                    if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 8, 8);
+                    else DRT_LAUNCH_PATH_SIG(false, 8, 8);
+                } else if (backward) {
                     if (ctx->has_specular) { if (three) DRT_LAUNCH_PATH_SIG(true, 4, 3); else DRT_LAUNCH_PATH_SIG(true, 4, 4); }
                     else { if (three) DRT_LAUNCH_PATH_SIG(false, 4, 3); else DRT_LAUNCH_PATH_SIG(false, 4, 4); }
                 } else {
