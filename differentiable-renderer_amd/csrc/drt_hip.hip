@@ -80,7 +80,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, cand, cand_a, cand_b, cand_count,
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -439,8 +439,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     // min_bounces on -- and the regenerating form (a lane whose path ended starts its next sample at once) otherwise:
     // roulette-terminated paths under the default cap of 64, the reference's own defaults (-b 1 -p 0.5).
     static const int path_env = getenv("DRT_HIP_PATH") ? atoi(getenv("DRT_HIP_PATH")) : 1;
-    bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && !unbiased && gimg_param < 0 && D > 0 &&
-                    (!backward || ctx->n_params <= DRT_FAST_PARAMS) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
+    bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && !unbiased && D > 0 &&
+                    (!(backward || gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
                     !getenv("DRT_HIP_DUMP_PATH");
     static const int regen_env = getenv("DRT_HIP_PATH_REGEN") ? atoi(getenv("DRT_HIP_PATH_REGEN")) : -1;
     bool path_regen = regen_env > 0;
@@ -519,6 +519,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if (use_path) {
         cw = 2 * path_waves;                     // [segments | capped paths] per wave
         if ((rc = ensure(ctx, ctx->fpart, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
+        if (gimg_param >= 0)
+            if ((rc = ensure(ctx, ctx->gpix, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
     } else {
     for (int i = 0; i < 2; ++i) {
         if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
@@ -687,6 +689,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 const size_t n_waves = (size_t)pa.n_groups * pa.n_ranges;
                 const int gpath = (int)((n_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
                 double* fpart = film ? (double*)ctx->fpart.p : (double*)nullptr;
+                double* gpix = gimg_param >= 0 ? (double*)ctx->gpix.p : (double*)nullptr;   // gradient image partials
+                pa.gimg_param = gimg_param;
                 // the kinds of the reference's own scene are compiled in (no per-shape branches); any other
                 // analytic scene reads its kinds from the program
                 static const bool sig_env = !(getenv("DRT_HIP_PATH_SIG") && atoi(getenv("DRT_HIP_PATH_SIG")) == 0);
@@ -697,10 +701,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     do {                                                                                                                 \
         if (path_regen)                                                                                                  \
             hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                         \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
         else                                                                                                             \
             hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                         \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
     } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
     do {                                                                                   \
@@ -709,10 +713,11 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     } while (0)
                 // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
                 const bool three = ctx->max_colour_param < 3;
-                if (backward && ctx->n_params > 4) {        // 5 .. 8 parameters: 24 tangent + 24 gradient registers per lane
+                const bool tangents = backward || gimg_param >= 0;
+                if (tangents && ctx->n_params > 4) {        // 5 .. 8 parameters: 24 tangent + 24 gradient registers per lane
                     if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 8, 8);
                     else DRT_LAUNCH_PATH_SIG(false, 8, 8);
-                } else if (backward) {
+                } else if (tangents) {
                     if (ctx->has_specular) { if (three) DRT_LAUNCH_PATH_SIG(true, 4, 3); else DRT_LAUNCH_PATH_SIG(true, 4, 4); }
                     else { if (three) DRT_LAUNCH_PATH_SIG(false, 4, 3); else DRT_LAUNCH_PATH_SIG(false, 4, 4); }
                 } else {
@@ -738,6 +743,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_FILM]++;
                     st->units[DRT_K_FILM] += a.n_paths;
+                    if (gpix && d_out_gimg) {   // the gradient image: the same sums over the sample ranges, its own output
+                        const uint32_t gb = (uint32_t)grid_for(ctx, a.Pb);
+                        hipLaunchKernelGGL(k_path_finish, dim3(gb), dim3(DRT_BLOCK), 0, ctx->stream, pa, (const double*)gpix, d_out_gimg, gb,
+                                           (const double*)nullptr, 0, 0, DRT_FAST_PARAMS * 3, (double*)nullptr, 0u, (const uint32_t*)counts,
+                                           0u, (unsigned long long*)ctx->segtotal.p);
+                    }
                     path_finished = true;
                     continue;
                 }
@@ -759,6 +770,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     st->launches[DRT_K_FILM]++;
                     st->units[DRT_K_FILM] += a.n_paths;
                 }
+                if (gpix && gfilm)
+                    hipLaunchKernelGGL(k_film_parts, dim3(grid_for(ctx, a.Pb)), dim3(DRT_BLOCK), 0, ctx->stream, gpix,
+                                       pa.n_ranges, a.Pb, a.p0, gfilm);
                 continue;
             }
             HIPCHK(ctx, hipMemsetAsync(counts, 0, cw * sizeof(uint32_t), ctx->stream));
@@ -1021,7 +1035,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
                            a, n_local_pixels, film, d_out_rgb);
     }
-    if (gimg_param >= 0 && gfilm && d_out_gimg) {
+    if (gimg_param >= 0 && gfilm && d_out_gimg && !path_finished) {
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
                            a, n_local_pixels, gfilm, d_out_gimg);
     }
@@ -1095,7 +1109,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->fpart, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};

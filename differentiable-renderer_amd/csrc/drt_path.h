@@ -46,6 +46,7 @@ struct PathArgs {
     int32_t min_bounces, depth_cap, cap_is_roulette;
     uint32_t rr_threshold, seed;
     uint32_t regen_min;             // regenerating form: idle lanes it takes to run the camera code (see k_path)
+    int32_t gimg_param;             // >= 0: the lanes' gradient sums of this parameter also leave per pixel (gradient image)
     double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
     // camera
     double eye[3], fwd[3], right[3], up[3];
@@ -338,7 +339,7 @@ template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSI
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
-       unsigned long long* __restrict__ total)
+       unsigned long long* __restrict__ total, double* __restrict__ gimg_part)
 {
     if (total && blockIdx.x == 0 && threadIdx.x < 4)
         total[threadIdx.x] = 0;                           // (the finishing kernel behind this launch adds into them)
@@ -514,6 +515,16 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         if (fpart && have) {
             double* f = fpart + ((size_t)range * 3) * a.Pb + lp;       // [range][channel][pixel]: coalesced
             f[0] = fx; f[(size_t)a.Pb] = fy; f[(size_t)a.Pb * 2] = fz;
+        }
+        if (NP > 0 && gimg_part && have) {
+            // gradient image (README.md:142-145): a lane IS a pixel, its gradient sum of one parameter over the samples of
+            // this range is that pixel's share -- same layout as the radiance partials, same finishing kernels
+            V3<R> v = tg.acc[0];
+#pragma unroll
+            for (int p = 1; p < NP; ++p)
+                v = mk<R>(a.gimg_param == p ? tg.acc[p].x : v.x, a.gimg_param == p ? tg.acc[p].y : v.y, a.gimg_param == p ? tg.acc[p].z : v.z);
+            double* f = gimg_part + ((size_t)range * 3) * a.Pb + lp;
+            f[0] = (double)v.x; f[(size_t)a.Pb] = (double)v.y; f[(size_t)a.Pb * 2] = (double)v.z;
         }
         if (lane == 0) {
             counts[w] = n_seg;
