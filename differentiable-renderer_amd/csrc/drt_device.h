@@ -48,7 +48,7 @@ struct DevScene {
     // k_path's intersection program (drt_path.h): one record per shape, scene order, 3 kind bits per shape;
     // prog_ok = the scene has at most DRT_PROG_MAX shapes and no mesh
     unsigned long long prog_kinds;
-    int prog_ok, prog_pad;
+    int prog_ok, prog_sorted;     // prog_sorted: the kind-sorted copy below is valid for the ANALYTIC shapes (mesh records left out)
     R prog[DRT_PROG_MAX][4];
     // the same records SORTED BY KIND (scene order kept inside a kind) for scenes whose kinds are not compiled in:
     // sorted[i] = (record.xyzw), sorted_shape[i] = its shape index, kind k occupies [kind_begin[k], kind_begin[k + 1])

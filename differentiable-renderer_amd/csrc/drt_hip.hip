@@ -65,6 +65,7 @@ struct drt_hip_ctx {
     bool has_specular = false;
     int max_colour_param = -1;            // largest parameter index that is some material's colour (device numbering)
     bool prog_ok = false;                 // k_path's intersection program covers the scene (drt_path.h)
+    bool prog_sorted = false;             // the kind-sorted program covers the scene's analytic shapes (k_shade's tail)
     unsigned long long prog_kinds = 0;
     int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)
     int n_user_params = 0;            // what the caller uploaded and gets gradients for
@@ -80,7 +81,7 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
+    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, hit2, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal, film, gpart, grad, adjoint, out;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -294,13 +295,18 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         ds.emitter_param[i] = s->emitters[i].param;
     // k_path (drt_path.h): the parameter ids of every shape in one word, and the intersection program
     ds.prog_ok = s->n_shapes <= DRT_PROG_MAX ? 1 : 0;
+    bool has_mesh_shape = false;
     for (int i = 0; i < s->n_shapes; ++i) {
         const int m = s->shapes[i].material, e = s->shapes[i].emitter;
         const uint32_t cid = m >= 0 ? (uint32_t)ds.materials[m].param : DRT_ID_NONE;
         const uint32_t eid = e >= 0 ? (uint32_t)s->emitters[e].param : DRT_ID_NONE;
         ds.shapes[i].pad = (int)(cid | (eid << 16));
-        if (s->shapes[i].type == DRT_SHAPE_MESH)
-            ds.prog_ok = 0;
+        if (s->shapes[i].type == DRT_SHAPE_MESH) {
+            has_mesh_shape = true;              // (k_path does not walk meshes; the program simply leaves the record out:
+            if (i < DRT_PROG_MAX)               //  kind 7 belongs to no kind loop -- k_shade's tail tests the analytic rest)
+                ds.prog_kinds |= 7ull << (3 * i);
+            continue;
+        }
         if (!ds.prog_ok || i >= DRT_PROG_MAX)
             continue;
         int kind = s->shapes[i].type == DRT_SHAPE_SPHERE ? DRT_PK_SPHERE : DRT_PK_PLANE;
@@ -334,6 +340,9 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         for (int k = 5; k < 8; ++k)
             ds.kind_begin[k] = n;
     }
+    ds.prog_sorted = ds.prog_ok;                   // the sorted program is valid (for the analytic shapes)
+    if (has_mesh_shape)
+        ds.prog_ok = 0;                         // ... but k_path is not for scenes with a mesh
     params.assign((size_t)ds.n_params * 3, R(1));
     for (size_t i = 0; i < (size_t)s->n_params * 3; ++i)
         params[i] = (R)s->params[i];
@@ -511,7 +520,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     // the rays the BVH walk has to see: one dense list per wave of k_intersect's persistent grid (+ the walk's list counter)
     // (list l = span [l * cand_cap, ...) of `cand`, cand_cap = the chunks one K2 wave of THIS launch sees, x 64)
     const uint32_t k2_waves = (uint32_t)k2_mesh_grid(ctx, N) * (DRT_BLOCK / DRT_WAVE);
-    const size_t cand_words = (((size_t)max_regions << (region_shift - 6)) + k2_waves) * DRT_WAVE;
+    const size_t cand_words = (((size_t)max_regions << (region_shift - 6)) + k2_waves) * DRT_WAVE;   // (>= max_regions * region_size)
+    // scenes with a mesh: the shade launch intersects the ray it produces with the analytic shapes and builds the BVH
+    // walk's candidate lists itself (k_shade<TAIL>); the hit lane is double-buffered like the queue
+    static const uint32_t shade_list_group = getenv("DRT_HIP_SHADE_LIST_GROUP") ? (uint32_t)std::max(1, atoi(getenv("DRT_HIP_SHADE_LIST_GROUP"))) : 3u;
+    static const bool tail_env = !(getenv("DRT_HIP_SHADE_TAIL") && atoi(getenv("DRT_HIP_SHADE_TAIL")) == 0);
+    const bool shade_tail = tail_env && ctx->has_mesh && !unbiased && !can_fuse && (ctx->prog_sorted || sizeof(R) == 8);
     int rc;
     ChainState<R> cs;
     memset(&cs, 0, sizeof cs);
@@ -528,11 +542,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         if ((rc = ensure(ctx, ctx->ray_id[i], N * sizeof(uint2))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->hit, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
+    if (shade_tail)
+        if ((rc = ensure(ctx, ctx->hit2, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
     if (ctx->has_mesh) {
         if ((rc = ensure(ctx, ctx->cand, cand_words * sizeof(uint32_t))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->cand_a, cand_words * sizeof(R4))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->cand_b, cand_words * sizeof(R4))) != DRT_OK) return rc;
-        if ((rc = ensure(ctx, ctx->cand_count, ((size_t)k2_waves + DRT_PULL_WORDS) * sizeof(uint32_t))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, ctx->cand_count, ((size_t)std::max<uint32_t>(k2_waves, max_regions) + DRT_PULL_WORDS) * sizeof(uint32_t))) != DRT_OK) return rc;
     }
     if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
     if (gimg_param >= 0)
@@ -816,28 +832,36 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 R4* sv_a = save_here && fused ? cs.cv_a : (R4*)nullptr;
                 typename Q2<R>::T* sv_b = save_here && fused ? cs.cv_b : (typename Q2<R>::T*)nullptr;
                 HitRec<R>* sv_hit = save_here && fused ? cs.cv_hit : (HitRec<R>*)nullptr;
+                // hit lane of this depth (double-buffered when the shade launch fills the next depth's itself)
+                HitRec<R>* hit_k = shade_tail && (lc & 1) ? (HitRec<R>*)ctx->hit2.p : hit;
+                HitRec<R>* hit_n = shade_tail ? ((lc & 1) ? hit : (HitRec<R>*)ctx->hit2.p) : (HitRec<R>*)nullptr;
+                const bool lists_from_shade = shade_tail && k > 0;      // (the camera rays still go through k_intersect)
                 if (!fused) {
-                    if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
-                    hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                       ra[cur], rb[cur], hit, counts + (size_t)k * max_regions, bvh,
-                                       ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
-                                       (uint32_t*)ctx->cand_count.p, cand_cap);
-                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
-                    st->launches[DRT_K_INTERSECT]++;
+                    if (!lists_from_shade) {
+                        if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
+                        hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                           ra[cur], rb[cur], hit_k, counts + (size_t)k * max_regions, bvh,
+                                           ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
+                                           (uint32_t*)ctx->cand_count.p, cand_cap);
+                        if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                        st->launches[DRT_K_INTERSECT]++;
+                    }
                     if (ctx->has_mesh) {   // continues from the analytic hit: (t, primitive) refined by the BVH walk
                         if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT_MESH)) != DRT_OK) return rc;
                         const int gm = (int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu);
+                        // lists: one per k_intersect wave, or one per queue region (half as long: handed out in pairs)
                         hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                           bvh, hit, (const uint32_t*)ctx->cand.p, (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p,
-                                           (uint32_t*)ctx->cand_count.p, cand_cap,
-                                           (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
+                                           bvh, hit_k, (const uint32_t*)ctx->cand.p, (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p,
+                                           (uint32_t*)ctx->cand_count.p, lists_from_shade ? region_size : cand_cap,
+                                           lists_from_shade ? a.n_regions : (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE),
+                                           lists_from_shade ? shade_list_group : 1u);
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT_MESH]++;
                     }
                 }
                 if (save_here && !fused)
                     hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur], rb[cur],
-                                       rid[cur], hit, counts + (size_t)k * max_regions, cs.cv_a, cs.cv_b, cs.cv_hit);
+                                       rid[cur], hit_k, counts + (size_t)k * max_regions, cs.cv_a, cs.cv_b, cs.cv_hit);
 
                 TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                 if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
@@ -847,21 +871,32 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (shade_bpc > 0 && ctx->n_cu * shade_bpc < g)
                         gs = ctx->n_cu * shade_bpc;
                     uint32_t* ck = counts + (size_t)k * max_regions;
+#define DRT_SHADE_NO_TAIL bvh, (HitRec<R>*)nullptr, (uint32_t*)nullptr, (R4*)nullptr, (R4*)nullptr, (uint32_t*)nullptr
 #define DRT_LAUNCH_SHADE(SPEC, FUSE, SEG, DBASE)                                                               \
     hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk, d_scene, \
-                       d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,      \
-                       ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit)
+                       d_params, ra[cur], rb[cur], rid[cur], hit_k, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,    \
+                       ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit, DRT_SHADE_NO_TAIL)
+#define DRT_LAUNCH_SHADE_TAIL(SPEC)                                                                                    \
+    hipLaunchKernelGGL((k_shade<R, SPEC, false, false, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,   \
+                       d_scene, d_params, ra[cur], rb[cur], rid[cur], hit_k, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,   \
+                       ck, (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit, bvh, \
+                       hit_n, (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p)
                     if (fused && camera_fused && k == 0) {
 #define DRT_LAUNCH_CAMERA(SPEC)                                                                                       \
     hipLaunchKernelGGL((k_shade<R, SPEC, true, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,         \
-                       d_scene, d_params, ra[cur], rb[cur], rid[cur], hit, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, ck, \
-                       (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit)
+                       d_scene, d_params, ra[cur], rb[cur], rid[cur], hit_k, ra[nxt], rb[nxt], rid[nxt], tape_k, nv, ck, \
+                       (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit, DRT_SHADE_NO_TAIL)
                         if (ctx->has_specular) DRT_LAUNCH_CAMERA(true);
                         else DRT_LAUNCH_CAMERA(false);
 #undef DRT_LAUNCH_CAMERA
                     } else if (fused) {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, true, 0, (const uint32_t*)nullptr);
+                    } else if (shade_tail && k + nbk < D) {
+                        // (the region lists of regions no wave visits stay empty)
+                        HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+                        if (ctx->has_specular) DRT_LAUNCH_SHADE_TAIL(true);
+                        else DRT_LAUNCH_SHADE_TAIL(false);
                     } else {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, false, 0, (const uint32_t*)nullptr);
@@ -924,6 +959,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         }
                         uint32_t* ck = counts + (size_t)k * max_regions;
                         const bool fused = can_fuse;
+                        HitRec<R>* hit_k = hit;                 // (the suffix rounds keep K2 a kernel of its own)
                         R4* sv_a = k == s && fused ? cs.nx_a : (R4*)nullptr;
                         typename Q2<R>::T* sv_b = k == s && fused ? cs.nx_b : (typename Q2<R>::T*)nullptr;
                         HitRec<R>* sv_hit = k == s && fused ? cs.nx_hit : (HitRec<R>*)nullptr;
@@ -935,7 +971,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                             if (ctx->has_mesh)
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
                                                    ctx->stream, a, d_scene, bvh, hit, (const uint32_t*)ctx->cand.p,
-                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE));
+                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE), 1u);
                             st->launches[DRT_K_INTERSECT]++;
                         }
                         if (k == s && !fused)
@@ -1109,7 +1145,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->hit2, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal, &ctx->film, &ctx->gpart, &ctx->grad,
                       &ctx->adjoint, &ctx->out};
@@ -1200,6 +1236,7 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_d, pd.data(), pd.size() * sizeof(double));
     const int n_dev_params = hf->n_params;   // user parameters + internal constants
     ctx->prog_ok = hf->prog_ok != 0;
+    ctx->prog_sorted = hf->prog_sorted != 0;
     ctx->prog_kinds = hf->prog_kinds;
     ctx->max_colour_param = -1;
     for (int i = 0; i < hf->n_materials; ++i)

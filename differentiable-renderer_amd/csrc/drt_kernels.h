@@ -37,6 +37,7 @@
 #pragma once
 
 #include "drt_device.h"
+#include "drt_prog.h"
 
 struct BatchArgs {
     // batch geometry
@@ -467,8 +468,9 @@ __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh, HitRec<R>* hit,
                  const uint32_t* __restrict__ cand, const typename Q4<R>::T* __restrict__ cand_a,
                  const typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
-                 uint32_t n_lists)
+                 uint32_t n_lists, uint32_t group)
 {
+    // (group = lists handed out per pull: 1 for k_intersect's lists, 2 for the shorter per-region lists of k_shade)
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES;
@@ -485,8 +487,9 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     // the wave's stream: whole candidate lists (k_intersect), pulled from DRT_PULL_COUNTERS device-wide counters (one
     // returning atomic per list; a single address sustains only ~88 of them per microsecond, which a single counter
     // made the floor of every launch: 0.19 ms); the current list's rays are cand[cur_base + cur_off .. cur_base + cur_cnt)
-    uint32_t cur_base = 0, cur_cnt = 0, cur_off = 0;
-    bool dry = false;                                           // no list left
+    uint32_t cur_base = 0, cur_cnt = 0, cur_off = 0, cur_list = 0, group_end = 0;
+    const uint32_t n_groups = (n_lists + group - 1) / group;
+    bool dry = false;                                           // no group of lists left
     bool home_dry = false;                                      // the wave's own counter has run out
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t home = (blockIdx.x * (DRT_BLOCK / DRT_WAVE) + threadIdx.x / DRT_WAVE) & (DRT_PULL_COUNTERS - 1);
@@ -505,17 +508,24 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             bool want = !active;
             for (;;) {
                 if (cur_off >= cur_cnt) {
+                    if (cur_list + 1 < group_end) {             // the next list of the group pulled last
+                        ++cur_list;
+                        cur_base = cur_list * cand_cap;
+                        cur_cnt = __builtin_amdgcn_readfirstlane(cand_count[cur_list]);
+                        cur_off = 0;
+                        continue;
+                    }
                     if (dry)
                         break;
-                    // next list: from the home counter while it lasts, then from whichever counter still has lists
-                    // (every lane looks at one counter; a lost race just looks again)
-                    uint32_t list = 0xFFFFFFFFu;
+                    // next group of lists: from the home counter while it lasts, then from whichever counter still has
+                    // some (every lane looks at one counter; a lost race just looks again)
+                    uint32_t grp = 0xFFFFFFFFu;
                     for (;;) {
                         uint32_t c = home;
                         if (home_dry) {
                             // (a device-scope load: another XCD's L2 must not serve a stale counter -- the loop would never end)
                             const uint32_t seen = __hip_atomic_load(ctr + lane * DRT_PULL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const uint64_t left = __ballot((uint64_t)seen * DRT_PULL_COUNTERS + lane < (uint64_t)n_lists);
+                            const uint64_t left = __ballot((uint64_t)seen * DRT_PULL_COUNTERS + lane < (uint64_t)n_groups);
                             if (left == 0)
                                 break;
                             const uint64_t rot = home ? (left >> home) | (left << (64 - home)) : left;
@@ -525,18 +535,20 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                         if (lane == 0)
                             i = atomicAdd(ctr + c * DRT_PULL_STRIDE, 1u);
                         i = __builtin_amdgcn_readfirstlane(i);
-                        if ((uint64_t)i * DRT_PULL_COUNTERS + c < (uint64_t)n_lists) {
-                            list = i * DRT_PULL_COUNTERS + c;
+                        if ((uint64_t)i * DRT_PULL_COUNTERS + c < (uint64_t)n_groups) {
+                            grp = i * DRT_PULL_COUNTERS + c;
                             break;
                         }
                         home_dry = true;
                     }
-                    if (list == 0xFFFFFFFFu) {
+                    if (grp == 0xFFFFFFFFu) {
                         dry = true;
                         break;
                     }
-                    cur_base = list * cand_cap;
-                    cur_cnt = __builtin_amdgcn_readfirstlane(cand_count[list]);
+                    cur_list = grp * group;
+                    group_end = cur_list + group < n_lists ? cur_list + group : n_lists;
+                    cur_base = cur_list * cand_cap;
+                    cur_cnt = __builtin_amdgcn_readfirstlane(cand_count[cur_list]);
                     cur_off = 0;
                     continue;
                 }
@@ -1104,7 +1116,22 @@ __device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __res
 // CAM (fused launches that start at depth 0, every path alive there): the camera ray is generated in
 // place -- K1 folded in too: nothing is read from the queue, the row of depth 0 is written here.
 // (A launch that takes every path from the eye to its end needs neither queue nor tape: that is k_path, drt_path.h.)
-template <typename R, bool SPEC, bool FUSED, bool CAM = false>
+// the analytic closest hit of k_shade's tail: the LDS program in f32 (no scalar loop: the launch stays bandwidth-bound),
+// the literal loop in the f64 verification mode
+__device__ inline HitRec<float> tail_closest_hit(const DevScene<float>* __restrict__ sc, const ProgRecs<0>& recs, float4 ra, float2 rb)
+{
+    return closest_hit_prog<0ull, 0>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
+}
+__device__ inline HitRec<double> tail_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<0>&, double4 ra, double2 rb)
+{
+    return closest_hit_packed(sc, ra, rb);
+}
+
+// TAIL (scenes with a mesh, one bounce per launch): the ray this launch PRODUCES is intersected with the analytic shapes
+// right here, while it is still in registers, and handed to the BVH walk if it reaches the mesh -- K2's analytic pass
+// (k_intersect) then only runs for the camera rays, and the queue is not read a second time (24 bytes per ray).  The
+// candidate list of a region is the region's own span of the candidate arrays; hit_next is the hit lane of the NEXT depth.
+template <typename R, bool SPEC, bool FUSED, bool CAM = false, bool TAIL = false>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
@@ -1116,7 +1143,9 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         const typename Q4<R>::T* __restrict__ tri_shade,
         int seg_start, const uint32_t* __restrict__ draw_base,
         typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
-        HitRec<R>* __restrict__ save_hit)
+        HitRec<R>* __restrict__ save_hit,
+        DevBvh<R> bvh_t, HitRec<R>* __restrict__ hit_next, uint32_t* __restrict__ cand,
+        typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count)
 {
     // nb > 1 (FUSED only): the launch takes every ray through nb bounces -- depths k .. k+nb-1 -- in
     // registers; only the survivors of the LAST one are compacted and written back.  Lanes whose
@@ -1127,7 +1156,19 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     __shared__ SceneLds<R> lds;
-    stage_scene(lds, sc, params);
+    __shared__ ProgLds s_prog;                  // TAIL, f32: the kind-sorted intersection program of the analytic shapes
+    ProgRecs<0> recs;
+    recs.lds = &s_prog;
+    if (TAIL && sizeof(R) == 4) {
+        const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
+        if (threadIdx.x < DRT_PROG_MAX) {
+            s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
+            s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
+        }
+        if (threadIdx.x < 8)
+            s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
+    }
+    stage_scene(lds, sc, params);               // (ends with a barrier)
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
@@ -1135,11 +1176,13 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
     uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
+    if (TAIL && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)     // the walk's list counters (it runs after this kernel)
+        pull_counters(cand_count, a.n_regions)[threadIdx.x * DRT_PULL_STRIDE] = 0;
     uint32_t cnt;
     uint32_t w = next_region<CAM>(a, counts_k, grid_wave(), n_waves, cnt);
     if (w >= a.n_regions)
         return;
-    uint32_t off = 0, running = 0;
+    uint32_t off = 0, running = 0, cand_running = 0;
     ShadeIn<R> cur, nxt;
     bool have = lane < cnt;
     if (!CAM)
@@ -1267,6 +1310,33 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
             next_b[ns] = nb2;
             next_id[ns] = cur.rid;
         }
+        if (TAIL) {
+            bool reach = false;
+            HitRec<R> hn;
+            hn.t = (R)INFINITY;
+            hn.prim = -1;
+            if (alive) {
+                hn = tail_closest_hit(sc, recs, na, nb2);
+                hit_next[ns] = hn;
+                const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb2.x, nb2.y);
+                const V3<R> inv2 = mk<R>(R(1) / d2.x, R(1) / d2.y, R(1) / d2.z);
+                R tn;
+                reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
+            }
+            uint32_t n_reach;
+            const uint32_t rk = wave_rank(reach, n_reach);
+            if (reach) {
+                const size_t at = ((size_t)w << a.region_shift) + cand_running + rk;
+                const uint32_t flat = hn.prim >= 0 ? (uint32_t)sc->flat[hn.prim] : 0xFFFFFFFFu;
+                R4 ca, cb;
+                ca.x = na.x; ca.y = na.y; ca.z = na.z; ca.w = hn.t;
+                cb.x = na.w; cb.y = nb2.x; cb.z = nb2.y; cb.w = pid_pack(R(0), flat);
+                cand[at] = ns;
+                cand_a[at] = ca;
+                cand_b[at] = cb;
+            }
+            cand_running += n_reach;
+        }
         running += n_alive;
         if (nw != w) {                                         // region finished
             if (lane == 0) {
@@ -1274,8 +1344,11 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                     counts_next[w] = running;
                 if (CAM)
                     counts_k[w] = cnt;                         // depth 0: every path of the region
+                if (TAIL)
+                    cand_count[w] = cand_running;
             }
             running = 0;
+            cand_running = 0;
         }
         if (!more)
             break;

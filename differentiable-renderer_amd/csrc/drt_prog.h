@@ -1,0 +1,111 @@
+// drt_prog.h -- the f32 "intersection program" of the analytic shapes: one record per shape with a KIND (general plane,
+// axis plane, sphere), tested either from scalar registers with the kinds compiled in (k_path on the reference's own
+// scene) or from a kind-sorted copy in LDS (any other scene; also k_shade's tail in scenes with a mesh, where the
+// program covers the analytic shapes and the mesh records are left out).  Built by drt_hip_upload_scene (fill_scene).
+#pragma once
+
+#include "drt_device.h"
+
+// ---- the intersection program (f32) ----------------------------------------------------------------
+__device__ inline void prog_accept(float t, int s, float& tmin, int& prim)
+{
+    if (t > 0.f && !(t >= tmin)) {          // shape.hpp:55 / pathtracer.hpp:80: first shape wins ties
+        tmin = t;
+        prim = s;
+    }
+}
+
+template <int KIND>
+__device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float& tmin, int& prim)
+{
+    if (KIND == DRT_PK_AX) {
+        prog_accept((r.x - o.x) * inv_d.x, s, tmin, prim);
+    } else if (KIND == DRT_PK_AY) {
+        prog_accept((r.x - o.y) * inv_d.y, s, tmin, prim);
+    } else if (KIND == DRT_PK_AZ) {
+        prog_accept((r.x - o.z) * inv_d.z, s, tmin, prim);
+    } else if (KIND == DRT_PK_PLANE) {
+        const float h = o.x * r.x + o.y * r.y + o.z * r.z - r.w;
+        const float den = d.x * r.x + d.y * r.y + d.z * r.z;
+        prog_accept(h * __builtin_amdgcn_rcpf(-den), s, tmin, prim);
+    } else {                                 // sphere: b' = oc.d, disc' = b'^2 - (oc.oc - r^2), t = -b' -+ sqrt(disc')
+        const V3<float> oc = mk<float>(o.x - r.x, o.y - r.y, o.z - r.z);
+        const float bh = dot(oc, d);
+        const float cc = dot(oc, oc) - r.w * r.w;
+        const float disc = bh * bh - cc;
+        if (disc >= 0.f) {                   // (NaN fails, as in the reference; the branch-free form -- sqrt of a negative
+                                             // = NaN, which fails `t > 0` -- was measured 4 % slower)
+            const float sq = __builtin_amdgcn_sqrtf(disc);
+            const float t1 = -bh - sq, t2 = sq - bh;
+            prog_accept(t1 > 0.f ? t1 : t2, s, tmin, prim);
+        }
+    }
+}
+
+// The records of the program, as the bounce loop sees them.  SIG != 0 (kinds fixed at compile time, 3 bits per shape,
+// NSIG shapes): the NSIG records are loaded ONCE per wave, before the sample loop, and stay in scalar registers --
+// the loop body then contains no scalar load, no wait and no branch for the scene at all.  SIG == 0: kinds and
+// records are read from the scene inside the loop (uniform branches on the kind mask; scalar loads).
+struct ProgLds {               // the kind-sorted program in LDS (scenes whose kinds are not compiled in)
+    float4 rec[DRT_PROG_MAX];
+    int shape[DRT_PROG_MAX];
+    int kind_begin[8];
+};
+
+template <int NSIG>
+struct ProgRecs {
+    float4 r[NSIG > 0 ? NSIG : 1];
+    const ProgLds* lds;
+    __device__ inline void load(const DevScene<float>* __restrict__ sc)
+    {
+#pragma unroll
+        for (int s = 0; s < NSIG; ++s)
+            r[s] = *reinterpret_cast<const float4*>(sc->prog[s]);
+    }
+};
+
+template <unsigned long long SIG, int NSIG>
+__device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs,
+                                                 V3<float> o, V3<float> d)
+{
+    const V3<float> inv_d = mk<float>(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    float tmin = INFINITY;
+    int prim = -1;
+    if (NSIG > 0) {
+#pragma unroll
+        for (int s = 0; s < NSIG; ++s) {
+            constexpr unsigned long long sig = SIG;
+            const int kind = (int)((sig >> (3 * s)) & 7ull);
+            const float4 r = recs.r[s];
+            if (kind == DRT_PK_AX) prog_test<DRT_PK_AX>(r, s, o, d, inv_d, tmin, prim);
+            else if (kind == DRT_PK_AY) prog_test<DRT_PK_AY>(r, s, o, d, inv_d, tmin, prim);
+            else if (kind == DRT_PK_AZ) prog_test<DRT_PK_AZ>(r, s, o, d, inv_d, tmin, prim);
+            else if (kind == DRT_PK_PLANE) prog_test<DRT_PK_PLANE>(r, s, o, d, inv_d, tmin, prim);
+            else prog_test<DRT_PK_SPHERE>(r, s, o, d, inv_d, tmin, prim);
+        }
+    } else {
+        // kinds not compiled in: the records sorted by kind (upload), one counted loop per kind -- no branch on the kind,
+        // no scalar load: every lane reads the SAME record from LDS (a broadcast read), the next record is requested
+        // while the current one is tested.  Inside a kind the scene order is kept, so the first shape wins ties
+        // (pathtracer.hpp:80); an exact tie between shapes of DIFFERENT kinds goes to the kind tested first (planes
+        // before spheres) -- t values from two different formulas agreeing in all 32 bits; the f64 mode keeps the
+        // literal loop.
+        const ProgLds& pl = *recs.lds;
+#define DRT_KIND_LOOP(K)                                                              \
+        for (int i = pl.kind_begin[K]; i < pl.kind_begin[K + 1]; ++i) {               \
+            const float4 r = pl.rec[i];                                               \
+            prog_test<K>(r, pl.shape[i], o, d, inv_d, tmin, prim);                    \
+        }
+        DRT_KIND_LOOP(DRT_PK_AX)
+        DRT_KIND_LOOP(DRT_PK_AY)
+        DRT_KIND_LOOP(DRT_PK_AZ)
+        DRT_KIND_LOOP(DRT_PK_PLANE)
+        DRT_KIND_LOOP(DRT_PK_SPHERE)
+#undef DRT_KIND_LOOP
+    }
+    HitRec<float> h;
+    h.t = tmin;
+    h.prim = prim;
+    return h;
+}
+
