@@ -390,6 +390,18 @@ int k2_mesh_grid(const drt_hip_ctx* ctx, uint64_t n_paths)
     return (int)blocks;
 }
 
+// a multiplier coprime to n (the walk's pull order is a multiplicative permutation of its list groups)
+uint32_t coprime_multiplier(uint32_t n)
+{
+    if (n <= 2)
+        return 1;
+    uint32_t m = (uint32_t)(2654435761ull % n);
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+    while (m < 2 || gcd(m, n) != 1)
+        m = m + 1 < n ? m + 1 : 2;
+    return m;
+}
+
 int grid_for(const drt_hip_ctx* ctx, uint64_t work)
 {
     uint64_t blocks = (work + DRT_BLOCK - 1) / DRT_BLOCK;
@@ -523,7 +535,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     const size_t cand_words = (((size_t)max_regions << (region_shift - 6)) + k2_waves) * DRT_WAVE;   // (>= max_regions * region_size)
     // scenes with a mesh: the shade launch intersects the ray it produces with the analytic shapes and builds the BVH
     // walk's candidate lists itself (k_shade<TAIL>); the hit lane is double-buffered like the queue
-    static const uint32_t shade_list_group = getenv("DRT_HIP_SHADE_LIST_GROUP") ? (uint32_t)std::max(1, atoi(getenv("DRT_HIP_SHADE_LIST_GROUP"))) : 3u;
+    static const uint32_t shade_list_group = getenv("DRT_HIP_SHADE_LIST_GROUP") ? (uint32_t)std::max(1, atoi(getenv("DRT_HIP_SHADE_LIST_GROUP"))) : 4u;
     static const bool tail_env = !(getenv("DRT_HIP_SHADE_TAIL") && atoi(getenv("DRT_HIP_SHADE_TAIL")) == 0);
     const bool shade_tail = tail_env && ctx->has_mesh && !unbiased && !can_fuse && (ctx->prog_sorted || sizeof(R) == 8);
     int rc;
@@ -849,12 +861,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (ctx->has_mesh) {   // continues from the analytic hit: (t, primitive) refined by the BVH walk
                         if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT_MESH)) != DRT_OK) return rc;
                         const int gm = (int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu);
-                        // lists: one per k_intersect wave, or one per queue region (half as long: handed out in pairs)
+                        // lists: one per k_intersect wave, or one per queue region (half as long: handed out four at a time)
+                        const uint32_t walk_lists = lists_from_shade ? a.n_regions : (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE);
+                        const uint32_t walk_group = lists_from_shade ? shade_list_group : 1u;
                         hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                            bvh, hit_k, (const uint32_t*)ctx->cand.p, (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p,
                                            (uint32_t*)ctx->cand_count.p, lists_from_shade ? region_size : cand_cap,
-                                           lists_from_shade ? a.n_regions : (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE),
-                                           lists_from_shade ? shade_list_group : 1u);
+                                           walk_lists, walk_group, coprime_multiplier((walk_lists + walk_group - 1) / walk_group));
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT_MESH]++;
                     }
@@ -971,7 +984,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                             if (ctx->has_mesh)
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
                                                    ctx->stream, a, d_scene, bvh, hit, (const uint32_t*)ctx->cand.p,
-                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE), 1u);
+                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE), 1u,
+                                                   coprime_multiplier((uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE)));
                             st->launches[DRT_K_INTERSECT]++;
                         }
                         if (k == s && !fused)

@@ -468,9 +468,13 @@ __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh, HitRec<R>* hit,
                  const uint32_t* __restrict__ cand, const typename Q4<R>::T* __restrict__ cand_a,
                  const typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
-                 uint32_t n_lists, uint32_t group)
+                 uint32_t n_lists, uint32_t group, uint32_t perm_mul)
 {
-    // (group = lists handed out per pull: 1 for k_intersect's lists, 2 for the shorter per-region lists of k_shade)
+    // (group = lists handed out per pull: 1 for k_intersect's lists, 4 for the shorter per-region lists of k_shade.
+    //  perm_mul, coprime to the number of groups: pull number n is group (n * perm_mul) mod n_groups -- consecutive pulls
+    //  of a counter land all over the frame.  Handed out in order, counter c's groups are the regions c, c + 64, ...:
+    //  with two regions per image row that is the same eight ROWS for every sample, and the counters whose rows cross
+    //  the mesh hold most of the work.)
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES;
@@ -545,6 +549,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                         dry = true;
                         break;
                     }
+                    grp = (uint32_t)(((uint64_t)grp * perm_mul) % n_groups);
                     cur_list = grp * group;
                     group_end = cur_list + group < n_lists ? cur_list + group : n_lists;
                     cur_base = cur_list * cand_cap;
