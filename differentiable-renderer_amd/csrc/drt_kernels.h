@@ -1324,7 +1324,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                 hn = tail_closest_hit(sc, recs, na, nb2);
                 hit_next[ns] = hn;
                 const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb2.x, nb2.y);
-                const V3<R> inv2 = mk<R>(R(1) / d2.x, R(1) / d2.y, R(1) / d2.z);
+                const V3<R> inv2 = mk<R>(div_r(R(1), d2.x), div_r(R(1), d2.y), div_r(R(1), d2.z));   // (f32: v_rcp; the bounds are padded)
                 R tn;
                 reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
             }
