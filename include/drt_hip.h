@@ -156,7 +156,10 @@ typedef struct drt_render_params {
     int32_t bounces_per_launch; /* scenes of analytic shapes: bounces a shade launch takes a ray through in
                                registers before survivors are compacted back into the queue (1 = the
                                classic one-launch-per-bounce wavefront, HBM-bound; up to 8). <= 0 = automatic:
-                               as many as most rays are expected to survive. Results do not depend on it. */
+                               analytic scenes with at most 8 parameters take the whole path in ONE launch, in
+                               registers (k_path, DRT_K_PATH: same samples, sums in another order -- equal to f32
+                               rounding); otherwise as many bounces per launch as most rays are expected to survive.
+                               Values >= 1 give bitwise identical results among themselves. */
     int32_t reserved;
 } drt_render_params;
 
