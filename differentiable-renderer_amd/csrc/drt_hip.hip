@@ -466,19 +466,22 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     static const int regen_env = getenv("DRT_HIP_PATH_REGEN") ? atoi(getenv("DRT_HIP_PATH_REGEN")) : -1;
     bool path_regen = regen_env > 0;
     if (use_path && regen_env < 0) {
-        // lockstep: a wave runs until the longest of its 64 paths ends (~ the depth where 1 path in 64 is left);
-        // regenerating: every lane runs the mean path length, at ~1.4 x the cost per bounce (measured on config 3,
-        // where both apply: 1.20 against 0.88 ms) -- ~2.1 x with glossy surfaces, whose regenerating kernel needs
-        // 139 registers, 3 waves per SIMD (config 5's scene at depth 16: 5.70 against 4.37 ms)
+        // lockstep: a wave runs until the longest of its 64 paths ends -- the depth cap for fixed-depth renders, under the
+        // roulette about the depth that 1 path in 256 reaches; regenerating: every lane runs the mean path length, at
+        // ~1.7 x the cost per bounce (per-lane depth bookkeeping, 126-139 registers) + the camera code inside the loop.
+        // Calibrated on the reference's scene at 512 x 512 x 64 (ms, lockstep / regenerating): depth 8 0.88 / 1.20,
+        // 12: 1.26 / 1.81, 16: 1.62 / 2.33, 24: 2.35 / 3.29; -b 6 -p 0.1: 4.04 / 2.65, -b 2 -p 0.05: 5.57 / 3.37,
+        // -b 3 -p 0.2: 2.41 / 1.47, -b 1 -p 0.5: 0.87 / 0.50; glossy, depth 16: 4.37 / 5.70.  In a closed room ~2.5 % of the
+        // paths end per bounce on the light (measured mean lengths 7.3, 10.5, 13.3 at depths 8, 12, 16).
         double alive = 1.0, mean_len = 0.0;
         int longest = D;
         for (int k = 0; k < D; ++k) {
             mean_len += alive;
-            alive *= 0.93 * ((k + 1) >= rp->min_bounces ? 1.0 - rp->absorb : 1.0);
-            if (alive < 1.0 / 64 && longest == D)
+            alive *= 0.975 * ((k + 1) >= rp->min_bounces ? 1.0 - rp->absorb : 1.0);
+            if (alive < 1.0 / 256 && longest == D)
                 longest = k + 1;
         }
-        path_regen = (ctx->has_specular ? 2.1 : 1.4) * mean_len < (double)longest;
+        path_regen = 1.7 * mean_len + 0.5 < (double)longest;
     }
     uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
     if (use_path && rp->batch_paths <= 0)
