@@ -16,7 +16,8 @@
 #define DRT_ID_NONE 0xFFFFu
 #define DRT_BLOCK 256
 #define DRT_WAVE 64
-#define DRT_PROG_MAX 16          // shapes k_path's unrolled intersection program covers
+#define DRT_PROG_MAX 16          // shapes whose kinds fit the 64-bit signature (3 bits each; k_path's compiled-in program)
+#define DRT_PROG_SORTED_MAX DRT_MAX_SHAPES   // shapes the kind-sorted program in LDS covers (every analytic scene the ABI takes)
 enum { DRT_PK_PLANE = 0, DRT_PK_SPHERE = 1, DRT_PK_AX = 2, DRT_PK_AY = 3, DRT_PK_AZ = 4 };
 
 // ---- scene records (one instance per compute type, built by drt_hip_upload_scene) ----------
@@ -46,14 +47,14 @@ struct DevScene {
     unsigned long long item_pair, item_sphere, item_skip;   // skip: a mesh record (one shape index, no test)
     R items[DRT_MAX_SHAPES][8];
     // k_path's intersection program (drt_path.h): one record per shape, scene order, 3 kind bits per shape;
-    // prog_ok = the scene has at most DRT_PROG_MAX shapes and no mesh
+    // prog_ok = the scene has no mesh (k_path applies); prog / prog_kinds cover the first DRT_PROG_MAX shapes only
     unsigned long long prog_kinds;
     int prog_ok, prog_sorted;     // prog_sorted: the kind-sorted copy below is valid for the ANALYTIC shapes (mesh records left out)
     R prog[DRT_PROG_MAX][4];
     // the same records SORTED BY KIND (scene order kept inside a kind) for scenes whose kinds are not compiled in:
     // sorted[i] = (record.xyzw), sorted_shape[i] = its shape index, kind k occupies [kind_begin[k], kind_begin[k + 1])
-    R sorted[DRT_PROG_MAX][4];
-    int sorted_shape[DRT_PROG_MAX];
+    R sorted[DRT_PROG_SORTED_MAX][4];
+    int sorted_shape[DRT_PROG_SORTED_MAX];
     int kind_begin[8];
     int flat[DRT_MAX_SHAPES];   // position of shape s in the flattened scene (a mesh counts once per
                                 // triangle): the order that breaks exact ties, pathtracer.hpp:80

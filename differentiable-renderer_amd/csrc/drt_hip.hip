@@ -294,46 +294,51 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     for (int i = 0; i < s->n_emitters; ++i)
         ds.emitter_param[i] = s->emitters[i].param;
     // k_path (drt_path.h): the parameter ids of every shape in one word, and the intersection program
-    ds.prog_ok = s->n_shapes <= DRT_PROG_MAX ? 1 : 0;
+    ds.prog_ok = 1;
     bool has_mesh_shape = false;
+    int kinds[DRT_MAX_SHAPES];
+    R recs[DRT_MAX_SHAPES][4];
     for (int i = 0; i < s->n_shapes; ++i) {
         const int m = s->shapes[i].material, e = s->shapes[i].emitter;
         const uint32_t cid = m >= 0 ? (uint32_t)ds.materials[m].param : DRT_ID_NONE;
         const uint32_t eid = e >= 0 ? (uint32_t)s->emitters[e].param : DRT_ID_NONE;
         ds.shapes[i].pad = (int)(cid | (eid << 16));
+        kinds[i] = 7;                           // (a mesh record: belongs to no kind loop -- k_path does not walk meshes,
+        recs[i][0] = recs[i][1] = recs[i][2] = recs[i][3] = R(0);   //  k_shade's tail tests the analytic rest)
         if (s->shapes[i].type == DRT_SHAPE_MESH) {
-            has_mesh_shape = true;              // (k_path does not walk meshes; the program simply leaves the record out:
-            if (i < DRT_PROG_MAX)               //  kind 7 belongs to no kind loop -- k_shade's tail tests the analytic rest)
-                ds.prog_kinds |= 7ull << (3 * i);
-            continue;
-        }
-        if (!ds.prog_ok || i >= DRT_PROG_MAX)
-            continue;
-        int kind = s->shapes[i].type == DRT_SHAPE_SPHERE ? DRT_PK_SPHERE : DRT_PK_PLANE;
-        R rec[4] = {(R)s->shapes[i].p[0], (R)s->shapes[i].p[1], (R)s->shapes[i].p[2], (R)s->shapes[i].p[3]};
-        if (kind == DRT_PK_PLANE) {
-            // n = +-e_a exactly: t = (sgn off - o_a) * rcp(d_a), bit-identical to the general form (drt_path.h)
-            int axis = -1, nonzero = 0;
-            for (int a = 0; a < 3; ++a)
-                if (rec[a] != R(0)) { ++nonzero; axis = a; }
-            if (nonzero == 1 && (rec[axis] == R(1) || rec[axis] == R(-1))) {
-                kind = DRT_PK_AX + axis;
-                rec[0] = rec[axis] * rec[3];
-                rec[1] = rec[2] = rec[3] = R(0);
+            has_mesh_shape = true;
+        } else {
+            int kind = s->shapes[i].type == DRT_SHAPE_SPHERE ? DRT_PK_SPHERE : DRT_PK_PLANE;
+            R rec[4] = {(R)s->shapes[i].p[0], (R)s->shapes[i].p[1], (R)s->shapes[i].p[2], (R)s->shapes[i].p[3]};
+            if (kind == DRT_PK_PLANE) {
+                // n = +-e_a exactly: t = (sgn off - o_a) * rcp(d_a), bit-identical to the general form (drt_path.h)
+                int axis = -1, nonzero = 0;
+                for (int a = 0; a < 3; ++a)
+                    if (rec[a] != R(0)) { ++nonzero; axis = a; }
+                if (nonzero == 1 && (rec[axis] == R(1) || rec[axis] == R(-1))) {
+                    kind = DRT_PK_AX + axis;
+                    rec[0] = rec[axis] * rec[3];
+                    rec[1] = rec[2] = rec[3] = R(0);
+                }
             }
+            kinds[i] = kind;
+            for (int j = 0; j < 4; ++j)
+                recs[i][j] = rec[j];
         }
-        ds.prog_kinds |= (unsigned long long)kind << (3 * i);
-        for (int j = 0; j < 4; ++j)
-            ds.prog[i][j] = rec[j];
+        if (i < DRT_PROG_MAX) {                 // the signature of the first 16 shapes (k_path's compiled-in program)
+            ds.prog_kinds |= (unsigned long long)kinds[i] << (3 * i);
+            for (int j = 0; j < 4; ++j)
+                ds.prog[i][j] = recs[i][j];
+        }
     }
-    if (ds.prog_ok) {                       // the kind-sorted copy (stable: scene order inside a kind)
+    {   // the kind-sorted copy (stable: scene order inside a kind)
         int n = 0;
         for (int k = 0; k < 5; ++k) {
             ds.kind_begin[k] = n;
             for (int i = 0; i < s->n_shapes; ++i)
-                if ((int)((ds.prog_kinds >> (3 * i)) & 7ull) == k) {
+                if (kinds[i] == k) {
                     for (int j = 0; j < 4; ++j)
-                        ds.sorted[n][j] = ds.prog[i][j];
+                        ds.sorted[n][j] = recs[i][j];
                     ds.sorted_shape[n++] = i;
                 }
         }

@@ -1166,7 +1166,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     recs.lds = &s_prog;
     if (TAIL && sizeof(R) == 4) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
-        if (threadIdx.x < DRT_PROG_MAX) {
+        if (threadIdx.x < DRT_PROG_SORTED_MAX) {
             s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
             s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
         }

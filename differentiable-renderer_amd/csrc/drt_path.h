@@ -284,7 +284,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         recs.load(reinterpret_cast<const DevScene<float>*>(sc));
     if (sizeof(R) == 4 && NSIG == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
-        if (threadIdx.x < DRT_PROG_MAX) {
+        if (threadIdx.x < DRT_PROG_SORTED_MAX) {
             s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
             s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
         }

@@ -47,8 +47,8 @@ __device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d
 // the loop body then contains no scalar load, no wait and no branch for the scene at all.  SIG == 0: kinds and
 // records are read from the scene inside the loop (uniform branches on the kind mask; scalar loads).
 struct ProgLds {               // the kind-sorted program in LDS (scenes whose kinds are not compiled in)
-    float4 rec[DRT_PROG_MAX];
-    int shape[DRT_PROG_MAX];
+    float4 rec[DRT_PROG_SORTED_MAX];
+    int shape[DRT_PROG_SORTED_MAX];
     int kind_begin[8];
 };
 

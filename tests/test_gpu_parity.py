@@ -606,6 +606,25 @@ def test_path_kernel_corner_cases(pkg, hip, oracle):
     assert bst["kernels"]["path"]["launches"] == 0 and grad_rel_err(g, bref["grads"]) < 1e-9
 
 
+def test_path_kernel_scene_with_many_shapes(pkg, hip, oracle):
+    """k_path's kind-sorted LDS program covers every analytic scene the ABI takes (64 shapes), not only the 16 whose
+    kinds fit the compiled-in signature: 31 shapes (24 random spheres, 6 walls, a light), glossy materials, roulette."""
+    scene = pkg.random_scene(11, n_spheres=24)
+    assert len(scene.shapes) == 31 and scene.n_params <= 8
+    cam = pkg.Camera(72, 48).look_at((0.1, 0.0, -0.2), (0, 0.2, 1))
+    hip.upload_scene(scene)
+    for b, p in ((5, 1.0), (2, 0.3)):
+        rp = pkg.RenderParams(spp=5, min_bounces=b, absorb=p, seed=23)
+        ref = oracle.render(scene, cam, rp, backward=True)
+        img, g, st = hip.render(cam, rp, backward=True, f64=True)
+        assert st["kernels"]["path"]["launches"] == 1 and st["segments"] == ref["stats"]["segments"]
+        assert grad_rel_err(g, ref["grads"]) < 1e-9
+        np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+        img32, g32, st32 = hip.render(cam, rp, backward=True)
+        assert st32["kernels"]["path"]["launches"] == 1
+        check_f32(img32, g32, st32["segments"], ref["image"], ref["grads"], ref["stats"]["segments"], heavy_tailed=True)
+
+
 def test_eight_parameters_every_walls_albedo(pkg, hip, oracle):
     """The reference's scene with an albedo parameter per wall (8 parameters): k_path carries eight tangents; against
     the oracle in both modes, and the gradient of the shared parameters equals the 4-parameter scene's where the
