@@ -465,12 +465,15 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     // min_bounces on -- and the regenerating form (a lane whose path ended starts its next sample at once) otherwise:
     // roulette-terminated paths under the default cap of 64, the reference's own defaults (-b 1 -p 0.5).
     static const int path_env = getenv("DRT_HIP_PATH") ? atoi(getenv("DRT_HIP_PATH")) : 1;
-    bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && !unbiased && D > 0 &&
+    static const bool path_unb_env = !(getenv("DRT_HIP_PATH_UNBIASED") && atoi(getenv("DRT_HIP_PATH_UNBIASED")) == 0);
+    bool use_path = path_env > 0 && can_fuse && ctx->prog_ok && (!unbiased || path_unb_env) && D > 0 &&
                     (!(backward || gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) && rp->bounces_per_launch <= 0 && shade_nb_env <= 0 &&
                     !getenv("DRT_HIP_DUMP_PATH");
     static const int regen_env = getenv("DRT_HIP_PATH_REGEN") ? atoi(getenv("DRT_HIP_PATH_REGEN")) : -1;
     bool path_regen = regen_env > 0;
-    if (use_path && regen_env < 0) {
+    if (unbiased)
+        path_regen = false;                    // (k_path_unbiased walks its samples in lockstep)
+    if (use_path && regen_env < 0 && !unbiased) {
         // lockstep: a wave runs until the longest of its 64 paths ends -- the depth cap for fixed-depth renders, under the
         // roulette about the depth that 1 path in 256 reaches; regenerating: every lane runs the mean path length, at
         // ~1.7 x the cost per bounce (per-lane depth bookkeeping, 126-139 registers) + the camera code inside the loop.
@@ -750,7 +753,20 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
                 const bool three = ctx->max_colour_param < 3;
                 const bool tangents = backward || gimg_param >= 0;
-                if (tangents && ctx->n_params > 4) {        // 5 .. 8 parameters: 24 tangent + 24 gradient registers per lane
+                if (unbiased) {                             // the unbiased operator: fresh suffix paths per vertex, in registers
+#define DRT_LAUNCH_UNB(SPEC, NP)                                                                                              \
+    do {                                                                                                                      \
+        if (cornell_sig)                                                                                                      \
+            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, DRT_SIG_CORNELL, DRT_NSIG_CORNELL>), dim3(gpath), dim3(DRT_BLOCK), 0, \
+                               ctx->stream, pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                   \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, 0ull, 0>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, pa,      \
+                               d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                                    \
+    } while (0)
+                    if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }
+                    else { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 4); else DRT_LAUNCH_UNB(false, 4); }
+#undef DRT_LAUNCH_UNB
+                } else if (tangents && ctx->n_params > 4) {        // 5 .. 8 parameters: 24 tangent + 24 gradient registers per lane
                     if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 8, 8);
                     else DRT_LAUNCH_PATH_SIG(false, 8, 8);
                 } else if (tangents) {

@@ -129,12 +129,21 @@ struct CameraLane {            // per-lane camera constants (the lane's pixel do
 // T/dT moved on iff `alive`; `on_light` = the path ended on a light without BxDF (pathtracer.hpp:38-39: f = 0) whose
 // emission parameter is `light` -- the caller adds that emission (the fixed-depth kernel once per sample, after its
 // bounce loop, for all lanes together; the regenerating kernel when the lane's path ends).
+// what the unbiased backward needs to know about a vertex (it re-samples a fresh direction there)
+template <typename R>
+struct PathVertex {
+    V3<R> P, nrm, d;           // point, normal, direction of the ray that arrived
+    uint32_t ids;              // colour | emission << 16 parameter ids
+    int material;              // index of the BxDF's material record (valid when scattered)
+    bool hit, scattered;       // the ray hit something / something with a BxDF
+};
+
 template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG>
 __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
                                    const R* __restrict__ params, const ProgRecs<(sizeof(R) == 4 ? NSIG : 0)>& recs, uint32_t key,
                                    R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
                                    typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
-                                   bool& alive, bool& capped, bool& on_light, uint32_t& light)
+                                   bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr)
 {
     const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
     const bool hit = live && h.prim >= 0;
@@ -153,6 +162,13 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     // emission, pathtracer.hpp:113-114: a shape with BxDF AND emitter (rare) adds it here, a pure light is the caller's
     on_light = emits && !has_bxdf;
     light = eid;
+    if (vo) {
+        vo->P = P; vo->nrm = nrm; vo->d = d;
+        vo->ids = ids;
+        vo->material = sh.material;
+        vo->hit = hit;
+        vo->scattered = hit && has_bxdf;
+    }
     if (__any(emits && has_bxdf)) {
         if (emits && has_bxdf)
             add_emission<R, NP, NC>(lds, params, eid, inv_pk, T, g, L, tg);
@@ -434,6 +450,236 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
 #pragma unroll
         for (int r = 0; r < NP * 3; ++r) {
             const V3<R> v3 = tg.acc[r / 3];
+            double v = (double)(r % 3 == 0 ? v3.x : (r % 3 == 1 ? v3.y : v3.z));
+#pragma unroll
+            for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)
+                v += __shfl_down(v, o2);
+            if (lane == 0)
+                s_red[wv][r] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < DRT_FAST_PARAMS * 3) {
+            double v = 0;
+            if ((int)threadIdx.x < NP * 3)
+                for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
+                    v += s_red[ww][threadIdx.x];
+            gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
+        }
+    }
+}
+
+// ---- the unbiased integration operator (integrate.hpp:11-24, 39-52; README.md:104-136) in one launch ------------------
+// The reference's IntegrateBackward does not reuse the forward samples: where a gradient arrives at a vertex it draws a
+// FRESH direction, evaluates forward(sample) -- a whole new suffix path -- back-propagates grad / pdf through
+// brdf * radiance * cos, and the recursion continues down the NEW path (O(depth^2) segments per camera sample).  Like
+// k_path, a lane is a pixel and everything lives in registers:
+//   forward walk from the eye (radiance -> the image; its first vertex starts the chain), then per chain vertex:
+//   emission gradient, fresh direction, suffix walk (radiance L'), colour gradient += L' * g / pdf * cos * bs,
+//   g *= f * cos / pdf, and the suffix's first vertex is the next chain vertex.
+// All draws of a path come from ONE stream in the order the reference consumes them (a counter per lane): camera 2,
+// then per vertex [roulette of its depth] theta phi -- including the roulette draw the reference spends AFTER a light
+// without BxDF (its zero-direction continuation is traced "faithfully" before it misses; oracle/ref_harness.cpp).
+// One walk = the bounce of k_path (path_bounce, forward-only) iterated while any lane of the wave still traces.
+template <typename R, bool SPEC, unsigned long long SIG, int NSIG>
+__device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
+                                     const R* __restrict__ params, const ProgRecs<(sizeof(R) == 4 ? NSIG : 0)>& recs, uint32_t key,
+                                     R pk_rr, R inv_p_rr, bool live, typename Q4<R>::T ra, typename Q2<R>::T rb, int kk,
+                                     uint32_t& nd, uint32_t& n_seg, uint32_t& n_capped, V3<R>& L, PathVertex<R>& first, bool& any_vertex)
+{
+    V3<R> T = mk<R>(R(1), R(1), R(1));
+    L = mk<R>(R(0), R(0), R(0));
+    any_vertex = false;
+    Tangents<R, 0, 0> none;
+    const V3<R> g1 = mk<R>(R(1), R(1), R(1));
+    for (;;) {
+        const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+        if (n_live == 0)
+            break;
+        n_seg += n_live;
+        const bool rr_here = kk >= a.min_bounces;
+        const R pk = rr_here ? pk_rr : R(1), inv_pk = rr_here ? inv_p_rr : R(1);
+        const bool next_rr = (kk + 1) >= a.min_bounces, next_cap = (kk + 1) >= a.depth_cap;
+        bool alive, capped, on_light;
+        uint32_t light;
+        PathVertex<R> v;
+        path_bounce<R, SPEC, 0, 0, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, nd, next_rr, next_cap, live, g1, ra, rb, T, L,
+                                              none, alive, capped, on_light, light, &v);
+        // the roulette of the next depth is drawn unless a user cap ends the path first (pathtracer.hpp:128 behind the cap test)
+        const uint32_t rr_drawn = (next_rr && (!next_cap || a.cap_is_roulette)) ? 1u : 0u;
+        if (live) {
+            if (!any_vertex && v.hit) {
+                first = v;
+                any_vertex = true;
+            }
+            nd += v.scattered ? 2u + rr_drawn : (v.hit ? rr_drawn : 0u);
+        }
+        if (__any(live && on_light)) {
+            if (live && on_light)
+                add_emission<R, 0, 0>(lds, params, light, inv_pk, T, g1, L, none);
+        }
+        if (!a.cap_is_roulette)
+            n_capped += (uint32_t)__popcll(__ballot(live && capped));
+        live = alive;
+        ++kk;
+    }
+}
+
+template <typename R, bool SPEC, int NP, unsigned long long SIG, int NSIG>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
+                double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
+                unsigned long long* __restrict__ total)
+{
+    if (total && blockIdx.x == 0 && threadIdx.x < 4)
+        total[threadIdx.x] = 0;
+    typedef typename Q4<R>::T R4;
+    typedef typename Q2<R>::T R2;
+    __shared__ SceneLds<R> lds;
+    __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+    stage_scene(lds, sc, params);
+
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t w = grid_wave();
+    const uint32_t range = w / a.n_groups, group = w - range * a.n_groups;
+    const uint32_t lp = group * DRT_WAVE + lane;
+    const bool have = range < a.n_ranges && lp < a.Pb;
+    const uint32_t s_begin = range * a.spr;
+    const uint32_t s_end = s_begin + a.spr < a.Sb ? s_begin + a.spr : a.Sb;
+
+    V3<R> acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        acc[p] = mk<R>(R(0), R(0), R(0));
+    double fx = 0, fy = 0, fz = 0;
+    uint32_t n_seg = 0, n_capped = 0;
+    uint32_t gpix = 0, px = 0, py = 0;
+    V3<R> g0 = mk<R>(R(1), R(1), R(1));                   // render.cpp:80: radiance.backward(Vec3(1))
+    if (have) {
+        gpix = path_global_pixel(a, a.p0 + lp);
+        py = gpix / (uint32_t)a.W;
+        px = gpix - py * (uint32_t)a.W;
+        if (adjoint)
+            g0 = mk<R>((R)adjoint[(size_t)gpix * 3], (R)adjoint[(size_t)gpix * 3 + 1], (R)adjoint[(size_t)gpix * 3 + 2]);
+    }
+    CameraLane<R> cl;
+    cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
+    cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
+    const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
+    ProgRecs<(sizeof(R) == 4 ? NSIG : 0)> recs;
+    __shared__ ProgLds s_prog;
+    recs.lds = &s_prog;
+    if (sizeof(R) == 4 && NSIG > 0)
+        recs.load(reinterpret_cast<const DevScene<float>*>(sc));
+    if (sizeof(R) == 4 && NSIG == 0) {
+        const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
+        if (threadIdx.x < DRT_PROG_SORTED_MAX) {
+            s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
+            s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
+        }
+        if (threadIdx.x < 8)
+            s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
+        __syncthreads();
+    }
+    // is the roulette of depth d drawn at all?  (not behind a user cap: the reference tests the cap first)
+    auto rr_drawn = [&](int d) { return d >= a.min_bounces && (d < a.depth_cap || a.cap_is_roulette != 0); };
+
+    if (range < a.n_ranges) {
+        for (uint32_t sl = s_begin; sl < s_end; ++sl) {
+            R4 ra;
+            R2 rb;
+            const uint32_t key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+            uint32_t nd = 2;                                  // the camera's two draws
+            bool live = have && a.depth_cap > 0;
+            if (rr_drawn(0)) {                                // pathtracer.hpp:128 at depth 0
+                live = live && !(drt_rng_draw(key, nd) < a.rr_threshold);
+                ++nd;
+            }
+            V3<R> L0;
+            PathVertex<R> cur;
+            bool in_chain;
+            unbiased_walk<R, SPEC, SIG, NSIG>(a, lds, sc, params, recs, key, pk_rr, inv_p_rr, live, ra, rb, 0, nd, n_seg, n_capped, L0,
+                                              cur, in_chain);
+            fx += (double)L0.x; fy += (double)L0.y; fz += (double)L0.z;
+            in_chain = in_chain && have;
+            int cdepth = 0;
+            V3<R> g = g0;
+            while (__any(in_chain)) {
+                // ---- at the chain vertex: emission gradient, fresh direction (integrate.hpp:13-16)
+                V3<R> gq = mk<R>(R(0), R(0), R(0)), fcol = gq;
+                R bs = R(0);
+                bool go = false;
+                R4 sa = ra;
+                R2 sb = rb;
+                uint32_t cid = DRT_ID_NONE;
+                if (in_chain) {
+                    const R inv_pk = cdepth >= a.min_bounces ? inv_p_rr : R(1);
+                    const V3<R> g1 = g * inv_pk;                  // "/ p" of trace()
+                    const uint32_t eid = cur.ids >> 16;
+                    cid = cur.ids & 0xFFFFu;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const bool own = eid == (uint32_t)p;
+                        acc[p] = mk<R>(acc[p].x + (own ? g1.x : R(0)), acc[p].y + (own ? g1.y : R(0)), acc[p].z + (own ? g1.z : R(0)));
+                    }
+                    if (cid == DRT_ID_NONE) {
+                        in_chain = false;                         // no BxDF: f = 0, nothing below
+                    } else {
+                        const DevMaterial<R>& m = lds.sc.materials[cur.material];
+                        V3<R> wo;
+                        R q;
+                        sample_bxdf<R, SPEC>(m, cur.nrm, cur.d, drt_rng_draw(key, nd), drt_rng_draw(key, nd + 1), wo, q, bs);
+                        nd += 2;
+                        const R c = dot(cur.nrm, wo);
+                        gq = g1 * div_r(c, q);                    // grad / pdf (integrate.hpp:17), times cos
+                        fcol = load_param<R, true>(lds, params, (int)cid) * bs;
+                        go = (cdepth + 1) < a.depth_cap;
+                        if (rr_drawn(cdepth + 1)) {
+                            go = go && !(drt_rng_draw(key, nd) < a.rr_threshold);
+                            ++nd;
+                        }
+                        const V3<R> no = cur.P + wo * R(1e-3);
+                        sa.x = no.x; sa.y = no.y; sa.z = no.z; sa.w = wo.x;
+                        sb.x = wo.y; sb.y = wo.z;
+                    }
+                }
+                // ---- forward(sample): the suffix from the fresh direction
+                V3<R> Ls;
+                PathVertex<R> nxt;
+                bool any_vertex;
+                unbiased_walk<R, SPEC, SIG, NSIG>(a, lds, sc, params, recs, key, pk_rr, inv_p_rr, in_chain && go, sa, sb, cdepth + 1, nd,
+                                                  n_seg, n_capped, Ls, nxt, any_vertex);
+                // ---- gradients of this vertex; the chain moves on to the suffix's first vertex
+                if (in_chain) {
+                    const V3<R> df = Ls * gq * bs;                // MulBackward, brdf side
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const bool own = cid == (uint32_t)p;
+                        acc[p] = mk<R>(acc[p].x + (own ? df.x : R(0)), acc[p].y + (own ? df.y : R(0)), acc[p].z + (own ? df.z : R(0)));
+                    }
+                    if (!any_vertex) {
+                        in_chain = false;                         // the suffix is a constant
+                    } else {
+                        g = fcol * gq;                            // MulBackward, radiance side
+                        cur = nxt;
+                        ++cdepth;
+                    }
+                }
+            }
+        }
+        if (fpart && have) {
+            double* f = fpart + ((size_t)range * 3) * a.Pb + lp;
+            f[0] = fx; f[(size_t)a.Pb] = fy; f[(size_t)a.Pb * 2] = fz;
+        }
+        if (lane == 0) {
+            counts[w] = n_seg;
+            counts[(size_t)a.n_groups * a.n_ranges + w] = n_capped;
+        }
+    }
+    {   // block reduction in fp64 (as in k_path)
+        const int wv = threadIdx.x / DRT_WAVE;
+#pragma unroll
+        for (int r = 0; r < NP * 3; ++r) {
+            const V3<R> v3 = acc[r / 3];
             double v = (double)(r % 3 == 0 ? v3.x : (r % 3 == 1 ? v3.y : v3.z));
 #pragma unroll
             for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)

@@ -331,6 +331,12 @@ def test_unbiased_backward_matches_reference(pkg, hip, name):
     assert st["segments"] == int(g["segments"])
     assert grad_rel_err(grads, g["grads"]) < 1e-9
     np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    # analytic scenes: the whole operator in one launch (k_path_unbiased); a mesh: the adjoint-round wavefront.  The
+    # wavefront on request (bounces_per_launch = 1) gives the same numbers
+    assert st["kernels"]["path"]["launches"] == (0 if "mesh" in name else 1)
+    import dataclasses
+    _, gq, sq = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, adjoint=adjoint, f64=True, unbiased=True)
+    assert sq["kernels"]["path"]["launches"] == 0 and sq["segments"] == st["segments"] and grad_rel_err(gq, grads) < 1e-9
     img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, unbiased=True)
     assert abs(st["segments"] - int(g["segments"])) <= 64
     # measured on the six fixtures (profiles/r02_parity_report.txt): <= 3.5e-6, no flipped path; the bound is 3 x that
