@@ -6,7 +6,7 @@ E=gpurun_out/evidence_$T
 for f in "$E"/${T}*; do cp "$f" profiles/; done                   # the per-profile files already carry the tag
 for f in parity_report.txt mesh_scale.txt bench.json bench_config2_fwd_only.json bench_config4_per_gpu_share.json \
          bench_config5_per_gpu_share.json bench_config4_full_size_one_gpu.json bench_config5_full_size_one_gpu.json \
-         bench_mesh160x160_512x512x64.json bench_roulette_b1_p0.5.json bench_2ranks_same_gpu_plumbing.json; do
+         bench_mesh160x160_512x512x64.json bench_roulette_b1_p0.5.json bench_unbiased.json bench_2ranks_same_gpu_plumbing.json; do
   cp "$E/$f" "profiles/${T}_$f"
 done
 cp "$E/${T}_traffic.json" profiles/traffic.json

@@ -11,6 +11,7 @@ bash tools/profile.sh ${T}_streaming cornell:512x512x64:d8:fwdbwd --bounces-per-
 bash tools/profile.sh ${T}_mesh mesh160x160:512x512x64:d8:fwdbwd --scene mesh160x160 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_config5 cornell_specular:1024x1024x16:d16:fwdbwd --config 5 --width 1024 --height 1024 --spp 16 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0.5 --min-bounces 1 >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_unbiased cornell:512x512x64:d8:unbiased --unbiased >> "$E/prof.log" 2>&1
 python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
 python3 bench.py > "$E/bench.json" 2> "$E/bench.err"
 python3 bench.py --config 2 --no-cpu-baseline > "$E/bench_config2_fwd_only.json" 2>> "$E/bench.err"
@@ -20,9 +21,10 @@ python3 bench.py --config 4 --spp 256 --steps 5 --warmup 1 --no-cpu-baseline --n
 python3 bench.py --config 5 --spp 1024 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-views > "$E/bench_config5_full_size_one_gpu.json" 2>> "$E/bench.err"
 python3 bench.py --scene mesh160x160 > "$E/bench_mesh160x160_512x512x64.json" 2>> "$E/bench.err"
 python3 bench.py --absorb 0.5 --min-bounces 1 > "$E/bench_roulette_b1_p0.5.json" 2>> "$E/bench.err"
+python3 bench.py --unbiased --no-extra-views > "$E/bench_unbiased.json" 2>> "$E/bench.err"
 python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-extra-views > "$E/bench_2ranks_same_gpu_plumbing.json" 2>> "$E/bench.err"
 python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
-for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_roulette; do
+for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_roulette ${T}_unbiased; do
   P=gpurun_out/prof_$t
   cp $P/summary.txt "$E/${t}_rocprofv3_summary.txt"
   cp $P/traffic.json "$E/${t}_traffic.json"

@@ -21,7 +21,7 @@ def find(sub, pattern):
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_raygen", "k_intersect_mesh", "k_intersect", "k_shade", "k_path_finish", "k_path", "k_film_parts", "k_film", "k_resolve", "k_backward_image",
+    for k in ("k_raygen", "k_intersect_mesh", "k_intersect", "k_shade", "k_path_finish", "k_path_unbiased", "k_path", "k_film_parts", "k_film", "k_resolve", "k_backward_image",
               "k_backward", "k_radiance", "k_gradreduce", "k_sum_counts", "k_add_f64"):
         if k in n:
             tag = k
@@ -83,7 +83,7 @@ json.dump({"kernels": summary, "traffic": traffic}, open(os.path.join(out, "summ
 # bench.py's "traffic" field: PMC bytes per launch / traced average launch time, per kernel
 names = {"k_raygen": "raygen", "k_intersect": "intersect", "k_intersect_mesh": "intersect_mesh", "k_shade<diffuse>": "shade",
          "k_shade<specular>": "shade", "k_shade<diffuse,fused>": "shade", "k_shade<specular,fused>": "shade", "k_film": "film",
-         "k_film_parts": "film", "k_backward": "backward", "k_radiance": "backward", "k_gradreduce": "gradreduce", "k_path": "path", "k_path<regen>": "path", "k_path_finish": "film"}
+         "k_film_parts": "film", "k_backward": "backward", "k_radiance": "backward", "k_gradreduce": "gradreduce", "k_path": "path", "k_path<regen>": "path", "k_path_unbiased": "path", "k_path_finish": "film"}
 tj = {"workload": workload}
 for k, t in traffic.items():
     if k in names and "avg_us" in summary.get(k, {}):
