@@ -358,7 +358,8 @@ def main():
         """Mray/s of a variant of the headline call (device buffers, same frame), a few steps."""
         bw = kw.pop("backward", backward)
         f64 = kw.pop("f64", False)
-        rpv = dataclasses.replace(rp, flags=(rp.flags | (pkg.RENDER_F64 if f64 else 0)))
+        unb = kw.pop("unbiased", False)
+        rpv = dataclasses.replace(rp, flags=(rp.flags | (pkg.RENDER_F64 if f64 else 0) | (pkg.RENDER_UNBIASED if unb else 0)))
 
         def one(timing=False):
             return r.render_device(cam, rpv, out_rgb.data_ptr(), grads[0].data_ptr() if bw else 0, backward=bw,
@@ -375,7 +376,10 @@ def main():
         fence()
         return {"value": round(segs / dt5 * 1e-6, 2), "unit": "Mray/s", "ms_per_step": round(dt5 * 1e3, 4)}
 
-    f64_view = fwd_view = None
+    f64_view = fwd_view = unb_view = None
+    if extra and not a.unbiased and backward and world == 1:
+        unb_view = dict(timed_variant(unbiased=True), note="the same frame with the reference's UNBIASED integration operator "
+                                                           "(integrate.hpp:39-52: a fresh suffix path per vertex, O(depth^2) segments)")
     if extra and not a.unbiased:
         f64_view = dict(timed_variant(f64=True), note="the same call with DRT_RENDER_F64: every kernel computes and stores in "
                                                       "double, the reference's precision (render.cpp:22)")
@@ -470,7 +474,7 @@ def main():
                        "parallelism": par, "batches_per_step": stats["batches"],
                        "capped_paths_per_step": stats["capped_paths"]},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
-            "f64": f64_view, "fwd_only": fwd_view,
+            "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view,
         }
         print(json.dumps(line), flush=True)
     # teardown in the same order on every rank: the library's communicator first (all ranks are still here), then the
