@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Random render configurations through every route of the library (run on the GPU box): each must finish, be finite,
+and the one-launch kernels (k_path, its regenerating, 8-parameter, gradient-image and unbiased forms) must agree with
+the queue wavefront (bounces_per_launch = 1) in the f64 mode to 1e-9 with identical segment counts.
+Usage: tools/fuzz_modes.py [n_cases] [seed]"""
+import dataclasses
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+
+pkg = e.load_package()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+r = pkg.HipRenderer(0)
+scenes = ["cornell", "cornell_specular", "cornell_walls", "cornell_emissive_wall", "cornell_mirror_wall", "random3", "random7",
+          "mesh6x8", "mesh10x12f5"]
+worst = 0.0
+t0 = time.time()
+for case in range(n_cases):
+    name = scenes[rs.randint(len(scenes))]
+    scene = pkg.scene_by_name(name)
+    w, h = int(rs.randint(8, 90)), int(rs.randint(8, 70))
+    cam = pkg.cornell_camera(w, h) if not name.startswith("random") else pkg.Camera(w, h).look_at((0.1, 0.0, -0.2), (0, 0.2, 1))
+    fixed = rs.rand() < 0.5
+    b = int(rs.randint(0, 9))
+    p = 1.0 if fixed else float(rs.choice([0.1, 0.3, 0.5, 0.8]))
+    md = int(rs.choice([0, 0, 3, 7, 20]))
+    if fixed and b == 0:
+        b = 1
+    kw = dict(spp=int(rs.randint(1, 12)), min_bounces=b, absorb=p, seed=int(rs.randint(1 << 30)))
+    if md:
+        kw["max_depth"] = md
+    n_sh = int(rs.choice([1, 1, 3]))
+    if n_sh > 1:
+        kw.update(shard=int(rs.randint(n_sh)), n_shards=n_sh, band_rows=int(rs.randint(1, 9)))
+    if rs.rand() < 0.3:
+        kw["batch_paths"] = int(rs.randint(64, w * h * kw["spp"] + 64))
+    rp = pkg.RenderParams(**kw)
+    unbiased = rs.rand() < 0.35
+    adjoint = rs.uniform(0.2, 1.5, (h, w, 3)).astype(np.float32) if rs.rand() < 0.3 else None
+    r.upload_scene(scene)
+    t1 = time.time()
+    a = r.render(cam, rp, backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
+    q = r.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
+    f = r.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
+    dt = time.time() - t1
+    assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all() and np.isfinite(f[0]).all() and np.isfinite(f[1]).all(), (case, name, kw)
+    assert a[2]["segments"] == q[2]["segments"], (case, name, kw, unbiased, a[2]["segments"], q[2]["segments"])
+    scale = max(1e-300, float(np.abs(q[1]).max()))
+    err = float(np.abs(a[1] - q[1]).max() / scale)
+    worst = max(worst, err)
+    assert err < 1e-9, (case, name, kw, unbiased, err)
+    np.testing.assert_allclose(a[0], q[0], rtol=1e-6, atol=1e-9)
+    route = "path" if a[2]["kernels"]["path"]["launches"] else "queue"
+    print(f"{case:3d} {name:22s} {w:3d}x{h:<3d} spp {kw['spp']:2d} b{b} p{p:g} md{md:<2d} shards {n_sh} {'unb' if unbiased else 'bia'} "
+          f"{'adj' if adjoint is not None else '   '} {route:5s} seg {a[2]['segments']:8d} err {err:.1e}  {dt * 1e3:6.0f} ms", flush=True)
+print(f"FUZZ OK: {n_cases} cases in {time.time() - t0:.0f} s, worst one-launch vs wavefront gradient difference (f64) {worst:.2e}")
