@@ -8,7 +8,9 @@ LIB := $(PKG)/libdrt_hip.so
 CXX ?= g++
 HIPCC ?= hipcc
 # the EXR writer compresses (ZIP blocks) when zlib is there, writes uncompressed scan lines otherwise
-EXR_ZLIB := $(shell echo '\#include <zlib.h>' | $(CXX) -E -x c++ - >/dev/null 2>&1 && echo -DDRT_EXR_ZLIB)
+# (no '#' inside $(shell ...): GNU Make >= 4.3 hands "\#" to the shell verbatim and the probe always "succeeds")
+# DRT_NO_ZLIB=1 forces the uncompressed fallback (tests/test_host_api.py builds both ways)
+EXR_ZLIB := $(if $(DRT_NO_ZLIB),,$(shell echo 'int main(){return 0;}' | $(CXX) -x c++ -include zlib.h -fsyntax-only - >/dev/null 2>&1 && echo -DDRT_EXR_ZLIB))
 EXR_ZLIB_LIB := $(if $(EXR_ZLIB),-lz)
 
 all: lib oracle host

@@ -263,15 +263,17 @@ def main():
     value = total_segments * a.steps / elapsed * 1e-6   # Mray/s, whole job
 
     # ---- per-kernel algorithmic bytes and the roofline of the dominant kernel ----------
-    units = {"intersect": segments, "intersect_mesh": segments, "shade": segments, "backward": segments, "path": segments,
-             "raygen": paths, "film": paths, "gradreduce": 0}
+    # units: what the library counted for each kernel (drt_hip_stats.units): paths (K1, K5), segments (K3, K6, k_path),
+    # the rays k_intersect tested (mesh scenes: camera rays only), the candidate rays the BVH walk took
+    units = {k: stats["kernels"][k]["units"] for k in pkg.KERNEL_NAMES}
     # fused shade: tape 8 B/segment + 32 B per ray read from / written to the queue (the library counts both);
     # unfused (mesh scenes): ray 24 + id 8 + hit 8 read, ray 24 + id 8 + tape 8 written;
     # k_path: a path lives in registers from the eye to its end; the launch writes 24 B per pixel and sample range,
-    # 192 B per block (gradient partials) and 8 B per wave (counters): stats["path_bytes"], ~0.2 B per segment;
-    # k_intersect_mesh: ray 24 + hit 8 read, hit 8 written (the BVH itself is L2 / Infinity-Cache resident)
+    # 192 B per block (gradient partials) and 8 B per wave (counters): stats["path_bytes"], ~0.4 B per segment;
+    # k_intersect_mesh: per CANDIDATE ray a 36-byte record (slot, origin, direction, analytic t, tie-break index) read and
+    # at most one 8-byte hit written (the BVH itself is L2 / Infinity-Cache resident)
     seg = max(1, segments)
-    bpu = {"intersect": 32.0, "intersect_mesh": 40.0,
+    bpu = {"intersect": 32.0, "intersect_mesh": 44.0,
            "shade": 80.0 if kernel_launches["intersect"] else
                     (8.0 if kernel_launches["backward"] else 16.0 * paths / seg) + 32.0 * queue_rays / seg,
            "path": stats.get("path_bytes", 0) / seg,
@@ -285,11 +287,11 @@ def main():
             continue
         gbs = units[k] * bpu[k] / (ms * 1e-3) * 1e-9 if ms > 0 else 0.0
         per_kernel[k] = {"ms_per_step": round(ms, 4), "launches_per_step": kernel_launches[k] // n_prof,
-                         "bytes_per_unit": round(bpu[k], 3), "achieved_GBs": round(gbs, 1),
+                         "units_per_step": int(units[k]), "bytes_per_unit": round(bpu[k], 3), "achieved_GBs": round(gbs, 1),
                          "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     dominant = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else "shade"
-    # rocprofv3 PMC figures of the dominant kernel (profiles/traffic.json, written by tools/profile.sh on the
-    # workload named in it): quoted only for that very workload
+    # rocprofv3 PMC figures of the dominant kernel (profiles/traffic.json, written by tools/profile.sh, one entry per
+    # profiled workload): quoted only for the very workload this run measures
     pmc = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     depth_text = f"roulette from bounce {a.min_bounces} with absorption {a.absorb:g}" if a.roulette else f"depth {a.depth}"
@@ -298,8 +300,8 @@ def main():
     if os.path.exists(tpath) and not a.unbiased and a.bounces_per_launch == 0:
         try:
             tj = json.load(open(tpath))
-            if tj.get("workload") == workload_key:
-                pmc = tj.get(dominant) or {}
+            entry_w = (tj.get("workloads") or {}).get(workload_key) or (tj if tj.get("workload") == workload_key else {})
+            pmc = entry_w.get(dominant) or {}
         except Exception:
             pmc = {}
     dk = per_kernel.get(dominant, {"achieved_GBs": 0.0, "launches_per_step": 1, "ms_per_step": 0.0})
@@ -307,23 +309,40 @@ def main():
     register_resident = dominant == "path" or (dominant == "shade" and not kernel_launches["intersect"]
                                                and dk["launches_per_step"] < a.depth * max(1, stats["batches"]) and not a.unbiased)
     traffic = round(pmc["bytes_per_launch"] / (launch_ms * 1e-3) * 1e-9, 1) if pmc.get("bytes_per_launch") and launch_ms > 0 else None
-    roofline = {"bound": "valu-issue (paths are register-resident: the kernel moves almost no bytes)" if register_resident
-                         else ("latency (divergent BVH walk out of L2)" if dominant == "intersect_mesh" else "hbm"),
-                "kernel": "k_" + dominant, "achieved": dk["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    hbm_view = {"achieved": dk["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4),
                 "frac_of_measured_copy_roof": round(dk["achieved_GBs"] / HBM_COPY_GBS, 4),
+                "note": "algorithmic bytes of the dominant kernel (units x bytes per unit) over its HIP-event time"}
+    valu_view = None
+    if pmc.get("valu_insts_per_launch") and launch_ms > 0:
+        ginst = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3) * 1e-9
+        valu_view = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                     "frac": round(ginst / VALU_PEAK_GINST, 4),
+                     "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
+                     "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
+                     "note": "SQ_INSTS_VALU per launch (profiles/traffic.json, rocprofv3 --pmc on this workload) / live launch "
+                             "time; peak = one wave64 VALU op per 2 cycles per SIMD-32, 256 CUs x 4 SIMDs x 2.4 GHz"}
+    # The top-level achieved / peak / unit / frac describe the roof that BOUNDS the dominant kernel: HBM bytes for the
+    # streaming kernels; vector-instruction issue for the register-resident k_path (it moves ~0.4 B per segment) and
+    # for the BVH walk (divergent, latency-bound: neither roof is near -- both fractions are printed).  The other
+    # view stays beside it (`hbm` / `valu`).
+    issue_bound = register_resident or dominant == "intersect_mesh"
+    top = valu_view if (issue_bound and valu_view) else (hbm_view if not issue_bound else
+                                                         {"achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": None,
+                                                          "note": "no rocprofv3 PMC profile of this workload in profiles/traffic.json: "
+                                                                  "run tools/profile.sh on it"})
+    roofline = {"bound": ("valu-issue (paths are register-resident: the kernel moves almost no bytes)" if register_resident
+                          else ("latency (divergent BVH walk out of L2): far from both the HBM and the vector-issue roof" if dominant == "intersect_mesh" else "hbm")),
+                "kernel": "k_" + dominant, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                "frac": top["frac"],
                 "traffic": traffic,
                 "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json, rocprofv3 --pmc, FETCH_SIZE "
                                 "doubled per the gfx950 correction) over the live launch time" if traffic else None,
                 "avg_launch_ms": round(launch_ms, 4),
+                "hbm": hbm_view, "valu": valu_view,
                 "kernels": per_kernel}
-    if pmc.get("valu_insts_per_launch") and launch_ms > 0:
-        ginst = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3) * 1e-9
-        roofline["valu"] = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
-                            "frac": round(ginst / VALU_PEAK_GINST, 4),
-                            "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
-                            "note": "SQ_INSTS_VALU per launch (profiles/traffic.json) / live launch time; peak = one VALU op "
-                                    "per 2 cycles per SIMD"}
+    if dominant == "intersect_mesh" and pmc.get("lane_stats"):
+        roofline["walk_lanes"] = pmc["lane_stats"]      # tools/bvh_stats.py on the same scene (a -DDRT_BVH_STATS build)
 
     extra = rank == 0 and world == 1 and not a.no_extra_views
     import dataclasses

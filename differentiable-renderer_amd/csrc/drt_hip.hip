@@ -435,6 +435,7 @@ int queue_length(drt_hip_ctx* ctx, const uint32_t* counts_row, uint32_t n_region
     return DRT_OK;
 }
 #define DRT_POLL_EVERY 4
+#define DRT_TOTAL_WORDS 8           // segtotal: segments, queue rays read, written, capped paths, K2 rays, walked candidates
 
 template <typename R>
 int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
@@ -600,13 +601,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     }
     *n_count_words = cw;
     if ((rc = ensure(ctx, ctx->counts, cw * sizeof(uint32_t))) != DRT_OK) return rc;
-    if ((rc = ensure(ctx, ctx->segtotal, 4 * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written, capped
+    if ((rc = ensure(ctx, ctx->segtotal, DRT_TOTAL_WORDS * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written, capped, K2 rays, walked candidates
     // a k_path launch that covers the whole frame is followed by ONE finishing launch that WRITES image, gradients and
     // totals (k_path_finish); every other route accumulates into zeroed buffers
     static const bool finish_env = !(getenv("DRT_HIP_PATH_FINISH") && atoi(getenv("DRT_HIP_PATH_FINISH")) == 0);
     const bool path_finish = finish_env && use_path && Pb == n_local_pixels && Sb == (uint32_t)spp && (!film || d_out_rgb);
     if (!path_finish) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->segtotal.p, 0, DRT_TOTAL_WORDS * sizeof(unsigned long long), ctx->stream));
         if (film)
             HIPCHK(ctx, hipMemsetAsync(film, 0, (size_t)n_local_pixels * 3 * sizeof(double), ctx->stream));
         if (backward)
@@ -878,7 +879,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                            ra[cur], rb[cur], hit_k, counts + (size_t)k * max_regions, bvh,
                                            ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
-                                           (uint32_t*)ctx->cand_count.p, cand_cap);
+                                           (uint32_t*)ctx->cand_count.p, cand_cap, (unsigned long long*)ctx->segtotal.p);
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT]++;
                     }
@@ -891,7 +892,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                            bvh, hit_k, (const uint32_t*)ctx->cand.p, (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p,
                                            (uint32_t*)ctx->cand_count.p, lists_from_shade ? region_size : cand_cap,
-                                           walk_lists, walk_group, coprime_multiplier((walk_lists + walk_group - 1) / walk_group));
+                                           walk_lists, walk_group, coprime_multiplier((walk_lists + walk_group - 1) / walk_group),
+                                           (unsigned long long*)ctx->segtotal.p);
                         if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_INTERSECT_MESH]++;
                     }
@@ -1004,12 +1006,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                             hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                                ra[cur], rb[cur], hit, ck, bvh,
                                                ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
-                                       (uint32_t*)ctx->cand_count.p, cand_cap);
+                                       (uint32_t*)ctx->cand_count.p, cand_cap, (unsigned long long*)ctx->segtotal.p);
                             if (ctx->has_mesh)
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
                                                    ctx->stream, a, d_scene, bvh, hit, (const uint32_t*)ctx->cand.p,
                                                    (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE), 1u,
-                                                   coprime_multiplier((uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE)));
+                                                   coprime_multiplier((uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE)), (unsigned long long*)ctx->segtotal.p);
                             st->launches[DRT_K_INTERSECT]++;
                         }
                         if (k == s && !fused)
@@ -1250,6 +1252,9 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // from here on the device state is being replaced: a failure below (BVH limits, out of memory) must leave the
+    // context WITHOUT a scene, not with the new records under the old scene's bookkeeping
+    ctx->has_scene = false;
     DevScene<float>* hf = new DevScene<float>();
     DevScene<double>* hd = new DevScene<double>();
     std::vector<float> pf;
@@ -1577,7 +1582,7 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true)
     ctx->h_segments = 0;
     j.want_segments = j.stats && j.n_count_words;
     if (j.want_segments)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage, ctx->segtotal.p, DRT_TOTAL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     return DRT_OK;
 }
 
@@ -1588,7 +1593,7 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (j.sync)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h_tot[4] = {0, 0, 0, 0};
+    unsigned long long h_tot[DRT_TOTAL_WORDS] = {0};
     if (j.want_segments)
         memcpy(h_tot, ctx->h_stage, sizeof h_tot);
     ctx->h_segments = h_tot[0];
@@ -1617,8 +1622,8 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true)
         st.queue_rays_written = h_tot[2];
         st.capped_paths = h_tot[3];
         st.bvh_bytes = ctx->has_mesh ? ctx->bvh_bytes : 0;
-        st.units[DRT_K_INTERSECT] = st.launches[DRT_K_INTERSECT] ? st.segments : 0;
-        st.units[DRT_K_INTERSECT_MESH] = st.launches[DRT_K_INTERSECT_MESH] ? st.segments : 0;
+        st.units[DRT_K_INTERSECT] = h_tot[4];              // rays k_intersect tested (mesh scenes: the camera rays only)
+        st.units[DRT_K_INTERSECT_MESH] = h_tot[5];         // candidate rays the BVH walk took (those that reach the mesh bounds)
         st.units[DRT_K_SHADE] = st.launches[DRT_K_SHADE] ? st.segments : 0;
         st.units[DRT_K_PATH] = st.launches[DRT_K_PATH] ? st.segments : 0;
         st.units[DRT_K_BACKWARD] = j.backward && st.launches[DRT_K_BACKWARD] ? st.segments : 0;
@@ -1884,6 +1889,7 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
         return DRT_ERR_INVALID;
     if (ctx->members.empty())
         return upload_scene_one(ctx, s);
+    ctx->has_scene = false;
     for (drt_hip_ctx* m : ctx->members) {
         const int rc = upload_scene_one(m, s);
         if (rc != DRT_OK) {

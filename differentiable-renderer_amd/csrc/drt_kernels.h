@@ -377,7 +377,7 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
             const typename Q2<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
             const uint32_t* __restrict__ counts_k, DevBvh<R> bvh, uint32_t* __restrict__ cand,
             typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b,
-            uint32_t* __restrict__ cand_count, uint32_t cand_cap)
+            uint32_t* __restrict__ cand_count, uint32_t cand_cap, unsigned long long* __restrict__ total)
 {
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
@@ -388,6 +388,7 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     constexpr int NR = DRT_K2_RAYS;
     const uint32_t gw = grid_wave();
     uint32_t n_cand = 0;                                        // length of this wave's candidate list
+    uint32_t n_rays = 0;                                        // rays this wave intersected (statistics: total[4])
     if (cand && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)   // the walk's list counters (it runs after this kernel)
         pull_counters(cand_count, n_waves)[threadIdx.x * DRT_PULL_STRIDE] = 0;
     for (uint32_t c = gw; c < n_chunks; c += NR * n_waves) {
@@ -401,6 +402,7 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
             ra[r] = R4{};
             rb[r] = R2{};
             if (slot[r] != 0xFFFFFFFFu) { ra[r] = ray_a[slot[r]]; rb[r] = ray_b[slot[r]]; }
+            n_rays += (uint32_t)__popcll(__ballot(slot[r] != 0xFFFFFFFFu));
         }
         closest_hit_n<R, NR>(sc, n_shapes, ra, rb, h);
 #pragma unroll
@@ -440,6 +442,8 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     }
     if (cand && lane == 0)
         cand_count[gw] = n_cand;
+    if (total && lane == 0 && n_rays)
+        atomicAdd(total + 4, (unsigned long long)n_rays);       // (integer: order-independent)
 }
 
 // ---- K2 (scenes with triangle meshes) -----------------------------------------------------------
@@ -468,7 +472,7 @@ __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh, HitRec<R>* hit,
                  const uint32_t* __restrict__ cand, const typename Q4<R>::T* __restrict__ cand_a,
                  const typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
-                 uint32_t n_lists, uint32_t group, uint32_t perm_mul)
+                 uint32_t n_lists, uint32_t group, uint32_t perm_mul, unsigned long long* __restrict__ total)
 {
     // (group = lists handed out per pull: 1 for k_intersect's lists, 4 for the shorter per-region lists of k_shade.
     //  perm_mul, coprime to the number of groups: pull number n is group (n * perm_mul) mod n_groups -- consecutive pulls
@@ -500,6 +504,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     uint32_t* const ctr = pull_counters(cand_count, n_lists);
 
     bool active = false;
+    uint32_t n_walked = 0;                                      // candidate rays this wave took (statistics: total[5])
     uint32_t slot = 0, cur = DRT_BVH_NONE, best_flat = 0xFFFFFFFFu;
     int sp = 0, prim = -1;
     V3<R> o = mk<R>(R(0), R(0), R(0)), d = o, inv_d = o;
@@ -582,6 +587,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     DRT_STAT(0, 1);
                 }
                 cur_off += n_want < avail ? n_want : avail;
+                n_walked += n_want < avail ? n_want : avail;
             }
         }
         if (!__any(active))
@@ -690,6 +696,8 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             active = false;
         }
     }
+    if (total && lane == 0 && n_walked)
+        atomicAdd(total + 5, (unsigned long long)n_walked);
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------

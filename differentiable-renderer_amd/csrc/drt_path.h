@@ -254,7 +254,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)
 {
-    if (total && blockIdx.x == 0 && threadIdx.x < 4)
+    if (total && blockIdx.x == 0 && threadIdx.x < 8)
         total[threadIdx.x] = 0;                           // (the finishing kernel behind this launch adds into them)
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
@@ -530,7 +530,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
                 double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
                 unsigned long long* __restrict__ total)
 {
-    if (total && blockIdx.x == 0 && threadIdx.x < 4)
+    if (total && blockIdx.x == 0 && threadIdx.x < 8)
         total[threadIdx.x] = 0;
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;

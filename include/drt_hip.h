@@ -185,7 +185,9 @@ typedef struct drt_hip_stats {
     double ms_total;                /* wall time of the call (host clock) */
     double ms_kernel[DRT_K_COUNT];  /* summed HIP-event time per kernel (DRT_RENDER_TIMING) */
     uint64_t launches[DRT_K_COUNT];
-    uint64_t units[DRT_K_COUNT];    /* segments (K2,K3,K6) or paths (K1,K5) processed */
+    uint64_t units[DRT_K_COUNT];    /* work items processed: paths (K1, K5), segments (K3, K6, k_path), rays tested by
+                                       k_intersect (mesh scenes: the camera rays only), candidate rays walked by
+                                       k_intersect_mesh (the rays that reach the bounds of the mesh) */
     uint64_t queue_rays_read;       /* rays the shade launches read from the queue (a fused launch keeps a ray */
     uint64_t queue_rays_written;    /* in registers over several bounces) / survivors they wrote back: 32 B each */
     uint64_t capped_paths;          /* paths still alive when they reached max_depth (cut short: 0 when the cap is

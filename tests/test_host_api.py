@@ -240,3 +240,18 @@ def test_repeated_calls_reuse_the_device_context(app, tmp_path):
     assert len(ms) == 4 and max(ms[1:]) < 0.25 * ms[0] and max(ms[1:]) < 50.0, ms
     np.testing.assert_array_equal(parse_grads(rep.stdout), parse_grads(once.stdout))   # zeroed between calls
     np.testing.assert_array_equal(read_exr_half_rgba(str(tmp_path / "a.exr")), read_exr_half_rgba(str(tmp_path / "b.exr")))
+
+
+def test_makefile_zlib_probe_reports_what_the_compiler_finds():
+    """The top-level Makefile compiles the EXR writer with -DDRT_EXR_ZLIB -lz only where <zlib.h> is found (a probe that
+    always succeeds would break `make host` on a machine without zlib instead of falling back to uncompressed scan
+    lines).  Dry runs: default compiler, a compiler that finds no system header at all, and the DRT_NO_ZLIB switch."""
+    def flags(*extra):
+        out = subprocess.run(["make", "-n", "-B", "build/render"] + list(extra), cwd=ROOT, capture_output=True, text=True, check=True).stdout
+        line = [l for l in out.splitlines() if "render_hip.cpp" in l][0]
+        return "-DDRT_EXR_ZLIB" in line, line.rstrip().endswith("-lz")
+    have = subprocess.run("echo 'int main(){return 0;}' | g++ -x c++ -include zlib.h -fsyntax-only -", shell=True,
+                          capture_output=True).returncode == 0
+    assert flags() == (have, have)
+    assert flags("CXX=g++ -nostdinc") == (False, False)
+    assert flags("DRT_NO_ZLIB=1") == (False, False)

@@ -9,5 +9,5 @@ for f in parity_report.txt mesh_scale.txt bench.json bench_config2_fwd_only.json
          bench_mesh160x160_512x512x64.json bench_roulette_b1_p0.5.json bench_unbiased.json bench_2ranks_same_gpu_plumbing.json; do
   cp "$E/$f" "profiles/${T}_$f"
 done
-cp "$E/${T}_traffic.json" profiles/traffic.json
+cp "$E/traffic_merged.json" profiles/traffic.json
 ls -la profiles | grep "${T}_" | wc -l

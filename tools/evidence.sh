@@ -6,12 +6,14 @@ T=${1:-r02}
 E=$PWD/gpurun_out/evidence_$T
 mkdir -p "$E"
 bash tools/profile.sh $T cornell:512x512x64:d8:fwdbwd > "$E/prof.log" 2>&1
-cp gpurun_out/prof_$T/traffic.json profiles/traffic.json          # bench.py quotes PMC numbers only for the workload named in it
 bash tools/profile.sh ${T}_streaming cornell:512x512x64:d8:fwdbwd --bounces-per-launch 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_mesh mesh160x160:512x512x64:d8:fwdbwd --scene mesh160x160 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_config5 cornell_specular:1024x1024x16:d16:fwdbwd --config 5 --width 1024 --height 1024 --spp 16 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0.5 --min-bounces 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_unbiased cornell:512x512x64:d8:unbiased --unbiased >> "$E/prof.log" 2>&1
+# bench.py quotes PMC numbers only for the workloads profiled above (one entry each)
+python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_roulette/traffic.json >> "$E/prof.log" 2>&1
+cp profiles/traffic.json "$E/traffic_merged.json"
 python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
 python3 bench.py > "$E/bench.json" 2> "$E/bench.err"
 python3 bench.py --config 2 --no-cpu-baseline > "$E/bench_config2_fwd_only.json" 2>> "$E/bench.err"

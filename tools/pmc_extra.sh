@@ -10,7 +10,7 @@ for set in "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
            "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
   i=$((i+1))
   d=$OUT/set$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$d" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> "$d.err"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$d" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-views "$@" > /dev/null 2> "$d.err" || { echo "bench.py failed under rocprofv3 (set $i): see $d.err" >&2; tail -5 "$d.err" >&2; exit 1; }
   python3 - "$d" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)

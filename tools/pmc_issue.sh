@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST
            "SQ_INST_LEVEL_SMEM SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_IFETCH SQ_WAVES"; do
   i=$((i+1))
   d=$OUT/set$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$d" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-streaming-view "$@" > /dev/null 2> "$d.err"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$d" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-views "$@" > /dev/null 2> "$d.err" || { echo "bench.py failed under rocprofv3 (set $i): see $d.err" >&2; tail -5 "$d.err" >&2; exit 1; }
   python3 - "$d" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
