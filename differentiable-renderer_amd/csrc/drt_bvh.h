@@ -39,7 +39,10 @@ constexpr int kMaxDepth = 20;     // bound of the binary build's depth.  The col
                                   // level: the wide depth is NOT kMaxDepth / 2 in general.  What the device needs is
                                   // Built::stack_need <= its per-lane stack (DRT_BVH_STACK); build() measures it on the
                                   // finished tree and rebuilds with a smaller depth bound until it holds.
-constexpr int kStackEntries = 32; // = DRT_BVH_STACK (drt_device.h; static_assert in drt_hip.hip)
+#ifndef DRT_BVH_STACK
+#define DRT_BVH_STACK 30
+#endif
+constexpr int kStackEntries = DRT_BVH_STACK; // = DRT_BVH_STACK (drt_device.h; static_assert in drt_hip.hip)
 
 struct Built {
     std::vector<Node> nodes;      // final order, root = 0

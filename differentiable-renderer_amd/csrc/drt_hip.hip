@@ -1956,6 +1956,27 @@ extern "C" int drt_hip_debug_bvh_stats(unsigned long long* out8)
 }
 #endif
 
+#ifdef DRT_BVH_STATS
+extern "C" int drt_hip_debug_bvh_hist(unsigned long long* out24)
+{
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_bvh_hist), 24 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    unsigned long long zero[24] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_hist), zero, sizeof zero);
+    return 0;
+}
+#endif
+#ifdef DRT_WALK_TIMES
+// debug build only: start / counters-dry / exit time of every wave of the last k_intersect_mesh launch (drt_kernels.h)
+extern "C" int drt_hip_debug_walk_times(unsigned long long* out, int n_waves)
+{
+    (void)hipDeviceSynchronize();
+    if (n_waves > 8192) n_waves = 8192;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_times), (size_t)n_waves * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 const char* drt_hip_last_error(drt_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 const char* drt_hip_kernel_name(int k)

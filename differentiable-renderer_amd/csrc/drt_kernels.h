@@ -462,13 +462,21 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
 #ifdef DRT_BVH_STATS
 // debug build only (tools/): [0] rays, [1] node visits served from LDS, [2] from memory, [3] leaf visits, [4] triangle tests
 __device__ unsigned long long g_bvh_stats[8];
+// [0..7]: rays by their number of node visits (1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, more); [8..15]: those of them that ended
+// on a triangle; [16..23]: node visits summed per bin
+__device__ unsigned long long g_bvh_hist[24];
 #define DRT_STAT(i, n) atomicAdd(&g_bvh_stats[i], (unsigned long long)(n))
 #else
 #define DRT_STAT(i, n)
 #endif
+#ifdef DRT_WALK_TIMES
+// debug build only (tools/walk_diag.py): per wave of the LAST walk launch, s_memrealtime (100 MHz) at its start, when its
+// list counters ran dry, at its exit
+__device__ unsigned long long g_walk_times[8192][3];
+#endif
 
 template <typename R>
-__global__ void __launch_bounds__(DRT_BLOCK)
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 ? DRT_WALK_MIN_BLOCKS : 1))
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh, HitRec<R>* hit,
                  const uint32_t* __restrict__ cand, const typename Q4<R>::T* __restrict__ cand_a,
                  const typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count, uint32_t cand_cap,
@@ -503,6 +511,15 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     const uint32_t home = (blockIdx.x * (DRT_BLOCK / DRT_WAVE) + threadIdx.x / DRT_WAVE) & (DRT_PULL_COUNTERS - 1);
     uint32_t* const ctr = pull_counters(cand_count, n_lists);
 
+#ifdef DRT_WALK_TIMES
+    const uint32_t stat_wave = blockIdx.x * (DRT_BLOCK / DRT_WAVE) + threadIdx.x / DRT_WAVE;
+    unsigned long long stat_dry_at = 0;
+    if (lane == 0 && stat_wave < 8192)
+        g_walk_times[stat_wave][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef DRT_BVH_STATS
+    uint32_t stat_visits = 0;
+#endif
     bool active = false;
     uint32_t n_walked = 0;                                      // candidate rays this wave took (statistics: total[5])
     uint32_t slot = 0, cur = DRT_BVH_NONE, best_flat = 0xFFFFFFFFu;
@@ -552,6 +569,9 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     }
                     if (grp == 0xFFFFFFFFu) {
                         dry = true;
+#ifdef DRT_WALK_TIMES
+                        stat_dry_at = __builtin_amdgcn_s_memrealtime();
+#endif
                         break;
                     }
                     grp = (uint32_t)(((uint64_t)grp * perm_mul) % n_groups);
@@ -585,6 +605,9 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     want = false;
                     active = true;
                     DRT_STAT(0, 1);
+#ifdef DRT_BVH_STATS
+                    stat_visits = 0;
+#endif
                 }
                 cur_off += n_want < avail ? n_want : avail;
                 n_walked += n_want < avail ? n_want : avail;
@@ -608,6 +631,9 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                 continue;
             uint4 w0, w1, w2, w3;
             DRT_STAT(cur < n_lds ? 1 : 2, 1);
+#ifdef DRT_BVH_STATS
+            ++stat_visits;
+#endif
             if (cur < n_lds) {
                 w0 = s_node[cur][0]; w1 = s_node[cur][1]; w2 = s_node[cur][2]; w3 = s_node[cur][3];
             } else {
@@ -687,6 +713,15 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
         if (active && cur == DRT_BVH_NONE) {
+#ifdef DRT_BVH_STATS
+            {
+                const uint32_t v = stat_visits;
+                const int bin = v <= 1 ? 0 : (v <= 2 ? 1 : (v <= 4 ? 2 : (v <= 8 ? 3 : (v <= 16 ? 4 : (v <= 32 ? 5 : (v <= 64 ? 6 : 7))))));
+                atomicAdd(&g_bvh_hist[bin], 1ull);
+                if (prim >= 0) atomicAdd(&g_bvh_hist[8 + bin], 1ull);
+                atomicAdd(&g_bvh_hist[16 + bin], (unsigned long long)v);
+            }
+#endif
             if (prim >= 0) {                                    // a triangle beat the analytic hit k_intersect recorded
                 HitRec<R> h;
                 h.t = tmin;
@@ -698,6 +733,12 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     }
     if (total && lane == 0 && n_walked)
         atomicAdd(total + 5, (unsigned long long)n_walked);
+#ifdef DRT_WALK_TIMES
+    if (lane == 0 && stat_wave < 8192) {
+        g_walk_times[stat_wave][1] = stat_dry_at;
+        g_walk_times[stat_wave][2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------

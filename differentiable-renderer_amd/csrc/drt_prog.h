@@ -15,31 +15,63 @@ __device__ inline void prog_accept(float t, int s, float& tmin, int& prim)
     }
 }
 
+// t of one record, every product-sum written as explicit fma chains: the kind-sorted program evaluates a record a
+// second time when it has seen an exact tie (below), and both evaluations must agree in all 32 bits whatever the
+// compiler's contraction choices would have been.  Returns false where the reference's predicate cannot hold
+// (sphere: negative discriminant).
+template <int KIND>
+__device__ inline bool prog_t(const float4 r, V3<float> o, V3<float> d, V3<float> inv_d, float& t)
+{
+    if (KIND == DRT_PK_AX) {
+        t = (r.x - o.x) * inv_d.x;
+    } else if (KIND == DRT_PK_AY) {
+        t = (r.x - o.y) * inv_d.y;
+    } else if (KIND == DRT_PK_AZ) {
+        t = (r.x - o.z) * inv_d.z;
+    } else if (KIND == DRT_PK_PLANE) {
+        const float h = fmaf(o.z, r.z, fmaf(o.y, r.y, o.x * r.x)) - r.w;
+        const float den = fmaf(d.z, r.z, fmaf(d.y, r.y, d.x * r.x));
+        t = h * __builtin_amdgcn_rcpf(-den);
+    } else {                                 // sphere: b' = oc.d, disc' = b'^2 - (oc.oc - r^2), t = -b' -+ sqrt(disc')
+        const V3<float> oc = mk<float>(o.x - r.x, o.y - r.y, o.z - r.z);
+        const float bh = fmaf(oc.z, d.z, fmaf(oc.y, d.y, oc.x * d.x));
+        const float cc = fmaf(-r.w, r.w, fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, oc.x * oc.x)));
+        const float disc = fmaf(bh, bh, -cc);
+        if (!(disc >= 0.f))                  // (NaN fails, as in the reference; the branch-free form -- sqrt of a negative
+            return false;                    // = NaN, which fails `t > 0` -- was measured 4 % slower)
+        const float sq = __builtin_amdgcn_sqrtf(disc);
+        const float t1 = -bh - sq, t2 = sq - bh;
+        t = t1 > 0.f ? t1 : t2;
+    }
+    return true;
+}
+
 template <int KIND>
 __device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float& tmin, int& prim)
 {
-    if (KIND == DRT_PK_AX) {
-        prog_accept((r.x - o.x) * inv_d.x, s, tmin, prim);
-    } else if (KIND == DRT_PK_AY) {
-        prog_accept((r.x - o.y) * inv_d.y, s, tmin, prim);
-    } else if (KIND == DRT_PK_AZ) {
-        prog_accept((r.x - o.z) * inv_d.z, s, tmin, prim);
-    } else if (KIND == DRT_PK_PLANE) {
-        const float h = o.x * r.x + o.y * r.y + o.z * r.z - r.w;
-        const float den = d.x * r.x + d.y * r.y + d.z * r.z;
-        prog_accept(h * __builtin_amdgcn_rcpf(-den), s, tmin, prim);
-    } else {                                 // sphere: b' = oc.d, disc' = b'^2 - (oc.oc - r^2), t = -b' -+ sqrt(disc')
-        const V3<float> oc = mk<float>(o.x - r.x, o.y - r.y, o.z - r.z);
-        const float bh = dot(oc, d);
-        const float cc = dot(oc, oc) - r.w * r.w;
-        const float disc = bh * bh - cc;
-        if (disc >= 0.f) {                   // (NaN fails, as in the reference; the branch-free form -- sqrt of a negative
-                                             // = NaN, which fails `t > 0` -- was measured 4 % slower)
-            const float sq = __builtin_amdgcn_sqrtf(disc);
-            const float t1 = -bh - sq, t2 = sq - bh;
-            prog_accept(t1 > 0.f ? t1 : t2, s, tmin, prim);
-        }
+    float t;
+    if (prog_t<KIND>(r, o, d, inv_d, t))
+        prog_accept(t, s, tmin, prim);
+}
+
+// the kind-sorted program's version: also notes an exact tie with the closest hit so far (see closest_hit_prog)
+template <int KIND>
+__device__ inline void prog_test_tie(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float& tmin, int& prim, bool& tie)
+{
+    float t;
+    if (prog_t<KIND>(r, o, d, inv_d, t)) {
+        tie = tie || t == tmin;
+        prog_accept(t, s, tmin, prim);
     }
+}
+
+// second pass after a tie: among the shapes whose t equals the closest hit bit for bit, the FIRST IN SCENE ORDER wins
+template <int KIND>
+__device__ inline void prog_resolve_tie(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float tmin, int& prim)
+{
+    float t;
+    if (prog_t<KIND>(r, o, d, inv_d, t) && t == tmin && s < prim)
+        prim = s;
 }
 
 // The records of the program, as the bounce loop sees them.  SIG != 0 (kinds fixed at compile time, 3 bits per shape,
@@ -86,15 +118,18 @@ __device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restri
     } else {
         // kinds not compiled in: the records sorted by kind (upload), one counted loop per kind -- no branch on the kind,
         // no scalar load: every lane reads the SAME record from LDS (a broadcast read), the next record is requested
-        // while the current one is tested.  Inside a kind the scene order is kept, so the first shape wins ties
-        // (pathtracer.hpp:80); an exact tie between shapes of DIFFERENT kinds goes to the kind tested first (planes
-        // before spheres) -- t values from two different formulas agreeing in all 32 bits; the f64 mode keeps the
-        // literal loop.
+        // while the current one is tested.  Inside a kind the scene order is kept, but an exact tie between shapes of
+        // DIFFERENT kinds (two formulas agreeing in all 32 bits) would go to the kind tested first instead of the
+        // earlier shape (pathtracer.hpp:80).  So every test also notes whether its t EQUALS the closest hit so far
+        // (one compare): any shape that ties with the final winner is seen that way -- tested after the winner it meets
+        // tmin == t, tested before it IS the winner and the later one meets it -- and a wave in which some lane saw a tie
+        // (in practice never) walks the records once more, giving the hit to the smallest shape index among the equals.
         const ProgLds& pl = *recs.lds;
+        bool tie = false;
 #define DRT_KIND_LOOP(K)                                                              \
         for (int i = pl.kind_begin[K]; i < pl.kind_begin[K + 1]; ++i) {               \
             const float4 r = pl.rec[i];                                               \
-            prog_test<K>(r, pl.shape[i], o, d, inv_d, tmin, prim);                    \
+            prog_test_tie<K>(r, pl.shape[i], o, d, inv_d, tmin, prim, tie);           \
         }
         DRT_KIND_LOOP(DRT_PK_AX)
         DRT_KIND_LOOP(DRT_PK_AY)
@@ -102,6 +137,19 @@ __device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restri
         DRT_KIND_LOOP(DRT_PK_PLANE)
         DRT_KIND_LOOP(DRT_PK_SPHERE)
 #undef DRT_KIND_LOOP
+        if (__any(tie && prim >= 0)) {
+#define DRT_KIND_LOOP(K)                                                              \
+            for (int i = pl.kind_begin[K]; i < pl.kind_begin[K + 1]; ++i) {           \
+                const float4 r = pl.rec[i];                                           \
+                prog_resolve_tie<K>(r, pl.shape[i], o, d, inv_d, tmin, prim);         \
+            }
+            DRT_KIND_LOOP(DRT_PK_AX)
+            DRT_KIND_LOOP(DRT_PK_AY)
+            DRT_KIND_LOOP(DRT_PK_AZ)
+            DRT_KIND_LOOP(DRT_PK_PLANE)
+            DRT_KIND_LOOP(DRT_PK_SPHERE)
+#undef DRT_KIND_LOOP
+        }
     }
     HitRec<float> h;
     h.t = tmin;

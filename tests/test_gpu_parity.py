@@ -651,3 +651,41 @@ def test_eight_parameters_every_walls_albedo(pkg, hip, oracle):
         # the queue wavefront (tape + K6) gives the same gradients
         _, gq, stq = hip.render(cam, dataclasses_replace(rp, bounces_per_launch=1), backward=True, f64=True)
         assert stq["kernels"]["path"]["launches"] == 0 and grad_rel_err(gq, g) < 1e-9
+
+
+def tie_scene(pkg, general_first=True):
+    """The Cornell box with its back wall doubled: the SAME plane z = 6 once as a general plane record (normal (0, 0, -2),
+    offset -12) and once as an axis plane (normal (0, 0, -1), offset -6).  Both forms give bit-identical t in f32 and in
+    f64 (power-of-two scalings are exact; v_rcp is exact under them), so every ray that reaches the wall is an exact tie
+    between shapes of two different KINDS of the device's intersection program -- which the reference resolves by scene
+    order (pathtracer.hpp:80: `t >= tmin` skips).  The two copies carry different albedo parameters."""
+    s = pkg.cornell_box()
+    first = s.diffuse(s.parameter((0.7, 0.3, 0.2), True, "wall_first"))
+    second = s.diffuse(s.parameter((0.2, 0.3, 0.7), True, "wall_second"))
+    general = (pkg.SHAPE_PLANE, first if general_first else second, -1, (0., 0., -2., -12.))
+    axis = (pkg.SHAPE_PLANE, second if general_first else first, -1, (0., 0., -1., -6.))
+    pair = [general, axis] if general_first else [axis, general]
+    s.shapes[4:5] = pair                                   # in place of the back wall (render.cpp:43)
+    return s
+
+
+@pytest.mark.parametrize("general_first", [True, False])
+def test_exact_tie_between_kinds_goes_to_the_earlier_shape(pkg, hip, oracle, general_first):
+    """pathtracer.hpp:80 on the device's kind-sorted program (axis planes are tested before general planes whatever the
+    scene order): the earlier shape must win an exact tie.  The parameter of the later copy gets NO gradient at all, the
+    earlier one matches the oracle; every device route agrees."""
+    scene = tie_scene(pkg, general_first)
+    cam = pkg.cornell_camera(48, 40)
+    rp = pkg.RenderParams(spp=4, min_bounces=5, absorb=1.0, seed=9)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    i_first, i_second = scene.n_params - 2, scene.n_params - 1
+    assert np.abs(ref["grads"][i_first]).max() > 0 and np.abs(ref["grads"][i_second]).max() == 0
+    hip.upload_scene(scene)
+    import dataclasses
+    for kw in (dict(), dict(f64=True)):
+        for bpl in (0, 1):                                 # k_path (kind-sorted program) and the queue wavefront
+            img, grads, stats = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=bpl), backward=True, **kw)
+            assert np.abs(grads[i_second]).max() == 0, (kw, bpl, grads[i_second])
+            assert grad_rel_err(grads, ref["grads"]) <= (1e-9 if kw else GRAD_TOL)
+            if kw:
+                assert stats["segments"] == ref["stats"]["segments"]

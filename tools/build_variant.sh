@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build a variant of libdrt_hip.so into build/<name>.so with extra compiler flags (A/B experiments, debug counters).
+# Usage: tools/build_variant.sh <name> [-DFLAG ...]
+set -eu
+N=$1; shift
+mkdir -p build
+hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude "$@" \
+      -o build/$N.so differentiable-renderer_amd/csrc/drt_hip.hip -lrccl
+echo "build/$N.so"

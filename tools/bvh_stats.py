@@ -21,3 +21,11 @@ print(f"per ray: node visits from LDS {lds / rays:.2f}, from memory {mem / rays:
 print(f"wave level: interior iterations {out[5]}, outer iterations {out[6]}, refill events {out[7]}; lanes busy per interior iteration {(lds + mem) / max(1, out[5]):.1f} of 64, "
       f"leaf lanes per outer iteration {leaves / max(1, out[6]):.1f}")
 print(f"16-byte lane accesses per ray: nodes {4 * mem / rays:.1f} + triangles {3 * tris / rays:.1f} + ray/hit 3")
+
+hist = (C.c_ulonglong * 24)()
+if hasattr(r.lib, "drt_hip_debug_bvh_hist") and r.lib.drt_hip_debug_bvh_hist(hist) == 0:
+    names = ["1", "2", "3-4", "5-8", "9-16", "17-32", "33-64", ">64"]
+    tot = sum(hist[i] for i in range(8)); totv = sum(hist[16 + i] for i in range(8))
+    print("rays by node visits:   " + "  ".join(f"{n}: {100 * hist[i] / tot:.1f}%" for i, n in enumerate(names)))
+    print("their share of visits: " + "  ".join(f"{n}: {100 * hist[16 + i] / totv:.1f}%" for i, n in enumerate(names)))
+    print("ending on a triangle:  " + "  ".join(f"{n}: {100 * hist[8 + i] / max(1, hist[i]):.0f}%" for i, n in enumerate(names)) + f"   (all rays: {100 * sum(hist[8 + i] for i in range(8)) / tot:.1f}%)")

@@ -12,7 +12,7 @@ for set in "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
   d=$OUT/set$i
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$d" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-views "$@" > /dev/null 2> "$d.err" || { echo "bench.py failed under rocprofv3 (set $i): see $d.err" >&2; tail -5 "$d.err" >&2; exit 1; }
   python3 - "$d" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 if not f:
     print("no csv in", sys.argv[1]); sys.exit()
@@ -21,7 +21,7 @@ for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"].split("(")[0][:28]
     d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in d:
-    if any(x in k for x in ("k_shade", "k_intersect", "k_backward", "k_raygen")):
+    if any(x in k for x in os.environ.get("PMC_KERNELS", "k_shade,k_intersect,k_backward,k_raygen").split(",")):
         print(k, {c: "%.4g" % (sum(v) / len(v)) for c, v in d[k].items()})
 PY
 done
