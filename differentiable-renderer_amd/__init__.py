@@ -37,7 +37,7 @@ RENDER_ALLREDUCE = 0x40
 MAX_DEPTH = 64
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]
-ABI_VERSION = 4
+ABI_VERSION = 5
 UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3: "DRT_ERR_HIP",
@@ -445,7 +445,7 @@ class DrtHipError(RuntimeError):
 _ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_create_group",
                 "drt_hip_group_size", "drt_hip_destroy",
                 "drt_hip_comm_unique_id", "drt_hip_comm_init_rank", "drt_hip_comm_size", "drt_hip_comm_destroy",
-                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render",
+                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render", "drt_hip_render_async", "drt_hip_wait",
                 "drt_hip_render_gradient_image", "drt_hip_stream",
                 "drt_hip_synchronize", "drt_hip_last_error", "drt_hip_kernel_name"]
 
@@ -474,6 +474,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.drt_hip_update_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.drt_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
+    lib.drt_hip_render_async.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.drt_hip_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(HipStats)]
     lib.drt_hip_render_gradient_image.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
                                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
     lib.drt_hip_stream.argtypes = [C.c_void_p]
@@ -580,6 +583,35 @@ class HipRenderer:
                                      C.byref(stats))
         self._check(rc, "drt_hip_render")
         return img, grads, stats.as_dict()
+
+    def render_async(self, cam: Camera, rp: RenderParams, backward: bool = False, adjoint: Optional[np.ndarray] = None,
+                     f64: bool = False, unbiased: bool = False):
+        """drt_hip_render_async: enqueue one host-buffer frame -> a handle for wait().  At most two frames in flight."""
+        assert self.scene is not None
+        flags = rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC | RENDER_TIMING)
+        flags |= (RENDER_BACKWARD if backward else 0) | (RENDER_F64 if f64 else 0) | (RENDER_UNBIASED if unbiased else 0)
+        d = rp.to_desc()
+        d.flags = flags
+        img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        grads = np.zeros((self.scene.n_params, 3), dtype=np.float64) if backward else None
+        adj_ptr = None
+        if adjoint is not None:
+            adjoint = np.ascontiguousarray(adjoint, dtype=np.float32)
+            assert adjoint.shape == (cam.height, cam.width, 3)
+            adj_ptr = adjoint.ctypes.data_as(C.c_void_p)
+        ticket = C.c_uint64(0)
+        cd = cam.to_desc()
+        rc = self.lib.drt_hip_render_async(self.ctx, C.byref(cd), C.byref(d), adj_ptr, img.ctypes.data_as(C.c_void_p),
+                                           grads.ctypes.data_as(C.c_void_p) if backward else None, C.byref(ticket))
+        self._check(rc, "drt_hip_render_async")
+        return (int(ticket.value), img, grads)      # (the arrays are filled by wait())
+
+    def wait(self, handle, want_stats: bool = True):
+        """drt_hip_wait: -> (image, grads or None, stats dict) of the frame render_async() enqueued."""
+        ticket, img, grads = handle
+        stats = HipStats()
+        self._check(self.lib.drt_hip_wait(self.ctx, ticket, C.byref(stats) if want_stats else None), "drt_hip_wait")
+        return img, grads, (stats.as_dict() if want_stats else {})
 
     def render_gradient_image(self, cam: Camera, rp: RenderParams, param: int,
                               adjoint: Optional[np.ndarray] = None, f64: bool = False):

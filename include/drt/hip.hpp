@@ -259,19 +259,30 @@ public:
     {
         const uint64_t key = flat.topology_key();
         if (m_has_scene && key == m_scene_key) {
+            if (flat.params == m_params)       // nothing changed (drt_hip_update_params waits for the frames in flight)
+                return;
             check(drt_hip_update_params(m_ctx, flat.params.data()), "drt_hip_update_params");
+            m_params = flat.params;
             return;
         }
         const drt_scene_desc sd = flat.desc();
         m_has_scene = false;
         check(drt_hip_upload_scene(m_ctx, &sd), "drt_hip_upload_scene");
         m_scene_key = key;
+        m_params = flat.params;
         m_has_scene = true;
     }
 
 private:
     drt_hip_ctx* m_ctx = nullptr;
     uint64_t m_scene_key = 0;
+    std::vector<double> m_params;      // the parameter values the device holds
+public:
+    // host buffers of the (at most two) frames in flight: kept, so that a frame costs no 3 MB allocation
+    std::vector<float> frame_pool[2];
+    std::vector<double> grad_pool[2];
+    unsigned submitted = 0;
+private:
     bool m_has_scene = false;
     std::mutex m_mutex;        // a context is not thread-safe: pooled ones are locked for the duration of a call
 };
@@ -380,6 +391,126 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
         }
     }
     return total;
+}
+
+// ---- frames in flight ----------------------------------------------------------------------------------
+// render() returns with the frame in `img`: a device-to-host copy and a wait per call, the GPU idle meanwhile.  A loop
+// that renders frame after frame (several views or mini-batches per optimisation step, a turntable) submits the next
+// frame before it collects the previous one:
+//     auto a = drt::hip::submit(scene, cam, tracer, spp, img_a, opt);
+//     auto b = drt::hip::submit(scene, cam, tracer, spp, img_b, opt);   // at most two in flight per device context
+//     a.get();  b.get();             // img_* filled, gradients ADDED into param.grad() (vector.hpp:185-188) at get()
+// (drt_hip_render_async / drt_hip_wait: frame i's results travel to a pinned block while frame i + 1's kernels run.)
+// One device (opt.devices[0]); the frames of one context belong to one thread; the scene's geometry must not change
+// between submit and get (parameter values may: a submit uploads them).
+template <typename T>
+class Pending {
+public:
+    Pending() = default;
+    Pending(Pending&& o) noexcept { *this = std::move(o); }
+    Pending& operator=(Pending&& o) noexcept
+    {
+        m_ctx = o.m_ctx; o.m_ctx = nullptr;            // (the source no longer owns a frame)
+        m_ticket = o.m_ticket; m_img = o.m_img; m_backward = o.m_backward;
+        m_frame = o.m_frame; m_grads = o.m_grads; m_npix = o.m_npix;
+        m_requires_grad = std::move(o.m_requires_grad); m_handles = std::move(o.m_handles);
+        return *this;
+    }
+    Pending(const Pending&) = delete;
+    Pending& operator=(const Pending&) = delete;
+    bool valid() const { return m_ctx != nullptr; }
+    // wait for the frame, hand it over, accumulate its gradients
+    Stats get()
+    {
+        if (!m_ctx)
+            throw std::runtime_error("drt::hip::Pending::get: no frame");
+        drt_hip_stats st{};
+        Context* ctx = m_ctx;
+        m_ctx = nullptr;
+        ctx->check(drt_hip_wait(ctx->get(), m_ticket, &st), "drt_hip_wait");
+        const std::size_t npix = m_npix;
+        for (std::size_t i = 0; i < npix; ++i)
+            for (int c = 0; c < 3; ++c)
+                m_img[i][c] = T(m_frame[i * 3 + c]);
+        if (m_backward)
+            for (std::size_t p = 0; p < m_handles.size(); ++p) {
+                if (!m_requires_grad[p])
+                    continue;
+                Vector<T, 3> g(T(0));
+                for (int c = 0; c < 3; ++c)
+                    g[c] = T(m_grads[p * 3 + c]);
+                m_handles[p].grad() += g;
+            }
+        Stats total;
+        total.paths = st.paths;
+        total.segments = st.segments;
+        total.capped_paths = st.capped_paths;
+        total.ms = st.ms_total;
+        return total;
+    }
+
+private:
+    template <typename U>
+    friend Pending<U> submit(const Scene<U>&, const Camera<U>&, const Pathtracer<U>&, std::size_t, Vector<U, 3>*, const Options&,
+                             const Vector<U, 3>*);
+    Context* m_ctx = nullptr;
+    uint64_t m_ticket = 0;
+    Vector<T, 3>* m_img = nullptr;
+    bool m_backward = false;
+    float* m_frame = nullptr;                   // written by drt_hip_wait: buffers of the context's pool (two frames in flight)
+    double* m_grads = nullptr;
+    std::size_t m_npix = 0;
+    std::vector<uint8_t> m_requires_grad;
+    std::vector<Vector<T, 3, true>> m_handles;
+};
+
+template <typename T>
+inline Pending<T> submit(const Scene<T>& scene, const Camera<T>& cam, const Pathtracer<T>& tracer, std::size_t spp,
+                         Vector<T, 3>* img, const Options& opt = Options(), const Vector<T, 3>* adjoint = nullptr)
+{
+    if (opt.devices.size() != 1)
+        throw std::runtime_error("drt::hip::submit: one device (frames in flight are per device context)");
+    FlatScene<T> flat = flatten(scene);
+    const drt_camera_desc cd = describe(cam);
+    const std::size_t npix = cam.width() * cam.height();
+    std::vector<float> adj;
+    if (adjoint) {
+        adj.resize(npix * 3);
+        for (std::size_t i = 0; i < npix; ++i)
+            for (int c = 0; c < 3; ++c)
+                adj[i * 3 + c] = float(real(adjoint[i][c]));
+    }
+    Pending<T> f;
+    f.m_img = img;
+    f.m_backward = opt.backward;
+    f.m_requires_grad = flat.requires_grad;
+    f.m_handles = flat.handles;
+    Context& ctx = pooled_context(opt.devices);
+    const unsigned slot = ctx.submitted & 1u;   // (the library refuses a third frame in flight: its buffers are free again)
+    if (ctx.frame_pool[slot].size() < npix * 3) ctx.frame_pool[slot].resize(npix * 3);
+    if (ctx.grad_pool[slot].size() < flat.requires_grad.size() * 3) ctx.grad_pool[slot].resize(flat.requires_grad.size() * 3);
+    f.m_frame = ctx.frame_pool[slot].data();
+    f.m_grads = ctx.grad_pool[slot].data();
+    f.m_npix = npix;
+    ctx.set_scene(flat);
+    drt_render_params rp{};
+    rp.spp = (int32_t)spp;
+    rp.min_bounces = (int32_t)tracer.min_bounces();
+    rp.absorb = tracer.absorb();
+    rp.max_depth = opt.max_depth;
+    rp.seed = opt.seed;
+    rp.n_shards = 1;
+    rp.band_rows = opt.band_rows;
+    rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
+               (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
+    rp.batch_paths = opt.batch_paths;
+    rp.bounces_per_launch = opt.bounces_per_launch;
+    ctx.check(drt_hip_render_async(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, f.m_frame,
+                                   opt.backward ? f.m_grads : nullptr, &f.m_ticket),
+              "drt_hip_render_async");
+    ++ctx.submitted;
+    f.m_ctx = &ctx;
+    return f;
 }
 
 // Per-pixel gradient image of ONE parameter (the figure of the reference's README.md:142-145):

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 4
+#define DRT_HIP_ABI_VERSION 5
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -234,6 +234,18 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad,
                    drt_hip_stats* stats);
+/* The same call WITHOUT the wait at its end, for callers that render frame after frame (the loop of src/render.cpp:72-90
+ * inside an optimisation loop): drt_hip_render_async enqueues the frame and returns a ticket; the results travel to a
+ * pinned block of the context on a second stream while the NEXT frame's kernels run, and drt_hip_wait(ticket) hands them
+ * to out_rgb / out_param_grad (plain memcpy) and fills `stats` (totals only; no per-kernel times).  Buffer lifetime: out_rgb,
+ * out_param_grad must stay valid until drt_hip_wait returns -- they are written THERE, by the calling thread; adjoint_rgb is
+ * consumed before drt_hip_render_async returns.  At most TWO frames are in flight (a third drt_hip_render_async before the
+ * oldest was waited for returns DRT_ERR_INVALID), tickets are waited for in order of issue, and drt_hip_render /
+ * drt_hip_render_gradient_image refuse to run while frames are in flight.  Host buffers only; a plain (non-group) context.
+ * Results are bit-identical to drt_hip_render's. */
+int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
+                         const float* adjoint_rgb, float* out_rgb, double* out_param_grad, uint64_t* ticket);
+int drt_hip_wait(drt_hip_ctx* ctx, uint64_t ticket, drt_hip_stats* stats /* may be NULL */);
 /* Per-pixel gradient image (the figure of the reference's README.md:142-145): like drt_hip_render
  * with DRT_RENDER_BACKWARD, but instead of one summed gradient vector it returns
  *   out_grad_rgb[pixel] = mean over the pixel's samples of d(seed . radiance) / d params[param]

@@ -89,6 +89,34 @@ int main(int argc, const char* argv[])
                 std::printf("call %d: %.3f ms\n", it,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count());
         }
+        if (args.repeat > 2 && args.devices.size() == 1) {
+            // the same frames with two in flight (drt::hip::submit / Pending::get): frame i's copy to the host overlaps
+            // frame i + 1's kernels.  (The first two frames set up the second set of buffers: timed from the third on.)
+            std::vector<Vector<double, 3>> img2(width * height, Vector<double, 3>(0.));
+            auto zero_grads = [&]() {
+                for (Vector<T, 3, true>* p : {&red, &green, &white, &emission})
+                    p->grad() = Vector<T, 3>(0.);
+            };
+            const int n_pipe = args.repeat + 2;
+            auto tp = std::chrono::steady_clock::now();
+            hip::Pending<T> prev;
+            for (int it = 0; it < n_pipe; ++it) {
+                if (it == 2)
+                    tp = std::chrono::steady_clock::now();
+                hip::Pending<T> cur = hip::submit(scene, cam, tracer, args.samples, (it & 1) ? img2.data() : img.data(), opt);
+                if (prev.valid()) {
+                    zero_grads();
+                    prev.get();
+                }
+                prev = std::move(cur);
+            }
+            zero_grads();
+            prev.get();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count() / args.repeat;
+            if ((n_pipe - 1) & 1)
+                img = img2;                    // (the last frame went to img2)
+            std::printf("pipelined (two frames in flight): %.3f ms per frame\n", ms);
+        }
     } else {
         // the reference's loop on the host API, drawing the same per-path RNG streams
         for (std::size_t y = 0; y < cam.height(); ++y) {

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = C.CDLL(pkg.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(lib, s), f"libdrt_hip.so does not export {s}"
-    assert pkg.load_library().drt_hip_abi_version() == pkg.ABI_VERSION == 4   # v2 meshes, v3 queue statistics, v4 groups + communicators
+    assert pkg.load_library().drt_hip_abi_version() == pkg.ABI_VERSION == 5   # v2 meshes, v3 queue statistics, v4 groups + communicators, v5 asynchronous host-buffer renders
     assert sorted(pkg._ABI_SYMBOLS) == declared_symbols()
 
 

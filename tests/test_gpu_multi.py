@@ -134,3 +134,45 @@ def test_bench_single_rank_under_torchrun_uses_the_library_collective():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert line["n_gpus"] == 1 and "library all-reduce" in line["config"]["parallelism"]
+
+
+def test_async_host_renders_match_the_synchronous_call_bit_for_bit(pkg, hip):
+    """drt_hip_render_async / drt_hip_wait: two frames in flight, the copies of frame i overlap frame i + 1's kernels;
+    images, gradients and segment counts equal drt_hip_render's exactly; the documented refusals hold."""
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(96, 64)
+    hip.upload_scene(scene)
+    rps = [pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=s) for s in (1, 2, 3, 4, 5)]
+    ref = [hip.render(cam, rp, backward=True) for rp in rps]
+    handles, got = [], []
+    for i, rp in enumerate(rps):
+        handles.append(hip.render_async(cam, rp, backward=True))
+        if len(handles) == 2:                              # frame i is enqueued, frame i - 1 is collected
+            got.append(hip.wait(handles.pop(0)))
+    got.append(hip.wait(handles.pop(0)))
+    for (img, grads, st), (rimg, rgrads, rst) in zip(got, ref):
+        np.testing.assert_array_equal(img, rimg)
+        np.testing.assert_array_equal(grads, rgrads)
+        assert st["segments"] == rst["segments"] and st["paths"] == rst["paths"]
+    # a third frame while two are in flight, a synchronous render while frames are in flight, an unknown ticket: refused
+    h1 = hip.render_async(cam, rps[0], backward=True)
+    h2 = hip.render_async(cam, rps[1], backward=True)
+    with pytest.raises(pkg.DrtHipError, match="two frames are in flight"):
+        hip.render_async(cam, rps[2], backward=True)
+    with pytest.raises(pkg.DrtHipError, match="in flight"):
+        hip.render(cam, rps[2], backward=True)
+    with pytest.raises(pkg.DrtHipError, match="no such frame"):
+        hip.wait((h2[0] + 5, h2[1], h2[2]))
+    a = hip.wait(h1)
+    b = hip.wait(h2)
+    np.testing.assert_array_equal(a[0], ref[0][0])
+    np.testing.assert_array_equal(b[1], ref[1][1])
+    # mesh scenes (the queue wavefront) and an adjoint image go through the same path
+    mesh = pkg.scene_by_name("mesh10x12")
+    hip.upload_scene(mesh)
+    adj = np.random.RandomState(3).uniform(-1, 2, (64, 96, 3)).astype(np.float32)
+    rref = hip.render(cam, rps[0], backward=True, adjoint=adj)
+    h = hip.render_async(cam, rps[0], backward=True, adjoint=adj)
+    r = hip.wait(h)
+    np.testing.assert_array_equal(r[0], rref[0])
+    np.testing.assert_array_equal(r[1], rref[1])

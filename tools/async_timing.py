@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Host-buffer renders of config 3's frame: drt_hip_render (synchronous) against drt_hip_render_async / drt_hip_wait
+with two frames in flight; where the time of the pipelined loop goes (submit, wait)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+pkg = e.load_package()
+r = pkg.HipRenderer(0)
+r.upload_scene(pkg.cornell_box())
+cam = pkg.cornell_camera(512, 512)
+rp = pkg.RenderParams(spp=64, min_bounces=8, absorb=1.0, seed=1)
+for _ in range(3):
+    r.render(cam, rp, backward=True)
+n = 20
+t0 = time.perf_counter()
+for _ in range(n):
+    r.render(cam, rp, backward=True)
+print(f"drt_hip_render: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per frame")
+r.wait(r.render_async(cam, rp, backward=True))
+ts, tw = [], []
+t0 = time.perf_counter()
+prev = None
+for _ in range(n):
+    a = time.perf_counter()
+    h = r.render_async(cam, rp, backward=True)
+    b = time.perf_counter()
+    if prev is not None:
+        r.wait(prev, want_stats=False)
+    c = time.perf_counter()
+    ts.append(b - a); tw.append(c - b)
+    prev = h
+r.wait(prev)
+print(f"render_async + wait, two in flight: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per frame (submit {np.median(ts) * 1e3:.3f}, wait {np.median(tw) * 1e3:.3f})")
