@@ -114,8 +114,14 @@ def parse_args(argv):
                     help="nccl (= RCCL, the real thing) | gloo: rendezvous only, lets ranks share ONE GPU to exercise the "
                          "N > 1 path on a single-GPU box (with --same-gpu); the numbers of such a run mean nothing")
     ap.add_argument("--same-gpu", action="store_true", help="every rank uses device 0 (testing only)")
+    ap.add_argument("--store-n1", action="store_true",
+                    help="1-GPU runs: store value under this workload's key in profiles/n1_reference.json (N > 1 runs print "
+                         "weak_scaling.efficiency against it)")
     ap.add_argument("--reduce", default="library", choices=["library", "torch"],
                     help="where the gradient all-reduce runs: inside libdrt_hip.so (RCCL, default) or torch.distributed")
+    ap.add_argument("--allreduce", default="async", choices=["async", "stream"],
+                    help="library all-reduce on the context's second stream, overlapping the next step (async, default) or "
+                         "in stream order between two steps (stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the oracle on every host core (independent row-band processes)")
@@ -180,7 +186,10 @@ def main():
             if rank == 0:
                 print("bench.py: in-library communicator unavailable; reducing with torch.distributed", file=sys.stderr)
             reduce_mode = "torch"
-    flags = (pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0) | (pkg.RENDER_ALLREDUCE if reduce_mode == "library" else 0)
+    # the library's all-reduce runs on the context's second stream and overlaps the next step's kernels
+    # (DRT_RENDER_ALLREDUCE_ASYNC; the steps alternate between two gradient buffers, the fence waits for both streams)
+    flags = (pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0) | \
+            ((pkg.RENDER_ALLREDUCE_ASYNC if a.allreduce == "async" else pkg.RENDER_ALLREDUCE) if reduce_mode == "library" else 0)
     rp = pkg.RenderParams(spp=a.spp * world, min_bounces=a.min_bounces, absorb=a.absorb, seed=1,
                           shard=rank, n_shards=world, band_rows=16, batch_paths=a.batch_paths,
                           flags=flags, bounces_per_launch=a.bounces_per_launch)
@@ -487,11 +496,30 @@ def main():
                         "sync": {"value": round(total_segments / dt3 * 1e-6, 2), "ms_per_step": round(dt3 * 1e3, 4),
                                  "note": "drt_hip_render: returns with the results in the caller's buffers"}}
 
+    # N > 1: efficiency against the stored single-GPU value of the SAME per-GPU workload (profiles/n1_reference.json, written by
+    # a 1-GPU run with --store-n1; the driver computes its own figure from its own N = 1 run)
+    weak_scaling = None
+    n1_path = os.path.join(ROOT, "profiles", "n1_reference.json")
+    if rank == 0:
+        try:
+            n1 = json.load(open(n1_path)) if os.path.exists(n1_path) else {}
+        except Exception:
+            n1 = {}
+        if world == 1 and a.store_n1 and not use_dist:
+            n1[workload_key] = {"value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(ms_per_step, 4)}
+            json.dump(n1, open(n1_path, "w"), indent=1, sort_keys=True)
+        if world > 1 and workload_key in n1:
+            ref1 = n1[workload_key]["value"]
+            weak_scaling = {"efficiency": round(value / (world * ref1), 4), "n1_value": ref1, "unit": "Mray/s",
+                            "note": f"value / ({world} x the stored 1-GPU value of this per-GPU workload, profiles/n1_reference.json)"}
+        elif world > 1:
+            weak_scaling = {"efficiency": None, "note": f"no stored 1-GPU value for '{workload_key}' (run bench.py --store-n1 on one GPU)"}
+
     if rank == 0:
         what = "fwd+bwd" if backward else "fwd"
         if world > 1:
             par = (f"{dist.get_world_size()} ranks x 1 GPU ({'; '.join(devices)}): interleaved 16-row bands, ONE "
-                   f"{'ncclAllReduce(sum, f64, P x 3) inside libdrt_hip.so' if reduce_mode == 'library' else 'torch.distributed all_reduce'}"
+                   f"{('ncclAllReduce(sum, f64, P x 3) inside libdrt_hip.so' + (' on its second stream (overlaps the next step)' if a.allreduce == 'async' else '')) if reduce_mode == 'library' else 'torch.distributed all_reduce'}"
                    f" per step" + (" [ranks share device 0: plumbing test, numbers meaningless]" if a.same_gpu else ""))
         elif use_dist:
             par = f"1 rank, 1 GPU ({devices[0]}); gradient through the {reduce_mode or 'no'} all-reduce of a 1-rank communicator"
@@ -509,6 +537,7 @@ def main():
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
                        "parallelism": par, "batches_per_step": stats["batches"],
                        "capped_paths_per_step": stats["capped_paths"]},
+            "weak_scaling": weak_scaling,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
             "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view,
         }

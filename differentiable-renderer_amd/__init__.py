@@ -34,6 +34,7 @@ RENDER_TIMING = 0x8
 RENDER_F64 = 0x10
 RENDER_UNBIASED = 0x20
 RENDER_ALLREDUCE = 0x40
+RENDER_ALLREDUCE_ASYNC = 0x80
 MAX_DEPTH = 64
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]

@@ -100,6 +100,7 @@ struct drt_hip_ctx {
     RenderJob pending[2];
     bool in_flight[2] = {false, false};
     uint64_t next_ticket = 1;
+    uint64_t dev_frames = 0;              // renders made with DRT_RENDER_ALLREDUCE_ASYNC (their gradient set alternates)
     int slot = 0;                         // which of the double-buffered sets (grad, segtotal, out, h_stage) this render uses
     DevBuf probe;
     uint64_t bvh_bytes = 0;
@@ -1461,7 +1462,7 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     const bool f64 = (rp->flags & DRT_RENDER_F64) != 0;
     if (j.backward && !out_param_grad && gimg_param < 0 && !ctx->is_member)
         return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
-    if ((rp->flags & DRT_RENDER_ALLREDUCE) && j.backward && !ctx->comm && !ctx->is_member)
+    if ((rp->flags & (DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC)) && j.backward && !ctx->comm && !ctx->is_member)
         return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_ALLREDUCE on a context without a communicator (drt_hip_comm_init_rank)");
 
     j.t0 = std::chrono::steady_clock::now();
@@ -1532,16 +1533,45 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
 }
 
 // phase 2 (one process per GPU): THE collective of the path -- the P x 3 gradient accumulator summed over the ranks
-static int render_reduce(drt_hip_ctx* ctx)
+static int render_reduce(drt_hip_ctx* ctx, hipStream_t cs = nullptr)
 {
     RenderJob& j = ctx->job;
-    if (!(j.backward && (j.rp.flags & DRT_RENDER_ALLREDUCE) && ctx->comm && j.gimg_param < 0))
+    if (!(j.backward && (j.rp.flags & (DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC)) && ctx->comm && j.gimg_param < 0))
         return DRT_OK;
     const ncclResult_t r = ncclAllReduce(ctx->grad[ctx->slot].p, ctx->grad[ctx->slot].p, (size_t)ctx->n_user_params * 3, ncclDouble, ncclSum,
-                                         ctx->comm, ctx->stream);
+                                         ctx->comm, cs ? cs : ctx->stream);
     if (r != ncclSuccess) {
         ctx->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
         return DRT_ERR_COMM;
+    }
+    return DRT_OK;
+}
+
+// a render that carries an all-reduce failed on THIS rank before the collective was enqueued: the other ranks have
+// enqueued theirs (or will) and would wait for this one for ever -- abort the communicator, so that they fail instead
+static void abort_comm_after_failure(drt_hip_ctx* ctx, const drt_render_params* rp)
+{
+    if (ctx->comm && ctx->comm_size > 1 && rp && (rp->flags & DRT_RENDER_BACKWARD) &&
+        (rp->flags & (DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC))) {
+        (void)ncclCommAbort(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_size = 0;
+        ctx->err += " [the communicator was aborted: the other ranks' all-reduce fails instead of hanging]";
+    }
+}
+
+static int ensure_copy_stream(drt_hip_ctx* ctx)
+{
+    if (!ctx->copy_stream) {
+        // highest priority: the copies (and the all-reduce) of frame i must not queue behind the kernels of frame i + 1,
+        // which fill every CU
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->ev_rendered[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rendered[i], hipEventDisableTiming));
+        if (!ctx->ev_copied[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming));
     }
     return DRT_OK;
 }
@@ -1559,8 +1589,8 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t c
     if (j.backward && j.dev_out && j.out_param_grad && with_grad) {
         for (int p = 0; p < ctx->n_user_params; ++p)
             if (!ctx->requires_grad[p])
-                HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad[ctx->slot].p + (size_t)p * 3, 0, 3 * sizeof(double), ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(j.out_param_grad, ctx->grad[ctx->slot].p, (size_t)ctx->n_user_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync((double*)ctx->grad[ctx->slot].p + (size_t)p * 3, 0, 3 * sizeof(double), cs));
+        HIPCHK(ctx, hipMemcpyAsync(j.out_param_grad, ctx->grad[ctx->slot].p, (size_t)ctx->n_user_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, cs));
     }
     j.sync = !j.dev_out || (j.rp.flags & DRT_RENDER_SYNC) || j.timing || j.stats;
     j.img_bytes = npix_all * 3 * sizeof(float);
@@ -1692,7 +1722,7 @@ static int render_group(drt_hip_ctx* g, const drt_camera_desc* cam, const drt_re
         drt_render_params r = *rp;
         r.n_shards = outer * n;
         r.shard = outer_shard * n + i;
-        r.flags &= ~(uint32_t)DRT_RENDER_ALLREDUCE;        // the group reduces below
+        r.flags &= ~(uint32_t)(DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC);        // the group reduces below
         if ((rc = render_launch(g->members[i], cam, &r, adjoint_rgb, out_rgb, out_param_grad, stats ? &mstats[i] : nullptr,
                                 gimg_param, out_gimg)) != DRT_OK)
             return member_fail(i, rc);
@@ -1762,7 +1792,38 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     if (ctx->in_flight[0] || ctx->in_flight[1])
         return fail(ctx, DRT_ERR_INVALID, "render: asynchronous frames are in flight -- drt_hip_wait for them first");
     int rc;
-    if ((rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg)) != DRT_OK) return rc;
+    // DRT_RENDER_ALLREDUCE_ASYNC (device buffers, a communicator): the all-reduce and the copy of the reduced gradient run on
+    // the context's second stream while the NEXT render's kernels run on the first; the two gradient sets alternate, and a
+    // render only waits for the all-reduce of the render before the previous one (long finished)
+    const bool ar_async = rp && gimg_param < 0 && (rp->flags & DRT_RENDER_ALLREDUCE_ASYNC) && (rp->flags & DRT_RENDER_BACKWARD) &&
+                          (rp->flags & DRT_RENDER_DEVICE_OUT) && ctx->comm;
+    if (ar_async) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if ((rc = ensure_copy_stream(ctx)) != DRT_OK) return rc;
+        ctx->slot = (int)(ctx->dev_frames & 1);
+        if (ctx->dev_frames >= 2)
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[ctx->slot], 0));
+    }
+    rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
+    if (rc != DRT_OK) {
+        abort_comm_after_failure(ctx, rp);
+        ctx->slot = 0;
+        return rc;
+    }
+    if (ar_async) {
+        const int slot = ctx->slot;
+        hipError_t e = hipEventRecord(ctx->ev_rendered[slot], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rendered[slot], 0);
+        if (e != hipSuccess) { ctx->err = std::string("render: ") + hipGetErrorString(e); ctx->slot = 0; return DRT_ERR_HIP; }
+        if ((rc = render_reduce(ctx, ctx->copy_stream)) == DRT_OK) rc = render_collect(ctx, true, ctx->copy_stream);
+        if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream) != hipSuccess) rc = DRT_ERR_HIP;
+        ++ctx->dev_frames;
+        if (rc == DRT_OK && ctx->job.sync)
+            HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (rc == DRT_OK) rc = render_finish(ctx);
+        ctx->slot = 0;
+        return rc;
+    }
     if ((rc = render_reduce(ctx)) != DRT_OK) return rc;
     if ((rc = render_collect(ctx)) != DRT_OK) return rc;
     return render_finish(ctx);
@@ -1814,25 +1875,21 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     if (ctx->in_flight[slot])
         return fail(ctx, DRT_ERR_INVALID, "render_async: two frames are in flight already -- drt_hip_wait for the older one first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!ctx->copy_stream) {
-        // highest priority: the copies of frame i must not queue behind the kernels of frame i + 1, which fill every CU
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
-    }
-    for (int i = 0; i < 2; ++i) {
-        if (!ctx->ev_rendered[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rendered[i], hipEventDisableTiming));
-        if (!ctx->ev_copied[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming));
+    {
+        const int rc0 = ensure_copy_stream(ctx);
+        if (rc0 != DRT_OK) return rc0;
     }
     ctx->slot = slot;
     static drt_hip_stats sink;            // (render_launch only notes that totals are wanted; drt_hip_wait fills the caller's)
     int rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, &sink, -1, nullptr);
-    if (rc == DRT_OK) rc = render_reduce(ctx);
+    if (rc != DRT_OK)
+        abort_comm_after_failure(ctx, rp);
     if (rc == DRT_OK) {
         hipError_t e = hipEventRecord(ctx->ev_rendered[slot], ctx->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rendered[slot], 0);
         if (e != hipSuccess) { ctx->err = std::string("render_async: ") + hipGetErrorString(e); rc = DRT_ERR_HIP; }
     }
+    if (rc == DRT_OK) rc = render_reduce(ctx, ctx->copy_stream);     // (the all-reduce, too, overlaps the next frame)
     if (rc == DRT_OK) rc = render_collect(ctx, true, ctx->copy_stream);
     if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream) != hipSuccess) {
         ctx->err = "render_async: hipEventRecord failed";
@@ -1964,8 +2021,14 @@ int drt_hip_create_group(const int* device_ids, int n_devices, drt_hip_ctx** out
         }
     }
     std::vector<ncclComm_t> comms(distinct.size(), nullptr);
-    if (ncclCommInitAll(comms.data(), (int)distinct.size(), distinct.data()) != ncclSuccess) {
-        drt_hip_destroy(g);
+    const ncclResult_t cr = ncclCommInitAll(comms.data(), (int)distinct.size(), distinct.data());
+    if (cr != ncclSuccess) {
+        // (no context to carry the message: the caller gets the status, the RCCL text goes to stderr)
+        fprintf(stderr, "[drt_hip] drt_hip_create_group: ncclCommInitAll over %zu devices failed: %s\n", distinct.size(), ncclGetErrorString(cr));
+        for (ncclComm_t c : comms)
+            if (c)
+                (void)ncclCommAbort(c);
+        drt_hip_destroy(g);             // (destroys the members created so far; none of them holds a communicator yet)
         return DRT_ERR_COMM;
     }
     for (int i = 0, k = 0; i < n_devices; ++i)

@@ -25,18 +25,33 @@ def shard_params(rp, rank: int, world: int, band_rows: Optional[int] = None):
 def join_library_communicator(renderer, pkg, group=None) -> bool:
     """Give `renderer` (a HipRenderer of this rank) its rank in a communicator spanning the ranks of `group`.
     Collective.  -> True when every rank joined (renders may then carry RENDER_ALLREDUCE), False -- and no rank
-    keeps a communicator -- when any of them could not (e.g. two test ranks on one device)."""
+    keeps a communicator -- when any of them could not (e.g. two test ranks on one device).
+
+    ncclCommInitRank blocks until EVERY rank has entered it, so nobody may enter before all ranks are known to be
+    able to: rank 0's id is broadcast (None when it could not be made), every rank checks its own preconditions (a
+    plain context without a communicator) and the ranks agree (MIN) before the collective call."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    uid = [pkg.comm_unique_id() if rank == 0 else None]
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    uid = [None]
+    if rank == 0:
+        try:
+            uid = [pkg.comm_unique_id()]
+        except Exception:
+            uid = [None]
     dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ready = uid[0] is not None and renderer.group_size == 1 and renderer.comm_size == 0
+    ok = torch.tensor([1 if ready else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        return False
     joined = True
     try:
         renderer.comm_init(uid[0], rank, world)
     except pkg.DrtHipError:
         joined = False
-    ok = torch.tensor([1 if joined else 0], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    ok = torch.tensor([1 if joined else 0], device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if int(ok.item()) == 0 and joined:
         renderer.comm_destroy()

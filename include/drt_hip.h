@@ -133,6 +133,14 @@ typedef struct drt_camera_desc {
                                        the context's stream; out_param_grad is the sum over ALL ranks' shards.
                                        Every rank of the communicator must make the call.  (A group context
                                        always reduces; the flag is implied.) */
+#define DRT_RENDER_ALLREDUCE_ASYNC 0x80u /* like DRT_RENDER_ALLREDUCE, for renders with DRT_RENDER_DEVICE_OUT that follow each other
+                                       without a wait in between: the all-reduce and the copy of the reduced gradient into
+                                       out_param_grad are enqueued on a SECOND stream of the context and overlap the next render's
+                                       kernels (the ~30-60 us of an xGMI all-reduce of 96 bytes would otherwise stand between two
+                                       0.85 ms frames on every rank).  out_param_grad is valid after drt_hip_synchronize(ctx) (or
+                                       with DRT_RENDER_SYNC), NOT in the order of drt_hip_stream(ctx).  Alternate between two
+                                       out_param_grad buffers if every frame's gradient is wanted.  Without DRT_RENDER_DEVICE_OUT
+                                       the flag means DRT_RENDER_ALLREDUCE (drt_hip_render_async overlaps its all-reduce anyway). */
 #define DRT_RENDER_UNBIASED   0x20u /* with BACKWARD: the reference's unbiased integration operator
                                        (integrate.hpp:39-52, README.md:104-136): backward draws a
                                        FRESH direction at every vertex and traces a new suffix path

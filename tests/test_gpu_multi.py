@@ -176,3 +176,58 @@ def test_async_host_renders_match_the_synchronous_call_bit_for_bit(pkg, hip):
     r = hip.wait(h)
     np.testing.assert_array_equal(r[0], rref[0])
     np.testing.assert_array_equal(r[1], rref[1])
+
+
+def test_allreduce_on_the_second_stream_gives_the_same_gradients(pkg):
+    """DRT_RENDER_ALLREDUCE_ASYNC (device buffers, a communicator): all-reduce and gradient copy run on the context's second
+    stream, the steps alternate between two gradient sets; after drt_hip_synchronize every step's gradient equals the
+    stream-ordered DRT_RENDER_ALLREDUCE result (a 1-rank communicator: the collective call is made like on 8 GPUs)."""
+    import torch
+    r = pkg.HipRenderer(0)
+    try:
+        scene = pkg.cornell_box()
+        cam = pkg.cornell_camera(64, 48)
+        r.upload_scene(scene)
+        r.comm_init(pkg.comm_unique_id(), 0, 1)
+        dev = torch.device("cuda", 0)
+        out = torch.zeros((48, 64, 3), dtype=torch.float32, device=dev)
+        seeds = [1, 2, 3, 4, 5]
+        want = []
+        for s in seeds:
+            rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=s, flags=pkg.RENDER_ALLREDUCE)
+            g = torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev)
+            r.render_device(cam, rp, out.data_ptr(), g.data_ptr(), backward=True, sync=True)
+            want.append(g.cpu().numpy())
+        gs = [torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev) for _ in seeds]
+        for s, g in zip(seeds, gs):                          # five steps enqueued back to back, no wait in between
+            rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=s, flags=pkg.RENDER_ALLREDUCE_ASYNC)
+            r.render_device(cam, rp, out.data_ptr(), g.data_ptr(), backward=True, sync=False)
+        r.synchronize()
+        torch.cuda.synchronize(dev)
+        for g, w in zip(gs, want):
+            np.testing.assert_array_equal(g.cpu().numpy(), w)
+        # with DRT_RENDER_SYNC the call returns with the gradient in place
+        g = torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev)
+        rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=1, flags=pkg.RENDER_ALLREDUCE_ASYNC)
+        st = r.render_device(cam, rp, out.data_ptr(), g.data_ptr(), backward=True, sync=True, want_stats=True)
+        np.testing.assert_array_equal(g.cpu().numpy(), want[0])
+        assert st["segments"] > 0
+        # host buffers: the flag means DRT_RENDER_ALLREDUCE
+        _, gh, _ = r.render(cam, rp, backward=True)
+        np.testing.assert_array_equal(gh, want[0])
+        r.comm_destroy()
+    finally:
+        r.close()
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_plumbing():
+    """The launch shape of the driver's SCALE run -- 8 ranks, interleaved 16-row bands, weak scaling -- on one device over a
+    gloo rendezvous (RCCL refuses several ranks on one GPU: the reduce falls back to torch.distributed here, the only
+    place that fallback exists); the numbers of such a run mean nothing."""
+    line = _bench("--gpus", "8", "--dist-backend", "gloo", "--same-gpu", "--steps", "2", "--warmup", "1",
+                  "--width", "128", "--height", "128", "--spp", "2", "--no-cpu-baseline", "--no-extra-views", timeout=1100)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert "8 ranks" in line["config"]["parallelism"]
+    assert line["config"]["paths_per_step"] == 8 * 128 * 128 * 2
+    assert "weak_scaling" in line
