@@ -646,6 +646,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     a.cap_is_roulette = (rp->absorb >= 1.0 && rp->min_bounces == D) ? 1 : 0;
     a.absorb = rp->absorb;
     a.seed = rp->seed;
+    a.rng_stream = drt_rng_stream(rp->seed, 0u);
     for (int i = 0; i < 3; ++i) {
         a.eye[i] = cam->eye[i]; a.fwd[i] = cam->forward[i];
         a.right[i] = cam->right[i]; a.up[i] = cam->up[i];
@@ -725,7 +726,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 pa.n_ranges = (a.Sb + pa.spr - 1) / pa.spr;
                 pa.n_groups = (a.Pb + DRT_WAVE - 1) / DRT_WAVE;
                 pa.min_bounces = a.min_bounces; pa.depth_cap = a.depth_cap; pa.cap_is_roulette = a.cap_is_roulette;
-                pa.rr_threshold = a.rr_threshold; pa.seed = a.seed;
+                pa.rr_threshold = a.rr_threshold; pa.seed = a.seed; pa.rng_stream = a.rng_stream;
                 static const int regen_min_env = getenv("DRT_HIP_PATH_REGEN_MIN") ? atoi(getenv("DRT_HIP_PATH_REGEN_MIN")) : 8;
                 pa.regen_min = (uint32_t)(regen_min_env < 1 ? 1 : regen_min_env);
                 pa.p_rr = 1.0 - rp->absorb;
@@ -1440,6 +1441,10 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         return fail(ctx, DRT_ERR_INVALID, "render: bad camera or render parameters");
     if ((uint64_t)cam->width * (uint64_t)cam->height >= 0xFFFFFFFFull)
         return fail(ctx, DRT_ERR_INVALID, "render: image too large");
+    // the path index (pixel * spp + sample) of every camera sample of the FRAME fits 32 bits: the kernels keep its low word
+    // as the path's RNG key and share the high word's hash round (drt_hip.h: path_hi = 0)
+    if ((uint64_t)cam->width * (uint64_t)cam->height * (uint64_t)rp->spp > (1ull << 32))
+        return fail(ctx, DRT_ERR_INVALID, "render: more than 2^32 camera samples in one frame (width x height x spp)");
     if (rp->max_depth > DRT_MAX_DEPTH)
         return fail(ctx, DRT_ERR_INVALID, "render: max_depth above DRT_MAX_DEPTH (64)");
     if (rp->absorb >= 1.0 && rp->max_depth <= 0 && rp->min_bounces > DRT_MAX_DEPTH)

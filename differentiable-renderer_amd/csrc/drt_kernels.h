@@ -56,6 +56,7 @@ struct BatchArgs {
                                // still draws its roulette number there (a user max_depth draws nothing)
     double absorb;
     uint32_t seed;
+    uint32_t rng_stream;     // drt_rng_stream(seed, 0): the h-seed of every path of the frame (at most 2^32 camera samples)
     // camera (double: per-path work, not per-segment)
     double eye[3], fwd[3], right[3], up[3];
     double tan_half, aspect;
@@ -71,6 +72,14 @@ __device__ inline uint32_t global_pixel(const BatchArgs& a, uint32_t lp)
         y = (b * (uint32_t)a.n_shards + (uint32_t)a.shard) * (uint32_t)a.band + r;
     }
     return y * (uint32_t)a.W + x;
+}
+
+// The n-th draw of the path whose index has the low word `key` (include/drt_hip.h).  The first hash round depends on the
+// draw index only: where the lanes of a wave stand at the same index (the lockstep kernels) the compiler evaluates it on
+// the scalar unit, and a draw costs the lanes one XOR and one hash round -- what the 32-bit-key scheme of rounds 1-2 cost.
+__device__ inline uint32_t rng_draw(uint32_t stream, uint32_t key, uint32_t n)
+{
+    return drt_rng_combine(drt_rng_index_hash(stream, n), key);
 }
 
 // wave index in the grid, as a scalar
@@ -116,11 +125,11 @@ __device__ inline void camera_ray(const BatchArgs& a, uint32_t i, typename Q4<R>
     const uint32_t sl = i / a.Pb, pl = i - sl * a.Pb;
     const uint32_t gpix = global_pixel(a, a.p0 + pl);
     const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
-    key = drt_rng_path_key(a.seed, path);
+    key = (uint32_t)path;
     const uint32_t y = gpix / (uint32_t)a.W, x = gpix - y * (uint32_t)a.W;
     // camera.hpp:53-58
-    const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
-    const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
+    const double u1 = (double)rng_draw(a.rng_stream, key, 0) / DRT_RAND_MAX_D;
+    const double u2 = (double)rng_draw(a.rng_stream, key, 1) / DRT_RAND_MAX_D;
     const double s = ((double)x + u1) / (double)a.W;
     const double t = ((double)y + u2) / (double)a.H;
     const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
@@ -162,7 +171,7 @@ k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* 
             // pathtracer.hpp:128 at depth 0
             if (a.depth_cap <= 0)
                 alive = false;
-            else if (a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold)
+            else if (a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold)
                 alive = false;
             rid.x = i; rid.y = key;
             if (!alive)
@@ -1310,7 +1319,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                         const uint32_t n_theta = n_off + (draw_base ? draw_base[pid] : 0u);
                         V3<R> wo;
                         R q, bs;
-                        sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+                        sample_bxdf<R, SPEC>(m, nrm, d, rng_draw(a.rng_stream, key, n_theta), rng_draw(a.rng_stream, key, n_theta + 1), wo, q, bs);
                         const R c = dot(nrm, wo);                  // pathtracer.hpp:103
                         const R mk_ = bs * c / (q * pk);           // T_{k+1} = T_k * color * m_k
 #ifdef DRT_DEBUG_NAN
@@ -1323,10 +1332,10 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                         // roulette / cap of depth kk+1, decided here so dead rays are never queued
                         alive = !next_cap;
                         if (alive && next_rr)
-                            alive = !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                            alive = !(rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold);
                         // a user max_depth ends the path here: had the reference's roulette let it live?
                         if (next_cap && !a.cap_is_roulette)
-                            capped = !next_rr || !(drt_rng_draw(key, n_theta + 2) < a.rr_threshold);
+                            capped = !next_rr || !(rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold);
                         tr.m = mk_;
                         tr.ids = (uint32_t)m.param | (eid << 16);
                         ended = !alive;
@@ -1685,7 +1694,7 @@ k_adj_init(BatchArgs a, const TapeRec<R>* __restrict__ tape, const uint32_t* __r
         const uint64_t path = (uint64_t)global_pixel(a, a.p0 + pl) * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
         const V3<R> g = path_seed<R>(a, adjoint, i);
         R4 o;
-        o.x = g.x; o.y = g.y; o.z = g.z; o.w = pid_pack(R(0), drt_rng_path_key(a.seed, path));
+        o.x = g.x; o.y = g.y; o.z = g.z; o.w = pid_pack(R(0), (uint32_t)path);
         cs.g[i] = o;
         if (K <= 0) {
             HitRec<R> h;
@@ -1753,7 +1762,7 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
                     const uint32_t n = cs.ndraw[i];
                     V3<R> wo;
                     R q, bs;
-                    sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n), drt_rng_draw(key, n + 1), wo, q, bs);
+                    sample_bxdf<R, SPEC>(m, nrm, d, rng_draw(a.rng_stream, key, n), rng_draw(a.rng_stream, key, n + 1), wo, q, bs);
                     const R c = dot(nrm, wo);
                     // seed of forward(sample).backward: (g / p) / pdf, then * cos (integrate.hpp:17,
                     // vector.hpp:457)
@@ -1763,7 +1772,7 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
                     uint32_t used = 2;
                     emit = s < a.depth_cap;
                     if (emit && s >= a.min_bounces) {
-                        emit = !(drt_rng_draw(key, n + 2) < a.rr_threshold);
+                        emit = !(rng_draw(a.rng_stream, key, n + 2) < a.rr_threshold);
                         used = 3;
                     }
                     cs.ndraw[i] = n + used;

@@ -44,7 +44,7 @@ struct PathArgs {
     uint32_t Pb, p0, Sb, s0, spr, n_ranges, n_groups;
     // integrator
     int32_t min_bounces, depth_cap, cap_is_roulette;
-    uint32_t rr_threshold, seed;
+    uint32_t rr_threshold, seed, rng_stream;   // rng_stream: drt_rng_stream(seed, 0)
     uint32_t regen_min;             // regenerating form: idle lanes it takes to run the camera code (see k_path)
     int32_t gimg_param;             // >= 0: the lanes' gradient sums of this parameter also leave per pixel (gradient image)
     double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
@@ -177,11 +177,11 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
     V3<R> wo;
     R q, bs;
-    sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_draw(key, n_theta), drt_rng_draw(key, n_theta + 1), wo, q, bs);
+    sample_bxdf<R, SPEC>(m, nrm, d, rng_draw(a.rng_stream, key, n_theta), rng_draw(a.rng_stream, key, n_theta + 1), wo, q, bs);
     const R c = dot(nrm, wo);                                         // pathtracer.hpp:103
     const R mk_ = div_r(bs * c, q * pk);                              // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
     // roulette / cap of the next depth (pathtracer.hpp:128)
-    const bool rr_kills = next_rr && drt_rng_draw(key, n_theta + 2) < a.rr_threshold;
+    const bool rr_kills = next_rr && rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold;
     alive = hit && has_bxdf && !next_cap && !rr_kills;
     capped = hit && has_bxdf && next_cap && !a.cap_is_roulette && !rr_kills;
     // throughput and tangents move on only in lanes whose path goes on (the others stay frozen for the light's turn)
@@ -209,10 +209,10 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
                                        typename Q4<R>::T& ra, typename Q2<R>::T& rb)
 {
     const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
-    const uint32_t key = drt_rng_path_key(a.seed, path);
+    const uint32_t key = (uint32_t)path;
     if (sizeof(R) == 4) {
-        const float cs = fmaf(u01(0.f, drt_rng_draw(key, 0)), (float)(2. * a.aspect * a.tan_half * a.inv_W), (float)cl.cs0);
-        const float ct = fmaf(u01(0.f, drt_rng_draw(key, 1)), (float)(2. * a.tan_half * a.inv_H), (float)cl.ct0);
+        const float cs = fmaf(u01(0.f, rng_draw(a.rng_stream, key, 0)), (float)(2. * a.aspect * a.tan_half * a.inv_W), (float)cl.cs0);
+        const float ct = fmaf(u01(0.f, rng_draw(a.rng_stream, key, 1)), (float)(2. * a.tan_half * a.inv_H), (float)cl.ct0);
         const V3<float> dir = mk<float>((float)a.fwd[0] + cs * (float)a.right[0] - ct * (float)a.up[0],
                                         (float)a.fwd[1] + cs * (float)a.right[1] - ct * (float)a.up[1],
                                         (float)a.fwd[2] + cs * (float)a.right[2] - ct * (float)a.up[2]);
@@ -220,8 +220,8 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
         ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dn.x;
         rb.x = (R)dn.y; rb.y = (R)dn.z;
     } else {                                          // f64 verification mode: the reference's own sequence, in double
-        const double u1 = (double)drt_rng_draw(key, 0) / DRT_RAND_MAX_D;
-        const double u2 = (double)drt_rng_draw(key, 1) / DRT_RAND_MAX_D;
+        const double u1 = (double)rng_draw(a.rng_stream, key, 0) / DRT_RAND_MAX_D;
+        const double u2 = (double)rng_draw(a.rng_stream, key, 1) / DRT_RAND_MAX_D;
         const double s = ((double)px + u1) / (double)a.W;
         const double t = ((double)py + u2) / (double)a.H;
         const double cs = (2. * s - 1.) * a.aspect * a.tan_half;
@@ -315,7 +315,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         R2 rb;
         const uint32_t key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
         // pathtracer.hpp:128 at depth 0
-        bool live = have && a.depth_cap > 0 && !(a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold);
+        bool live = have && a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
         uint32_t end_ids = DRT_ID_NONE;                   // emission parameter of the light the path ended on
         R end_inv_pk = R(1);
@@ -379,7 +379,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
                     key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
                     ++sl;
                     kk = 0;
-                    live = a.depth_cap > 0 && !(a.min_bounces <= 0 && drt_rng_draw(key, 2) < a.rr_threshold);
+                    live = a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
                     T = mk<R>(R(1), R(1), R(1));
                     L = mk<R>(R(0), R(0), R(0));
                     if (NC > 0) {
@@ -591,7 +591,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
             uint32_t nd = 2;                                  // the camera's two draws
             bool live = have && a.depth_cap > 0;
             if (rr_drawn(0)) {                                // pathtracer.hpp:128 at depth 0
-                live = live && !(drt_rng_draw(key, nd) < a.rr_threshold);
+                live = live && !(rng_draw(a.rng_stream, key, nd) < a.rr_threshold);
                 ++nd;
             }
             V3<R> L0;
@@ -627,14 +627,14 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
                         const DevMaterial<R>& m = lds.sc.materials[cur.material];
                         V3<R> wo;
                         R q;
-                        sample_bxdf<R, SPEC>(m, cur.nrm, cur.d, drt_rng_draw(key, nd), drt_rng_draw(key, nd + 1), wo, q, bs);
+                        sample_bxdf<R, SPEC>(m, cur.nrm, cur.d, rng_draw(a.rng_stream, key, nd), rng_draw(a.rng_stream, key, nd + 1), wo, q, bs);
                         nd += 2;
                         const R c = dot(cur.nrm, wo);
                         gq = g1 * div_r(c, q);                    // grad / pdf (integrate.hpp:17), times cos
                         fcol = load_param<R, true>(lds, params, (int)cid) * bs;
                         go = (cdepth + 1) < a.depth_cap;
                         if (rr_drawn(cdepth + 1)) {
-                            go = go && !(drt_rng_draw(key, nd) < a.rr_threshold);
+                            go = go && !(rng_draw(a.rng_stream, key, nd) < a.rr_threshold);
                             ++nd;
                         }
                         const V3<R> no = cur.P + wo * R(1e-3);

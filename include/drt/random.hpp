@@ -16,7 +16,7 @@ namespace drt { namespace random {
 
 struct Stream {
     bool keyed = false;
-    uint32_t path_key = 0;
+    drt_rng_key path_key = {0, 0};
     uint32_t draw = 0;
 };
 

@@ -272,7 +272,19 @@ const char* drt_hip_kernel_name(int k);
  *      the device all draw from it) --------------------------------------------------------
  * Replaces drt::random::uniform (include/drt/random.hpp:7-10): the n-th rand() call made while
  * tracing camera sample `path` (= pixel*spp + sample, pixel = y*width + x) returns
- * drt_rng_u31(seed, path, n) in [0, 2^31-1]; uniform = r / 2147483647.0 (RAND_MAX). */
+ * drt_rng_u31(seed, path, n) in [0, 2^31-1]; uniform = r / 2147483647.0 (RAND_MAX).
+ *
+ *     draw(seed, path, n) = mix32( mix32( mix32(seed + C (path_hi + 1)) + C (n + 1) ) ^ path_lo ) >> 1
+ *
+ * A path's key is the 64-bit pair (stream = mix32(seed + C (path_hi + 1)), path_lo): two different paths of a render never
+ * share a key -- mix32 is a bijection, so at every draw index the paths of one stream (2^32 of them: path_hi fixed) even
+ * get pairwise different 32-bit values -- and no path's sequence is a shifted copy of another's: the draw index enters
+ * through its own hash round h(n) = mix32(stream + C (n + 1)), the path through the XOR behind it, so "path b replays
+ * path a k draws later" would need h(n) ^ h(n + k) = a ^ b for every n.  (Rounds 1-2 drew mix32(key32 + C (n + 1)) with a
+ * 32-bit key per path: keys that differ by a multiple of C gave shifted copies of one sequence, and the 16.7 M paths of
+ * config 3 collided outright ~3e4 times in the 2^32 key space.  tests/test_oracle_properties.py scans config 3's paths.)
+ * h(n) is the same for every path of a render (the device refuses frames of more than 2^32 camera samples: path_hi = 0),
+ * so a wave whose lanes stand at the same draw index computes it once, on the scalar unit. */
 #if defined(__HIPCC__)
 #define DRT_HD __host__ __device__ static inline
 #else
@@ -287,17 +299,30 @@ DRT_HD uint32_t drt_mix32(uint32_t x)
     return x;
 }
 
-/* per-path part of the key (hoisted out of the per-draw hash) */
-DRT_HD uint32_t drt_rng_path_key(uint32_t seed, uint64_t path)
+typedef struct drt_rng_key {
+    uint32_t stream;   /* mix32(seed + C (path_hi + 1)): shared by all paths with the same high word */
+    uint32_t lo;       /* low word of the path index */
+} drt_rng_key;
+
+DRT_HD uint32_t drt_rng_stream(uint32_t seed, uint32_t path_hi) { return drt_mix32(seed + 0x9E3779B9u * (path_hi + 1u)); }
+
+DRT_HD drt_rng_key drt_rng_path_key(uint32_t seed, uint64_t path)
 {
-    uint32_t hi = (uint32_t)(path >> 32), lo = (uint32_t)path;
-    uint32_t h = drt_mix32(seed + 0x9E3779B9u * (hi + 1u));
-    return drt_mix32(h ^ lo);
+    drt_rng_key k;
+    k.stream = drt_rng_stream(seed, (uint32_t)(path >> 32));
+    k.lo = (uint32_t)path;
+    return k;
 }
 
-DRT_HD uint32_t drt_rng_draw(uint32_t path_key, uint32_t n)
+/* h(n): the draw index's own hash round (the same for every path of a stream) */
+DRT_HD uint32_t drt_rng_index_hash(uint32_t stream, uint32_t n) { return drt_mix32(stream + 0x9E3779B9u * (n + 1u)); }
+
+/* the draw, given h(n) and the path's low word */
+DRT_HD uint32_t drt_rng_combine(uint32_t index_hash, uint32_t path_lo) { return drt_mix32(index_hash ^ path_lo) >> 1; }
+
+DRT_HD uint32_t drt_rng_draw(drt_rng_key key, uint32_t n)
 {
-    return drt_mix32(path_key + 0x9E3779B9u * (n + 1u)) >> 1;
+    return drt_rng_combine(drt_rng_index_hash(key.stream, n), key.lo);
 }
 
 DRT_HD uint32_t drt_rng_u31(uint32_t seed, uint64_t path, uint32_t n)

@@ -58,7 +58,7 @@ static const double k_pi = 3.14159265358979323846; /* constants.hpp:9 */
 /* ---- RNG, random.hpp:7-10 ---------------------------------------------------------------- */
 typedef struct {
     int mode;
-    uint32_t path_key;
+    drt_rng_key path_key;
     uint32_t draw;
 } rng_t;
 

@@ -53,7 +53,7 @@ using P3 = drt::Vector<T, 3, true>;
 // ---- rand() interposition ---------------------------------------------------------------
 static int g_rng_mode = 0;       // 0 keyed, 1 libc stream (glibc rand() == random())
 static uint32_t g_seed = 1;
-static uint32_t g_path_key = 0;
+static drt_rng_key g_path_key = {0, 0};
 static uint32_t g_draw = 0;
 
 extern "C" int rand(void)

@@ -81,6 +81,50 @@ def test_rng_is_uniform_and_decorrelated(oracle):
     assert oracle.rng_u31(1, 5, 0) != oracle.rng_u31(1, 5 + (1 << 32), 0)
 
 
+def _mix32(x):
+    x = x.astype(np.uint32, copy=True)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def _u31(seed, paths, n):
+    """include/drt_hip.h's drt_rng_u31, vectorised over 64-bit path indices."""
+    c = np.uint32(0x9E3779B9)
+    paths = np.asarray(paths, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        stream = _mix32(np.uint32(seed) + c * ((paths >> np.uint64(32)).astype(np.uint32) + np.uint32(1)))
+        h = _mix32(stream + c * np.uint32(n + 1))
+        return _mix32(h ^ paths.astype(np.uint32)) >> np.uint32(1)
+
+
+def test_no_two_paths_of_config_3_share_draws(oracle):
+    """Independent streams: among ALL 16,777,216 camera samples of config 3 (512 x 512 x 64, seed 1)
+    no pair of consecutive draws (n, n + 1), n = 0..5, occurs twice -- neither in two paths at the same position (a key
+    collision) nor at different positions (one path replaying another's sequence shifted).  The 32-bit-key scheme of
+    rounds 1-2 (draw = mix32(key32 + C (n + 1))) fails this scan with ~6e4 repeated pairs on a QUARTER of the paths."""
+    rs = np.random.RandomState(0)
+    for seed, path, n in zip(rs.randint(0, 2**31, 64), rs.randint(0, 2**40, 64, dtype=np.int64), rs.randint(0, 300, 64)):
+        assert int(_u31(int(seed), np.array([path], np.uint64), int(n))[0]) == oracle.rng_u31(int(seed), int(path), int(n))
+    paths = np.arange(512 * 512 * 64, dtype=np.uint64)
+    draws = [_u31(1, paths, n).astype(np.uint64) for n in range(7)]
+    for d in draws[:2]:                       # at one draw index the paths get pairwise different 32-bit words (a bijection):
+        assert np.unique(d, return_counts=True)[1].max() <= 2      # a 31-bit draw is shared by at most two of them
+    windows = np.concatenate([(draws[i] << np.uint64(31)) | draws[i + 1] for i in range(6)])
+    windows.sort()
+    assert int((windows[1:] == windows[:-1]).sum()) == 0
+    # the scan does find the defect it is looking for: the old scheme, a quarter of the paths
+    c = np.uint32(0x9E3779B9)
+    with np.errstate(over="ignore"):
+        q = paths[: 1 << 22].astype(np.uint32)
+        key = _mix32(_mix32(np.uint32(1) + c) ^ q)
+        old = [(_mix32(key + c * np.uint32(n + 1)) >> np.uint32(1)).astype(np.uint64) for n in range(7)]
+    w_old = np.concatenate([(old[i] << np.uint64(31)) | old[i + 1] for i in range(6)])
+    w_old.sort()
+    assert int((w_old[1:] == w_old[:-1]).sum()) > 10000
+
+
 def test_keyed_and_libc_streams_agree_statistically(pkg, oracle):
     """Two sample sets of the same estimator: means agree within Monte-Carlo noise."""
     scene = pkg.cornell_box()
