@@ -82,7 +82,7 @@ struct drt_hip_ctx {
     std::vector<void*> mesh_allocs;
 
     DevBuf ray_a[2], ray_b[2], ray_id[2], hit, hit2, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
-        ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_lsuf, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[2], film, gpart, grad[2], adjoint, out[2];   // [2]: one set per frame in flight (drt_hip_render_async), slot 0 otherwise
+        ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[2], film, gpart, grad[2], adjoint, out[2];   // [2]: one set per frame in flight (drt_hip_render_async), slot 0 otherwise
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
@@ -558,7 +558,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     // walk's candidate lists itself (k_shade<TAIL>); the hit lane is double-buffered like the queue
     static const uint32_t shade_list_group = getenv("DRT_HIP_SHADE_LIST_GROUP") ? (uint32_t)std::max(1, atoi(getenv("DRT_HIP_SHADE_LIST_GROUP"))) : 4u;
     static const bool tail_env = !(getenv("DRT_HIP_SHADE_TAIL") && atoi(getenv("DRT_HIP_SHADE_TAIL")) == 0);
-    const bool shade_tail = tail_env && ctx->has_mesh && !unbiased && !can_fuse && (ctx->prog_sorted || sizeof(R) == 8);
+    const bool shade_tail = tail_env && ctx->has_mesh && !can_fuse && (ctx->prog_sorted || sizeof(R) == 8);
     int rc;
     ChainState<R> cs;
     memset(&cs, 0, sizeof cs);
@@ -596,13 +596,12 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         if ((rc = ensure(ctx, ctx->ch_nxh, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ch_g, N * sizeof(R4))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ch_w, N * sizeof(R4))) != DRT_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ch_lsuf, N * sizeof(R4))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ch_ids, N * sizeof(uint32_t))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ch_ndraw, N * sizeof(uint32_t))) != DRT_OK) return rc;
         if ((rc = ensure(ctx, ctx->ch_dbase, N * sizeof(uint32_t))) != DRT_OK) return rc;
         cs.cv_a = (R4*)ctx->ch_cva.p; cs.cv_b = (R2c*)ctx->ch_cvb.p; cs.cv_hit = (HitRec<R>*)ctx->ch_cvh.p;
         cs.nx_a = (R4*)ctx->ch_nxa.p; cs.nx_b = (R2c*)ctx->ch_nxb.p; cs.nx_hit = (HitRec<R>*)ctx->ch_nxh.p;
-        cs.g = (R4*)ctx->ch_g.p; cs.w = (R4*)ctx->ch_w.p; cs.lsuf = (R4*)ctx->ch_lsuf.p;
+        cs.g = (R4*)ctx->ch_g.p; cs.w = (R4*)ctx->ch_w.p;
         cs.ids = (uint32_t*)ctx->ch_ids.p; cs.ndraw = (uint32_t*)ctx->ch_ndraw.p; cs.dbase = (uint32_t*)ctx->ch_dbase.p;
     }
     if ((rc = ensure(ctx, ctx->tape, N * sizeof(TapeRec<R>) * (size_t)(D > 0 ? D : 1))) != DRT_OK) return rc;
@@ -876,9 +875,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 // it itself unless a mesh keeps the hit in a separate kernel's hands
                 const bool fused = can_fuse;
                 const bool save_here = unbiased && k == 0;
-                R4* sv_a = save_here && fused ? cs.cv_a : (R4*)nullptr;
-                typename Q2<R>::T* sv_b = save_here && fused ? cs.cv_b : (typename Q2<R>::T*)nullptr;
-                HitRec<R>* sv_hit = save_here && fused ? cs.cv_hit : (HitRec<R>*)nullptr;
+                // (fused or not, the shade launch has the ray and its final hit in registers)
+                R4* sv_a = save_here ? cs.cv_a : (R4*)nullptr;
+                typename Q2<R>::T* sv_b = save_here ? cs.cv_b : (typename Q2<R>::T*)nullptr;
+                HitRec<R>* sv_hit = save_here ? cs.cv_hit : (HitRec<R>*)nullptr;
                 // hit lane of this depth (double-buffered when the shade launch fills the next depth's itself)
                 HitRec<R>* hit_k = shade_tail && (lc & 1) ? (HitRec<R>*)ctx->hit2.p : hit;
                 HitRec<R>* hit_n = shade_tail ? ((lc & 1) ? hit : (HitRec<R>*)ctx->hit2.p) : (HitRec<R>*)nullptr;
@@ -908,10 +908,6 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         st->launches[DRT_K_INTERSECT_MESH]++;
                     }
                 }
-                if (save_here && !fused)
-                    hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur], rb[cur],
-                                       rid[cur], hit_k, counts + (size_t)k * max_regions, cs.cv_a, cs.cv_b, cs.cv_hit);
-
                 TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                 if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
                 {
@@ -925,10 +921,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     hipLaunchKernelGGL((k_shade<R, SPEC, FUSE>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk, d_scene, \
                        d_params, ra[cur], rb[cur], rid[cur], hit_k, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,    \
                        ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit, DRT_SHADE_NO_TAIL)
-#define DRT_LAUNCH_SHADE_TAIL(SPEC)                                                                                    \
+#define DRT_LAUNCH_SHADE_TAIL(SPEC, SEG, DBASE)                                                                        \
     hipLaunchKernelGGL((k_shade<R, SPEC, false, false, true>), dim3(gs), dim3(DRT_BLOCK), 0, ctx->stream, a, k, nbk,   \
                        d_scene, d_params, ra[cur], rb[cur], rid[cur], hit_k, ra[nxt], rb[nxt], rid[nxt], tape_k, nv,   \
-                       ck, (uint32_t)max_regions, bvh.tri_shade, 0, (const uint32_t*)nullptr, sv_a, sv_b, sv_hit, bvh, \
+                       ck, (uint32_t)max_regions, bvh.tri_shade, SEG, DBASE, sv_a, sv_b, sv_hit, bvh,                  \
                        hit_n, (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p)
                     if (fused && camera_fused && k == 0) {
 #define DRT_LAUNCH_CAMERA(SPEC)                                                                                       \
@@ -944,8 +940,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     } else if (shade_tail && k + nbk < D) {
                         // (the region lists of regions no wave visits stay empty)
                         HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
-                        if (ctx->has_specular) DRT_LAUNCH_SHADE_TAIL(true);
-                        else DRT_LAUNCH_SHADE_TAIL(false);
+                        if (ctx->has_specular) DRT_LAUNCH_SHADE_TAIL(true, 0, (const uint32_t*)nullptr);
+                        else DRT_LAUNCH_SHADE_TAIL(false, 0, (const uint32_t*)nullptr);
                     } else {
                         if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, 0, (const uint32_t*)nullptr);
                         else DRT_LAUNCH_SHADE(false, false, 0, (const uint32_t*)nullptr);
@@ -978,14 +974,21 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     const int s = r + 1;
                     HIPCHK(ctx, hipMemsetAsync(counts + (size_t)s * max_regions, 0,
                                                (size_t)(D + 1 - s) * max_regions * sizeof(uint32_t), ctx->stream));
-                    if (ctx->has_specular)
-                        hipLaunchKernelGGL((k_adj_vertex<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene,
-                                           d_params, cs, bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv,
-                                           counts + (size_t)s * max_regions);
-                    else
-                        hipLaunchKernelGGL((k_adj_vertex<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene,
-                                           d_params, cs, bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv,
-                                           counts + (size_t)s * max_regions);
+                    // (scenes with a mesh: the kernel also intersects the rays it queues with the analytic shapes and builds the
+                    //  BVH walk's candidate lists -- hit lane `hit`, the one the suffix loop starts on)
+#define DRT_LAUNCH_ADJ_VERTEX(SPEC, TAILV)                                                                                  \
+    hipLaunchKernelGGL((k_adj_vertex<R, SPEC, TAILV>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene, d_params, cs, \
+                       bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv, counts + (size_t)s * max_regions, bvh, hit,      \
+                       (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p)
+                    if (shade_tail) {
+                        HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+                        if (ctx->has_specular) DRT_LAUNCH_ADJ_VERTEX(true, true);
+                        else DRT_LAUNCH_ADJ_VERTEX(false, true);
+                    } else {
+                        if (ctx->has_specular) DRT_LAUNCH_ADJ_VERTEX(true, false);
+                        else DRT_LAUNCH_ADJ_VERTEX(false, false);
+                    }
+#undef DRT_LAUNCH_ADJ_VERTEX
                     bool chains_done = false;
                     if (D > 2 * DRT_POLL_EVERY && r >= 2) {
                         // no suffix ray queued in this round => every chain ends with this round
@@ -1008,30 +1011,44 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         }
                         uint32_t* ck = counts + (size_t)k * max_regions;
                         const bool fused = can_fuse;
-                        HitRec<R>* hit_k = hit;                 // (the suffix rounds keep K2 a kernel of its own)
-                        R4* sv_a = k == s && fused ? cs.nx_a : (R4*)nullptr;
-                        typename Q2<R>::T* sv_b = k == s && fused ? cs.nx_b : (typename Q2<R>::T*)nullptr;
-                        HitRec<R>* sv_hit = k == s && fused ? cs.nx_hit : (HitRec<R>*)nullptr;
+                        // scenes with a mesh: every depth gets its analytic hit and its candidate lists from the launch that
+                        // PRODUCES its rays (k_adj_vertex<TAIL> for depth s, k_shade<TAIL> after it), the hit lane double-buffered;
+                        // the suffix's first ray and its FINAL hit -- the next chain vertex -- are saved by the shade launch of
+                        // depth s, which holds both
+                        HitRec<R>* hit_k = shade_tail && (lc & 1) ? (HitRec<R>*)ctx->hit2.p : hit;
+                        HitRec<R>* hit_n = shade_tail ? ((lc & 1) ? hit : (HitRec<R>*)ctx->hit2.p) : (HitRec<R>*)nullptr;
+                        const bool lists_from_shade = shade_tail;         // (depth s: from k_adj_vertex<TAIL>)
+                        R4* sv_a = k == s ? cs.nx_a : (R4*)nullptr;
+                        typename Q2<R>::T* sv_b = k == s ? cs.nx_b : (typename Q2<R>::T*)nullptr;
+                        HitRec<R>* sv_hit = k == s ? cs.nx_hit : (HitRec<R>*)nullptr;
                         if (!fused) {
-                            hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
-                                               ra[cur], rb[cur], hit, ck, bvh,
-                                               ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
-                                       (uint32_t*)ctx->cand_count.p, cand_cap, (unsigned long long*)ctx->segtotal[ctx->slot].p);
-                            if (ctx->has_mesh)
+                            if (!lists_from_shade) {
+                                hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
+                                                   ra[cur], rb[cur], hit_k, ck, bvh,
+                                                   ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
+                                                   (uint32_t*)ctx->cand_count.p, cand_cap, (unsigned long long*)ctx->segtotal[ctx->slot].p);
+                                st->launches[DRT_K_INTERSECT]++;
+                            }
+                            if (ctx->has_mesh) {
+                                const uint32_t walk_lists = lists_from_shade ? a.n_regions : (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE);
+                                const uint32_t walk_group = lists_from_shade ? shade_list_group : 1u;
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
-                                                   ctx->stream, a, d_scene, bvh, hit, (const uint32_t*)ctx->cand.p,
-                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p, cand_cap, (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE), 1u,
-                                                   coprime_multiplier((uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE)), (unsigned long long*)ctx->segtotal[ctx->slot].p);
-                            st->launches[DRT_K_INTERSECT]++;
+                                                   ctx->stream, a, d_scene, bvh, hit_k, (const uint32_t*)ctx->cand.p,
+                                                   (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p,
+                                                   lists_from_shade ? region_size : cand_cap, walk_lists, walk_group,
+                                                   coprime_multiplier((walk_lists + walk_group - 1) / walk_group), (unsigned long long*)ctx->segtotal[ctx->slot].p);
+                                st->launches[DRT_K_INTERSECT_MESH]++;
+                            }
                         }
-                        if (k == s && !fused)
-                            hipLaunchKernelGGL(k_save_vertex<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[cur],
-                                               rb[cur], rid[cur], hit, ck, cs.nx_a, cs.nx_b, cs.nx_hit);
                         TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                         const int gs = g;
                         if (fused) {
                             if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, s, (const uint32_t*)cs.dbase);
                             else DRT_LAUNCH_SHADE(false, true, s, (const uint32_t*)cs.dbase);
+                        } else if (shade_tail && k + nbk < D) {
+                            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+                            if (ctx->has_specular) DRT_LAUNCH_SHADE_TAIL(true, s, (const uint32_t*)cs.dbase);
+                            else DRT_LAUNCH_SHADE_TAIL(false, s, (const uint32_t*)cs.dbase);
                         } else {
                             if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, s, (const uint32_t*)cs.dbase);
                             else DRT_LAUNCH_SHADE(false, false, s, (const uint32_t*)cs.dbase);
@@ -1042,8 +1059,6 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream,
                                            counts + (size_t)s * max_regions, (uint32_t)((size_t)(D - s) * max_regions),
                                            (unsigned long long*)ctx->segtotal[ctx->slot].p, (uint32_t)max_regions, sfx_read, sfx_written, 0xFFFFFFFFu);
-                    hipLaunchKernelGGL(k_radiance_from<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, s, d_scene,
-                                       d_params, tape, nv, cs);
                     if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                     if (ctx->n_params <= 4)
                         hipLaunchKernelGGL((k_adj_accumulate<R, 4>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r,
@@ -1199,7 +1214,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)hipEventDestroy(ctx->ev_done);
     DevBuf* bufs[] = {&ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->hit2, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
-                      &ctx->ch_w, &ctx->ch_lsuf, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal[0], &ctx->segtotal[1], &ctx->film, &ctx->gpart, &ctx->grad[0], &ctx->grad[1],
+                      &ctx->ch_w, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal[0], &ctx->segtotal[1], &ctx->film, &ctx->gpart, &ctx->grad[0], &ctx->grad[1],
                       &ctx->adjoint, &ctx->out[0], &ctx->out[1]};
     for (DevBuf* b : bufs)
         release(*b);

@@ -82,6 +82,10 @@ __device__ inline uint32_t rng_draw(uint32_t stream, uint32_t key, uint32_t n)
     return drt_rng_combine(drt_rng_index_hash(stream, n), key);
 }
 
+// wave vote on a bool without the detour through a vector register (HIP's __ballot / __any take an int: v_cndmask + v_cmp)
+__device__ inline uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
 // wave index in the grid, as a scalar
 __device__ inline uint32_t grid_wave()
 {
@@ -861,7 +865,7 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
         bs = R(1) / dot(nrm, wo);
         return;
     }
-    r1 = r1 < 1u ? 1u : (r1 > 2147483646u ? 2147483646u : r1);
+    r1 = min(max(r1, 1u), 2147483646u);                      // (v_med3_u32)
     R sphi, cphi;
     sincos_2pi_u31(r2, &sphi, &cphi);                          // phi = 2 pi u2
     V3<R> tg, bt;
@@ -1635,12 +1639,13 @@ k_backward_image(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __res
 // evaluates forward(sample) -- a whole new suffix path -- back-propagates grad / pdf through
 // brdf * radiance * cos, and the recursion continues down the NEW path.  As a wavefront: every path
 // keeps a CHAIN VERTEX (the incoming ray and its hit, depth r) and the gradient g arriving there.
-// Round r:  k_adj_vertex  (E-gradient bookkeeping, fresh theta/phi, suffix ray queued at depth r+1)
+// Round r:  k_adj_vertex  (E-gradient bookkeeping, fresh theta/phi, suffix ray queued at depth r+1; scenes with a mesh:
+//                          also its analytic hit and the BVH walk's candidate lists, <TAIL>)
 //           K2/K3 over depths r+1 .. D-1   (the ordinary bounce loop writes the suffix's tape)
-//           the suffix's first ray + hit = the next chain vertex: saved by K3 at depth r+1 (path-indexed;
-//           k_save_vertex does the same as a separate pass when a mesh keeps K2 a kernel of its own)
-//           k_radiance_from(r+1)            (L' of the suffix from its tape)
-//           k_adj_accumulate                (gradients of round r, g and chain vertex of round r+1)
+//           the suffix's first ray + FINAL hit = the next chain vertex: saved by the shade launch of depth r+1, which
+//           holds both (path-indexed)
+//           k_adj_accumulate                (L' of the suffix from its tape, gradients of round r, g and chain vertex
+//                                            of round r+1)
 template <typename R>
 struct ChainState {
     typename Q4<R>::T* cv_a;      // (o.xyz, d.x) of the ray that reached the chain vertex
@@ -1651,33 +1656,10 @@ struct ChainState {
     HitRec<R>* nx_hit;
     typename Q4<R>::T* g;         // (g.rgb, RNG path key bits)
     typename Q4<R>::T* w;         // (g3.rgb, bs) of the current round
-    typename Q4<R>::T* lsuf;      // L' of the current round's suffix
     uint32_t* ids;                // colour | emission << 16 of the chain vertex
     uint32_t* ndraw;              // next unused draw of the path's stream
     uint32_t* dbase;              // draw base of the current suffix (index of theta at depth r+1)
 };
-
-// copies the rays of queue depth `s` and their hits to path-indexed storage
-template <typename R>
-__global__ void __launch_bounds__(DRT_BLOCK)
-k_save_vertex(BatchArgs a, const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
-              const uint2* __restrict__ ray_id, const HitRec<R>* __restrict__ hit,
-              const uint32_t* __restrict__ counts_k, typename Q4<R>::T* __restrict__ out_a,
-              typename Q2<R>::T* __restrict__ out_b, HitRec<R>* __restrict__ out_hit)
-{
-    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
-    const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
-    const uint32_t n_chunks = a.n_regions << (a.region_shift - 6);
-    for (uint32_t c = grid_wave(); c < n_chunks; c += n_waves) {
-        const uint32_t slot = chunk_slot(a, counts_k, c, n_chunks, lane);
-        if (slot == 0xFFFFFFFFu)
-            continue;
-        const uint32_t pid = ray_id[slot].x;
-        out_a[pid] = ray_a[slot];
-        out_b[pid] = ray_b[slot];
-        out_hit[pid] = hit[slot];
-    }
-}
 
 // after the forward pass: seed, draw position and liveness of every path's chain
 template <typename R>
@@ -1714,19 +1696,39 @@ k_adj_init(BatchArgs a, const TapeRec<R>* __restrict__ tape, const uint32_t* __r
 }
 
 // round r, step 1: one wave per queue region (like K1) over the PATHS of the region
-template <typename R, bool SPEC>
+// TAIL (scenes with a mesh): like k_shade<TAIL>, the kernel intersects the ray it PRODUCES with the analytic shapes, writes the
+// hit lane of depth r + 1 and appends the ray to its region's candidate list for the BVH walk -- no k_intersect pass over
+// the suffix's first rays.
+template <typename R, bool SPEC, bool TAIL = false>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
 k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
              ChainState<R> cs, const typename Q4<R>::T* __restrict__ tri_shade,
              typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* __restrict__ ray_b,
-             uint2* __restrict__ ray_id, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts_s)
+             uint2* __restrict__ ray_id, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts_s,
+             DevBvh<R> bvh_t, HitRec<R>* __restrict__ hit_next, uint32_t* __restrict__ cand,
+             typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count)
 {
     typedef typename Q4<R>::T R4;
     __shared__ SceneLds<R> lds;
+    __shared__ ProgLds s_prog;                  // TAIL, f32: the kind-sorted intersection program of the analytic shapes
+    ProgRecs<0> recs;
+    recs.lds = &s_prog;
+    if (TAIL && sizeof(R) == 4) {
+        const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
+        if (threadIdx.x < DRT_PROG_SORTED_MAX) {
+            s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
+            s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
+        }
+        if (threadIdx.x < 8)
+            s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
+    }
     stage_scene(lds, sc, params);
+    if (TAIL && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)     // the walk's list counters (it runs after this kernel)
+        pull_counters(cand_count, a.n_regions)[threadIdx.x * DRT_PULL_STRIDE] = 0;
     const uint32_t w = grid_wave();
     if (w >= a.n_regions)
         return;
+    uint32_t cand_running = 0;
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t begin = w << a.region_shift;
     const uint32_t end = min(begin + a.region_size, a.n_paths);
@@ -1793,43 +1795,39 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
             ray_b[slot] = nb;
             ray_id[slot] = nid;
         }
+        if (TAIL) {
+            bool reach = false;
+            HitRec<R> hn;
+            hn.t = (R)INFINITY;
+            hn.prim = -1;
+            if (emit) {
+                hn = tail_closest_hit(sc, recs, na, nb);
+                hit_next[slot] = hn;
+                const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb.x, nb.y);
+                const V3<R> inv2 = mk<R>(div_r(R(1), d2.x), div_r(R(1), d2.y), div_r(R(1), d2.z));
+                R tn;
+                reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
+            }
+            uint32_t n_reach;
+            const uint32_t rk = wave_rank(reach, n_reach);
+            if (reach) {
+                const size_t at = ((size_t)w << a.region_shift) + cand_running + rk;
+                const uint32_t flat = hn.prim >= 0 ? (uint32_t)sc->flat[hn.prim] : 0xFFFFFFFFu;
+                R4 ca, cb;
+                ca.x = na.x; ca.y = na.y; ca.z = na.z; ca.w = hn.t;
+                cb.x = na.w; cb.y = nb.x; cb.z = nb.y; cb.w = pid_pack(R(0), flat);
+                cand[at] = slot;
+                cand_a[at] = ca;
+                cand_b[at] = cb;
+            }
+            cand_running += n_reach;
+        }
         running += n_emit;
     }
-    if (lane == 0)
+    if (lane == 0) {
         counts_s[w] = running;
-}
-
-// L' of the current suffix: tape records of depths s .. nv-1, deepest first
-template <typename R>
-__global__ void __launch_bounds__(DRT_BLOCK)
-k_radiance_from(BatchArgs a, int s, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
-                const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv, ChainState<R> cs)
-{
-    typedef typename Q4<R>::T R4;
-    __shared__ SceneLds<R> lds;
-    stage_scene(lds, sc, params);
-    const size_t N = a.n_paths;
-    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
-        if (cs.cv_hit[i].prim < 0)
-            continue;
-        const int K = (int)nv[i];
-        V3<R> L = mk<R>(R(0), R(0), R(0));
-        for (int k = K - 1; k >= s; --k) {
-            const TapeRec<R> tr = tape[(size_t)k * N + i];
-            const uint32_t cid = tr.ids & 0xFFFFu, eid = tr.ids >> 16;
-            const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
-            V3<R> Lk = mk<R>(R(0), R(0), R(0));
-            if (eid != DRT_ID_NONE)
-                Lk = load_param(lds, params, (int)eid) * inv_pk;
-            if (cid != DRT_ID_NONE)
-                Lk = Lk + load_param(lds, params, (int)cid) * (L * tr.m);
-            L = Lk;
-        }
-        R4 o;
-        o.x = L.x; o.y = L.y; o.z = L.z; o.w = R(0);
-        cs.lsuf[i] = o;
+        if (TAIL)
+            cand_count[w] = cand_running;
     }
 }
 
@@ -1853,6 +1851,7 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
     const size_t N = a.n_paths;
     const int s = r + 1;
     const R inv_pr = r >= a.min_bounces ? (R)(1.0 / (1.0 - a.absorb)) : R(1);
+    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
         HitRec<R> h = cs.cv_hit[i];
@@ -1866,10 +1865,23 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
         bool go_on = false;
         if (cid != DRT_ID_NONE) {
             const R4 wr = cs.w[i];
-            const R4 Ls = cs.lsuf[i];
-            const V3<R> g3 = mk<R>(wr.x, wr.y, wr.z);
-            ga.add(acc, grad, cid, mk<R>(Ls.x, Ls.y, Ls.z) * g3 * wr.w);    // MulBackward, brdf side
             const int K = (int)nv[i];
+            // L' of the round's suffix: its tape records of depths s .. K - 1, deepest first (read once, by the thread that
+            // needs their sum -- round 2 had a pass of its own for it)
+            V3<R> Lsuf = mk<R>(R(0), R(0), R(0));
+            for (int k = K - 1; k >= s; --k) {
+                const TapeRec<R> tr = tape[(size_t)k * N + i];
+                const uint32_t tc = tr.ids & 0xFFFFu, te = tr.ids >> 16;
+                const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
+                V3<R> Lk = mk<R>(R(0), R(0), R(0));
+                if (te != DRT_ID_NONE)
+                    Lk = load_param<R, SMALL>(lds, params, (int)te) * inv_pk;
+                if (tc != DRT_ID_NONE)
+                    Lk = Lk + load_param<R, SMALL>(lds, params, (int)tc) * (Lsuf * tr.m);
+                Lsuf = Lk;
+            }
+            const V3<R> g3 = mk<R>(wr.x, wr.y, wr.z);
+            ga.add(acc, grad, cid, Lsuf * g3 * wr.w);    // MulBackward, brdf side
             if (K > s) {                                        // the suffix has a first vertex
                 const V3<R> gn = load_param<R, SMALL>(lds, params, (int)cid) * wr.w * g3;   // radiance side
                 R4 o = gk;

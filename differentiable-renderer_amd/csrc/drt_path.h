@@ -169,7 +169,7 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
         vo->hit = hit;
         vo->scattered = hit && has_bxdf;
     }
-    if (__any(emits && has_bxdf)) {
+    if (wave_any(emits && has_bxdf)) {
         if (emits && has_bxdf)
             add_emission<R, NP, NC>(lds, params, eid, inv_pk, T, g, L, tg);
     }
@@ -325,7 +325,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
                 tg.dT[p] = mk<R>(R(0), R(0), R(0));
         }
         for (int kk = 0; kk < a.depth_cap; ++kk) {
-            const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+            const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
             if (n_live == 0)
                 break;
             n_seg += n_live;
@@ -344,10 +344,10 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             end_ids = on_light ? light : end_ids;
             end_inv_pk = on_light ? inv_pk : end_inv_pk;
             if (next_cap && !a.cap_is_roulette)
-                n_capped += (uint32_t)__popcll(__ballot(capped));
+                n_capped += (uint32_t)__popcll(wave_ballot(capped));
             live = alive;
         }
-        if (__any(end_ids != DRT_ID_NONE)) {
+        if (wave_any(end_ids != DRT_ID_NONE)) {
             if (end_ids != DRT_ID_NONE)
                 add_emission<R, NP, NC>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
         }
@@ -373,7 +373,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             // ---- lanes without a path start their next sample -- once enough of them wait (the whole wave walks
             // through the camera code), or as many as still run
             const bool start = have && !live && sl < s_end;
-            const uint32_t n_idle = (uint32_t)__popcll(__ballot(start)), n_run = (uint32_t)__popcll(__ballot(live));
+            const uint32_t n_idle = (uint32_t)__popcll(wave_ballot(start)), n_run = (uint32_t)__popcll(wave_ballot(live));
             if (n_idle >= a.regen_min || (n_idle > 0 && n_idle >= n_run)) {
                 if (start) {
                     key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
@@ -389,9 +389,9 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
                     }
                 }
             }
-            const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+            const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
             if (n_live == 0) {
-                if (!__any(have && sl < s_end))
+                if (!wave_any(have && sl < s_end))
                     break;                                // every lane is through its samples
                 continue;                                 // (all fresh paths were absorbed at depth 0)
             }
@@ -409,10 +409,10 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             path_bounce<R, SPEC, NP, NC, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
                                                     ra, rb, T, L, tg, alive, capped, on_light, light);
             if (!a.cap_is_roulette)
-                n_capped += (uint32_t)__popcll(__ballot(capped));
+                n_capped += (uint32_t)__popcll(wave_ballot(capped));
             // ---- paths that ended here hand their radiance to the pixel
             const bool ended = live && !alive;
-            if (__any(ended)) {
+            if (wave_any(ended)) {
                 if (ended) {
                     if (on_light)
                         add_emission<R, NP, NC>(lds, params, light, inv_pk, T, g, L, tg);
@@ -492,7 +492,7 @@ __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, 
     Tangents<R, 0, 0> none;
     const V3<R> g1 = mk<R>(R(1), R(1), R(1));
     for (;;) {
-        const uint32_t n_live = (uint32_t)__popcll(__ballot(live));
+        const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
         if (n_live == 0)
             break;
         n_seg += n_live;
@@ -513,12 +513,12 @@ __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, 
             }
             nd += v.scattered ? 2u + rr_drawn : (v.hit ? rr_drawn : 0u);
         }
-        if (__any(live && on_light)) {
+        if (wave_any(live && on_light)) {
             if (live && on_light)
                 add_emission<R, 0, 0>(lds, params, light, inv_pk, T, g1, L, none);
         }
         if (!a.cap_is_roulette)
-            n_capped += (uint32_t)__popcll(__ballot(live && capped));
+            n_capped += (uint32_t)__popcll(wave_ballot(live && capped));
         live = alive;
         ++kk;
     }
@@ -603,7 +603,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
             in_chain = in_chain && have;
             int cdepth = 0;
             V3<R> g = g0;
-            while (__any(in_chain)) {
+            while (wave_any(in_chain)) {
                 // ---- at the chain vertex: emission gradient, fresh direction (integrate.hpp:13-16)
                 V3<R> gq = mk<R>(R(0), R(0), R(0)), fcol = gq;
                 R bs = R(0);

@@ -16,11 +16,13 @@ for r in rs:
     for _ in range(2):
         r.render(cam, rp, backward=True, unbiased=UNB)
 res = {l: [] for l in libs}
-for rnd in range(7):
+for rnd in range(int(os.environ.get('AB_ROUNDS', '7'))):
     for l, r in zip(libs, rs):
         _, _, st = r.render(cam, rp, backward=True, timing=True, unbiased=UNB)
         res[l].append([st["kernels"][k]["ms"] for k in pkg.KERNEL_NAMES] + [st["ms_total"]])
 print("lib".ljust(44), " ".join(k[:9].rjust(9) for k in pkg.KERNEL_NAMES), "host_ms".rjust(9))
 for l in libs:
-    m = np.median(np.array(res[l]), 0)
-    print(os.path.basename(l).ljust(44), " ".join(f"{v:9.3f}" for v in m))
+    a = np.array(res[l])
+    m = np.median(a, 0)
+    tot = a[:, :-1].sum(1)
+    print(os.path.basename(l).ljust(44), " ".join(f"{v:9.3f}" for v in m), f"  kernels: median {np.median(tot):.4f} mean {tot.mean():.4f} q25-q75 {np.percentile(tot, 25):.4f}-{np.percentile(tot, 75):.4f}")
