@@ -183,9 +183,39 @@ template <typename R> __device__ inline V3<R> cross(V3<R> a, V3<R> b)
 // ~10 VALU instructions each and the path is already tolerance-, not bit-, comparable to the
 // fp64 reference).  f64 (verification mode): correctly rounded.
 __device__ inline float rsqrt_r(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ inline double rsqrt_r(double x) { return 1.0 / sqrt(x); }
 __device__ inline float sqrt_r(float x) { return __builtin_amdgcn_sqrtf(x); }
+// f64: the library's own refinement of v_rsq_f64 (Goldschmidt step + two corrections: what clang emits for sqrt()) WITHOUT its
+// range scaling (ldexp in, ldexp out, class test: 7 of its 17 instructions) -- the arguments here are squared lengths and
+// discriminants of a scene a few units across, nowhere near 2^-767.  Same result for every such argument.
+#ifndef DRT_F64_LIBM
+__device__ inline double sqrt_r(double x)
+{
+    if (!(x > 0.0))
+        return x == 0.0 ? 0.0 : __builtin_nan("");
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d0 = fma(-g, g, x);
+    g = fma(d0, h, g);
+    const double d1 = fma(-g, g, x);
+    return fma(d1, h, g);
+}
+// 1 / sqrt(x) to the last bit or two (the reference forms 1.0 / sqrt(x): a correctly rounded root, then a correctly rounded
+// quotient -- 29 instructions; this is v_rsq_f64 and two Newton steps in the residual form, 8): the f64 mode's bound is 1e-9
+__device__ inline double rsqrt_r(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);                     // 1 - x y^2
+    y = fma(y * e, fma(e, 0.375, 0.5), y);              // y (1 + e/2 + 3 e^2 / 8)
+    e = fma(-x * y, y, 1.0);
+    return fma(y * e, 0.5, y);
+}
+#else
 __device__ inline double sqrt_r(double x) { return sqrt(x); }
+__device__ inline double rsqrt_r(double x) { return 1.0 / sqrt(x); }
+#endif
 __device__ inline float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ inline double div_r(double a, double b) { return a / b; }
 __device__ inline float min_r(float a, float b) { return fminf(a, b); }   // NaN-ignoring (v_min_f32)
