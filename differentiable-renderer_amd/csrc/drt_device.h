@@ -134,6 +134,8 @@ struct DevBvh {
 #endif
 
 typedef float drt_f2 __attribute__((ext_vector_type(2)));
+typedef float drt_f3 __attribute__((ext_vector_type(3)));
+typedef drt_f3 drt_f3_u __attribute__((aligned(4)));      // a 12-byte pixel at any float boundary (global_store_dwordx3)
 
 // read-once streams: non-temporal loads (they go through the caches without claiming room in them)
 typedef float drt_f4 __attribute__((ext_vector_type(4)));

@@ -42,6 +42,7 @@ struct RenderJob {
     drt_hip_stats* stats = nullptr;
     int gimg_param = -1;
     bool backward = false, dev_out = false, timing = false, want_segments = false, sync = true;
+    bool zero_copy = false;               // the image is written straight into the pinned block (drt_hip_render_async)
     int n_shards = 1, shard = 0, band = 1;
     uint32_t n_local_pixels = 0;
     size_t n_count_words = 0;
@@ -100,6 +101,7 @@ struct drt_hip_ctx {
     RenderJob pending[2];
     bool in_flight[2] = {false, false};
     uint64_t next_ticket = 1;
+    bool zero_copy_next = false;          // set around the render_launch of an asynchronous host-buffer render
     uint64_t dev_frames = 0;              // renders made with DRT_RENDER_ALLREDUCE_ASYNC (their gradient set alternates)
     int slot = 0;                         // which of the double-buffered sets (grad, segtotal, out, h_stage) this render uses
     DevBuf probe;
@@ -851,8 +853,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             const bool camera_fused = cam_env && can_fuse && D > 0 && a.min_bounces > 0 && bounces_from(0) > 1;
             if (!camera_fused) {
                 if ((rc = timing_begin(ctx, timing, DRT_K_RAYGEN)) != DRT_OK) return rc;
-                hipLaunchKernelGGL(k_raygen<R>, dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, ra[0], rb[0],
-                                   rid[0], nv, counts);
+                // (scenes with a mesh: K1 also intersects its rays with the analytic shapes and builds the BVH walk's candidate
+                //  lists -- hit lane `hit`, the one the bounce loop starts on; k_intersect is not launched at all)
+                if (shade_tail) {
+                    HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+                    hipLaunchKernelGGL((k_raygen<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, ra[0], rb[0], rid[0], nv,
+                                       counts, bvh, hit, (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
+                                       (uint32_t*)ctx->cand_count.p);
+                } else
+                    hipLaunchKernelGGL((k_raygen<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, ra[0], rb[0], rid[0], nv,
+                                       counts, bvh, (HitRec<R>*)nullptr, (uint32_t*)nullptr, (R4*)nullptr, (R4*)nullptr, (uint32_t*)nullptr);
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 st->launches[DRT_K_RAYGEN]++;
                 st->units[DRT_K_RAYGEN] += a.n_paths;
@@ -882,7 +892,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 // hit lane of this depth (double-buffered when the shade launch fills the next depth's itself)
                 HitRec<R>* hit_k = shade_tail && (lc & 1) ? (HitRec<R>*)ctx->hit2.p : hit;
                 HitRec<R>* hit_n = shade_tail ? ((lc & 1) ? hit : (HitRec<R>*)ctx->hit2.p) : (HitRec<R>*)nullptr;
-                const bool lists_from_shade = shade_tail && k > 0;      // (the camera rays still go through k_intersect)
+                const bool lists_from_shade = shade_tail;               // (depth 0: from k_raygen<TAIL>)
                 if (!fused) {
                     if (!lists_from_shade) {
                         if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
@@ -1444,6 +1454,8 @@ static void for_each_band(int height, int band, int n_shards, int shard, F&& fn)
         fn(y0, y0 + band < height ? y0 + band : height);
 }
 
+static int ensure_stage(drt_hip_ctx* ctx, RenderJob& j);
+
 // phase 1: validate, set up, enqueue the whole pipeline; the gradient of THIS context's shard ends up in ctx->grad[ctx->slot]
 static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                          const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
@@ -1510,8 +1522,15 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         if (j.dev_out) {
             j.d_out = out_rgb;
         } else {
-            if ((rc = ensure(ctx, ctx->out[ctx->slot], npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
-            j.d_out = (float*)ctx->out[ctx->slot].p;       // only this shard's rows are written, and only they are copied back
+            if (ctx->zero_copy_next) {
+                // (the finishing kernels write the image into the pinned block of this frame: no device image, no copy)
+                j.zero_copy = true;
+                if ((rc = ensure_stage(ctx, j)) != DRT_OK) return rc;
+                j.d_out = (float*)(ctx->h_stage[ctx->slot] + j.off_img);
+            } else {
+                if ((rc = ensure(ctx, ctx->out[ctx->slot], npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
+                j.d_out = (float*)ctx->out[ctx->slot].p;       // only this shard's rows are written, and only they are copied back
+            }
         }
     }
     if (j.backward) {
@@ -1596,6 +1615,40 @@ static int ensure_copy_stream(drt_hip_ctx* ctx)
     return DRT_OK;
 }
 
+// the context's pinned block of one render: [totals 64 B | gradients | image | gradient image]
+static int ensure_stage(drt_hip_ctx* ctx, RenderJob& j)
+{
+    const size_t npix_all = (size_t)j.cam.width * j.cam.height;
+    j.img_bytes = npix_all * 3 * sizeof(float);
+    j.grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
+    j.off_grad = 64;
+    j.off_img = j.off_grad + ((j.grad_bytes + 15) & ~(size_t)15);
+    j.off_gimg = j.off_img + j.img_bytes;
+    const size_t need = j.off_gimg + j.img_bytes;
+    if (ctx->h_stage_cap[ctx->slot] < need) {
+        if (ctx->h_stage[ctx->slot])
+            (void)hipHostFree(ctx->h_stage[ctx->slot]);
+        ctx->h_stage[ctx->slot] = nullptr;
+        ctx->h_stage_cap[ctx->slot] = 0;
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage[ctx->slot], need));
+        ctx->h_stage_cap[ctx->slot] = need;
+    }
+    return DRT_OK;
+}
+
+// asynchronous host-buffer renders: gradients and totals of the frame -> the pinned block, written by the device (one
+// small launch in stream order; the image got there from the finishing kernels)
+__global__ void __launch_bounds__(DRT_WAVE) k_results_to_host(const double* __restrict__ grad, int n_grad, const uint8_t* __restrict__ requires_grad_dev,
+                                                              const unsigned long long* __restrict__ totals, double* __restrict__ h_grad,
+                                                              unsigned long long* __restrict__ h_totals)
+{
+    (void)requires_grad_dev;
+    for (int i = threadIdx.x; i < n_grad; i += DRT_WAVE)
+        h_grad[i] = grad[i];
+    if (threadIdx.x < DRT_TOTAL_WORDS)
+        h_totals[threadIdx.x] = totals[threadIdx.x];
+}
+
 // phase 3: results on their way to the caller (device pointers: a copy on the stream; host buffers: DMA into the
 // context's pinned staging block -- only the rows of this shard)
 static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t cs = nullptr)
@@ -1613,21 +1666,22 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t c
         HIPCHK(ctx, hipMemcpyAsync(j.out_param_grad, ctx->grad[ctx->slot].p, (size_t)ctx->n_user_params * 3 * sizeof(double), hipMemcpyDeviceToDevice, cs));
     }
     j.sync = !j.dev_out || (j.rp.flags & DRT_RENDER_SYNC) || j.timing || j.stats;
-    j.img_bytes = npix_all * 3 * sizeof(float);
-    j.grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
-    j.off_grad = 64;
-    j.off_img = j.off_grad + ((j.grad_bytes + 15) & ~(size_t)15);
-    j.off_gimg = j.off_img + j.img_bytes;
     {
-        const size_t need = j.off_gimg + j.img_bytes;
-        if (ctx->h_stage_cap[ctx->slot] < need) {
-            if (ctx->h_stage[ctx->slot])
-                (void)hipHostFree(ctx->h_stage[ctx->slot]);
-            ctx->h_stage[ctx->slot] = nullptr;
-            ctx->h_stage_cap[ctx->slot] = 0;
-            HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage[ctx->slot], need));
-            ctx->h_stage_cap[ctx->slot] = need;
-        }
+        const int rc = ensure_stage(ctx, j);
+        if (rc != DRT_OK) return rc;
+    }
+    (void)npix_all;
+    if (j.zero_copy) {
+        // (asynchronous host-buffer render: the image is in the pinned block already -- the finishing kernels wrote it
+        //  there; gradients and totals follow by one small launch)
+        ctx->h_segments = 0;
+        j.want_segments = j.stats && j.n_count_words;
+        hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(DRT_WAVE), 0, cs, (const double*)ctx->grad[ctx->slot].p,
+                           (j.backward && j.out_param_grad && with_grad) ? ctx->n_user_params * 3 : 0, (const uint8_t*)nullptr,
+                           (const unsigned long long*)ctx->segtotal[ctx->slot].p, (double*)(ctx->h_stage[ctx->slot] + j.off_grad),
+                           (unsigned long long*)ctx->h_stage[ctx->slot]);
+        HIPCHK(ctx, hipGetLastError());
+        return DRT_OK;
     }
     if (!j.dev_out) {
         const size_t row_bytes = (size_t)j.cam.width * 3 * sizeof(float);
@@ -1901,17 +1955,19 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     }
     ctx->slot = slot;
     static drt_hip_stats sink;            // (render_launch only notes that totals are wanted; drt_hip_wait fills the caller's)
+    // Everything of the frame is enqueued on the context's ONE stream: the finishing kernels write the image straight into
+    // the frame's pinned block (zero-copy: 3 MB over PCIe inside a kernel that was reading 45 MB of partial sums anyway),
+    // a small launch sends gradients and totals after it, an event marks the end.  (A first version copied on a second,
+    // high-priority stream: 0.85 ms per frame under ROCm 7.2's runtime, but 1.3 ms -- slower than the synchronous call --
+    // when the process had loaded PyTorch's bundled ROCm 7.0 runtime first, as bench.py does.)
+    ctx->zero_copy_next = true;
     int rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, &sink, -1, nullptr);
+    ctx->zero_copy_next = false;
     if (rc != DRT_OK)
         abort_comm_after_failure(ctx, rp);
-    if (rc == DRT_OK) {
-        hipError_t e = hipEventRecord(ctx->ev_rendered[slot], ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rendered[slot], 0);
-        if (e != hipSuccess) { ctx->err = std::string("render_async: ") + hipGetErrorString(e); rc = DRT_ERR_HIP; }
-    }
-    if (rc == DRT_OK) rc = render_reduce(ctx, ctx->copy_stream);     // (the all-reduce, too, overlaps the next frame)
-    if (rc == DRT_OK) rc = render_collect(ctx, true, ctx->copy_stream);
-    if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream) != hipSuccess) {
+    if (rc == DRT_OK) rc = render_reduce(ctx);
+    if (rc == DRT_OK) rc = render_collect(ctx, true);
+    if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], ctx->stream) != hipSuccess) {
         ctx->err = "render_async: hipEventRecord failed";
         rc = DRT_ERR_HIP;
     }

@@ -147,53 +147,6 @@ __device__ inline void camera_ray(const BatchArgs& a, uint32_t i, typename Q4<R>
     rb.x = (R)dy; rb.y = (R)dz;
 }
 
-// ---- K1 ---------------------------------------------------------------------------------------
-// One wave per queue region: generates the camera rays of its region's paths and compacts the
-// ones that survive the depth-0 roulette to the front of the region.
-template <typename R>
-__global__ void __launch_bounds__(DRT_BLOCK)
-k_raygen(BatchArgs a, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* __restrict__ ray_b,
-         uint2* __restrict__ ray_id, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts)
-{
-    typedef typename Q4<R>::T R4;
-    const uint32_t w = grid_wave();
-    if (w >= a.n_regions)
-        return;
-    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
-    const uint32_t begin = w * a.region_size;
-    const uint32_t end = min(begin + a.region_size, a.n_paths);
-    uint32_t running = 0;
-    for (uint32_t off = begin; off < end; off += DRT_WAVE) {
-        const uint32_t i = off + lane;
-        bool alive = i < end;
-        R4 ra;
-        typename Q2<R>::T rb;
-        uint2 rid;
-        if (alive) {
-            uint32_t key;
-            camera_ray<R>(a, i, ra, rb, key);
-            // pathtracer.hpp:128 at depth 0
-            if (a.depth_cap <= 0)
-                alive = false;
-            else if (a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold)
-                alive = false;
-            rid.x = i; rid.y = key;
-            if (!alive)
-                nv[i] = 0;
-        }
-        uint32_t n_alive;
-        const uint32_t slot = begin + running + wave_rank(alive, n_alive);
-        if (alive) {
-            ray_a[slot] = ra;
-            ray_b[slot] = rb;
-            ray_id[slot] = rid;
-        }
-        running += n_alive;
-    }
-    if (lane == 0)
-        counts[w] = running;
-}
-
 // ---- K2 ---------------------------------------------------------------------------------------
 // Streaming kernel: a 16-byte and an 8-byte load, one 8-byte store per ray (32 B, all used); the shape loop index is
 // wave-uniform so the records arrive through the scalar cache into SGPRs.  K2 appends nothing,
@@ -1194,6 +1147,124 @@ __device__ inline HitRec<double> tail_closest_hit(const DevScene<double>* __rest
     return closest_hit_packed(sc, ra, rb);
 }
 
+// ---- the TAIL step, shared by the kernels that PRODUCE rays in scenes with a mesh (k_raygen, k_shade, k_adj_vertex) ------
+// The ray a lane has just written to queue slot `slot` of region w is intersected with the analytic shapes while it is still
+// in registers (the hit lane of the ray's depth gets the result) and, if it reaches the bounds of the mesh before that hit,
+// its complete record -- slot, origin, direction, analytic t, tie-break index: 36 bytes -- is appended to the REGION's
+// candidate list (wave ballot + prefix rank, no atomics) for the BVH walk.  No kernel ever re-reads a ray just to find out
+// whether the walk must see it.
+__device__ inline void stage_tail_program(ProgLds& s_prog, const DevScene<float>* __restrict__ scf)
+{
+    if (threadIdx.x < DRT_PROG_SORTED_MAX) {
+        s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
+        s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
+    }
+    if (threadIdx.x < 8)
+        s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
+}
+__device__ inline void stage_tail_program(ProgLds&, const DevScene<double>* __restrict__) { }   // (f64: the literal loop)
+
+template <typename R>
+__device__ inline void tail_emit(const BatchArgs& a, const DevScene<R>* __restrict__ sc, const ProgRecs<0>& recs, const DevBvh<R>& bvh_t,
+                                 bool alive, uint32_t slot, typename Q4<R>::T na, typename Q2<R>::T nb, uint32_t w, uint32_t& cand_running,
+                                 HitRec<R>* __restrict__ hit_next, uint32_t* __restrict__ cand, typename Q4<R>::T* __restrict__ cand_a,
+                                 typename Q4<R>::T* __restrict__ cand_b)
+{
+    typedef typename Q4<R>::T R4;
+    bool reach = false;
+    HitRec<R> hn;
+    hn.t = (R)INFINITY;
+    hn.prim = -1;
+    if (alive) {
+        hn = tail_closest_hit(sc, recs, na, nb);
+        hit_next[slot] = hn;
+        const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb.x, nb.y);
+        const V3<R> inv2 = mk<R>(div_r(R(1), d2.x), div_r(R(1), d2.y), div_r(R(1), d2.z));   // (f32: v_rcp; the bounds are padded)
+        R tn;
+        reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
+        // (Measured and not kept: a second test against the <= 16 boxes two levels down -- 21 % of the rays that reach the
+        //  bounds of the 50,880-triangle sphere die within two levels -- took 5 % of the candidates' walk time away,
+        //  4.14 -> 4.06 ms per step, and added 0.48 ms to the shade launches that run it.)
+    }
+    uint32_t n_reach;
+    const uint32_t rk = wave_rank(reach, n_reach);
+    if (reach) {
+        const size_t at = ((size_t)w << a.region_shift) + cand_running + rk;
+        const uint32_t flat = hn.prim >= 0 ? (uint32_t)sc->flat[hn.prim] : 0xFFFFFFFFu;
+        R4 ca, cb;
+        ca.x = na.x; ca.y = na.y; ca.z = na.z; ca.w = hn.t;
+        cb.x = na.w; cb.y = nb.x; cb.z = nb.y; cb.w = pid_pack(R(0), flat);
+        cand[at] = slot;
+        cand_a[at] = ca;
+        cand_b[at] = cb;
+    }
+    cand_running += n_reach;
+}
+
+// ---- K1 ---------------------------------------------------------------------------------------
+// One wave per queue region: generates the camera rays of its region's paths and compacts the
+// ones that survive the depth-0 roulette to the front of the region.  TAIL (scenes with a mesh): plus the TAIL step above --
+// K1 and K2's analytic pass in one launch: the camera rays are never read back (32 B written and 24 B read per path saved).
+template <typename R, bool TAIL = false>
+__global__ void __launch_bounds__(DRT_BLOCK)
+k_raygen(BatchArgs a, const DevScene<R>* __restrict__ sc, typename Q4<R>::T* __restrict__ ray_a, typename Q2<R>::T* __restrict__ ray_b,
+         uint2* __restrict__ ray_id, uint32_t* __restrict__ nv, uint32_t* __restrict__ counts,
+         DevBvh<R> bvh_t, HitRec<R>* __restrict__ hit_next, uint32_t* __restrict__ cand,
+         typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count)
+{
+    typedef typename Q4<R>::T R4;
+    __shared__ ProgLds s_prog;
+    ProgRecs<0> recs;
+    recs.lds = &s_prog;
+    if (TAIL) {
+        stage_tail_program(s_prog, sc);
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)     // the walk's list counters (it runs after this kernel)
+            pull_counters(cand_count, a.n_regions)[threadIdx.x * DRT_PULL_STRIDE] = 0;
+    }
+    const uint32_t w = grid_wave();
+    if (w >= a.n_regions)
+        return;
+    const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+    const uint32_t begin = w * a.region_size;
+    const uint32_t end = min(begin + a.region_size, a.n_paths);
+    uint32_t running = 0, cand_running = 0;
+    for (uint32_t off = begin; off < end; off += DRT_WAVE) {
+        const uint32_t i = off + lane;
+        bool alive = i < end;
+        R4 ra;
+        typename Q2<R>::T rb;
+        uint2 rid;
+        if (alive) {
+            uint32_t key;
+            camera_ray<R>(a, i, ra, rb, key);
+            // pathtracer.hpp:128 at depth 0
+            if (a.depth_cap <= 0)
+                alive = false;
+            else if (a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold)
+                alive = false;
+            rid.x = i; rid.y = key;
+            if (!alive)
+                nv[i] = 0;
+        }
+        uint32_t n_alive;
+        const uint32_t slot = begin + running + wave_rank(alive, n_alive);
+        if (alive) {
+            ray_a[slot] = ra;
+            ray_b[slot] = rb;
+            ray_id[slot] = rid;
+        }
+        if (TAIL)
+            tail_emit<R>(a, sc, recs, bvh_t, alive, slot, ra, rb, w, cand_running, hit_next, cand, cand_a, cand_b);
+        running += n_alive;
+    }
+    if (lane == 0) {
+        counts[w] = running;
+        if (TAIL)
+            cand_count[w] = cand_running;
+    }
+}
+
 // TAIL (scenes with a mesh, one bounce per launch): the ray this launch PRODUCES is intersected with the analytic shapes
 // right here, while it is still in registers, and handed to the BVH walk if it reaches the mesh -- K2's analytic pass
 // (k_intersect) then only runs for the camera rays, and the queue is not read a second time (24 bytes per ray).  The
@@ -1226,15 +1297,8 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     __shared__ ProgLds s_prog;                  // TAIL, f32: the kind-sorted intersection program of the analytic shapes
     ProgRecs<0> recs;
     recs.lds = &s_prog;
-    if (TAIL && sizeof(R) == 4) {
-        const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
-        if (threadIdx.x < DRT_PROG_SORTED_MAX) {
-            s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
-            s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
-        }
-        if (threadIdx.x < 8)
-            s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
-    }
+    if (TAIL)
+        stage_tail_program(s_prog, sc);
     stage_scene(lds, sc, params);               // (ends with a barrier)
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
@@ -1377,33 +1441,8 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
             next_b[ns] = nb2;
             next_id[ns] = cur.rid;
         }
-        if (TAIL) {
-            bool reach = false;
-            HitRec<R> hn;
-            hn.t = (R)INFINITY;
-            hn.prim = -1;
-            if (alive) {
-                hn = tail_closest_hit(sc, recs, na, nb2);
-                hit_next[ns] = hn;
-                const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb2.x, nb2.y);
-                const V3<R> inv2 = mk<R>(div_r(R(1), d2.x), div_r(R(1), d2.y), div_r(R(1), d2.z));   // (f32: v_rcp; the bounds are padded)
-                R tn;
-                reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
-            }
-            uint32_t n_reach;
-            const uint32_t rk = wave_rank(reach, n_reach);
-            if (reach) {
-                const size_t at = ((size_t)w << a.region_shift) + cand_running + rk;
-                const uint32_t flat = hn.prim >= 0 ? (uint32_t)sc->flat[hn.prim] : 0xFFFFFFFFu;
-                R4 ca, cb;
-                ca.x = na.x; ca.y = na.y; ca.z = na.z; ca.w = hn.t;
-                cb.x = na.w; cb.y = nb2.x; cb.z = nb2.y; cb.w = pid_pack(R(0), flat);
-                cand[at] = ns;
-                cand_a[at] = ca;
-                cand_b[at] = cb;
-            }
-            cand_running += n_reach;
-        }
+        if (TAIL)
+            tail_emit<R>(a, sc, recs, bvh_t, alive, ns, na, nb2, w, cand_running, hit_next, cand, cand_a, cand_b);
         running += n_alive;
         if (nw != w) {                                         // region finished
             if (lane == 0) {
@@ -1493,9 +1532,11 @@ k_resolve(BatchArgs a, uint32_t n_pixels, const double* __restrict__ film, float
     const double inv = 1.0 / (double)a.spp;
     for (uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x; lp < n_pixels; lp += stride) {
         const uint32_t gp = global_pixel(a, lp);
-        out[(size_t)gp * 3 + 0] = (float)(film[(size_t)lp * 3 + 0] * inv);
-        out[(size_t)gp * 3 + 1] = (float)(film[(size_t)lp * 3 + 1] * inv);
-        out[(size_t)gp * 3 + 2] = (float)(film[(size_t)lp * 3 + 2] * inv);
+        drt_f3 px;                                   // (one 12-byte store per lane: `out` may be pinned host memory)
+        px.x = (float)(film[(size_t)lp * 3 + 0] * inv);
+        px.y = (float)(film[(size_t)lp * 3 + 1] * inv);
+        px.z = (float)(film[(size_t)lp * 3 + 2] * inv);
+        *reinterpret_cast<drt_f3_u*>(out + (size_t)gp * 3) = px;
     }
 }
 
@@ -1713,15 +1754,8 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
     __shared__ ProgLds s_prog;                  // TAIL, f32: the kind-sorted intersection program of the analytic shapes
     ProgRecs<0> recs;
     recs.lds = &s_prog;
-    if (TAIL && sizeof(R) == 4) {
-        const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
-        if (threadIdx.x < DRT_PROG_SORTED_MAX) {
-            s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
-            s_prog.shape[threadIdx.x] = scf->sorted_shape[threadIdx.x];
-        }
-        if (threadIdx.x < 8)
-            s_prog.kind_begin[threadIdx.x] = scf->kind_begin[threadIdx.x];
-    }
+    if (TAIL)
+        stage_tail_program(s_prog, sc);
     stage_scene(lds, sc, params);
     if (TAIL && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)     // the walk's list counters (it runs after this kernel)
         pull_counters(cand_count, a.n_regions)[threadIdx.x * DRT_PULL_STRIDE] = 0;
@@ -1795,33 +1829,8 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
             ray_b[slot] = nb;
             ray_id[slot] = nid;
         }
-        if (TAIL) {
-            bool reach = false;
-            HitRec<R> hn;
-            hn.t = (R)INFINITY;
-            hn.prim = -1;
-            if (emit) {
-                hn = tail_closest_hit(sc, recs, na, nb);
-                hit_next[slot] = hn;
-                const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb.x, nb.y);
-                const V3<R> inv2 = mk<R>(div_r(R(1), d2.x), div_r(R(1), d2.y), div_r(R(1), d2.z));
-                R tn;
-                reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
-            }
-            uint32_t n_reach;
-            const uint32_t rk = wave_rank(reach, n_reach);
-            if (reach) {
-                const size_t at = ((size_t)w << a.region_shift) + cand_running + rk;
-                const uint32_t flat = hn.prim >= 0 ? (uint32_t)sc->flat[hn.prim] : 0xFFFFFFFFu;
-                R4 ca, cb;
-                ca.x = na.x; ca.y = na.y; ca.z = na.z; ca.w = hn.t;
-                cb.x = na.w; cb.y = nb.x; cb.z = nb.y; cb.w = pid_pack(R(0), flat);
-                cand[at] = slot;
-                cand_a[at] = ca;
-                cand_b[at] = cb;
-            }
-            cand_running += n_reach;
-        }
+        if (TAIL)
+            tail_emit<R>(a, sc, recs, bvh_t, emit, slot, na, nb, w, cand_running, hit_next, cand, cand_a, cand_b);
         running += n_emit;
     }
     if (lane == 0) {

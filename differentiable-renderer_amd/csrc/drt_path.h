@@ -737,9 +737,11 @@ k_path_finish(PathArgs a, const double* __restrict__ fpart, float* __restrict__ 
                 r += f[0]; g += f[(size_t)a.Pb]; b += f[(size_t)a.Pb * 2];
             }
             const uint32_t gp = path_global_pixel(a, a.p0 + j);
-            out[(size_t)gp * 3 + 0] = (float)(r * inv);
-            out[(size_t)gp * 3 + 1] = (float)(g * inv);
-            out[(size_t)gp * 3 + 2] = (float)(b * inv);
+            // (one 12-byte store per lane: `out` may be host memory -- asynchronous host-buffer renders write the image
+            //  straight into the pinned block -- and whole lines travel better than three strided dwords)
+            drt_f3 px;
+            px.x = (float)(r * inv); px.y = (float)(g * inv); px.z = (float)(b * inv);
+            *reinterpret_cast<drt_f3_u*>(out + (size_t)gp * 3) = px;
         }
         return;
     }

@@ -2,17 +2,18 @@
 # Run on the GPU box (through gpurun): regenerate every file of one round's evidence from the SAME binary.
 # Usage: tools/evidence.sh <tag>      outputs under gpurun_out/evidence_<tag>/ (copy into profiles/ with tools/collect_evidence.sh)
 set -u
-T=${1:-r02}
+T=${1:-r03}
 E=$PWD/gpurun_out/evidence_$T
 mkdir -p "$E"
 bash tools/profile.sh $T cornell:512x512x64:d8:fwdbwd > "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_streaming cornell:512x512x64:d8:fwdbwd --bounces-per-launch 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_mesh mesh160x160:512x512x64:d8:fwdbwd --scene mesh160x160 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_config5 cornell_specular:1024x1024x16:d16:fwdbwd --config 5 --width 1024 --height 1024 --spp 16 >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_config4 mesh160x160:1024x1024x32:d8:fwdbwd --config 4 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0.5 --min-bounces 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_unbiased cornell:512x512x64:d8:unbiased --unbiased >> "$E/prof.log" 2>&1
 # bench.py quotes PMC numbers only for the workloads profiled above (one entry each)
-python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_roulette/traffic.json >> "$E/prof.log" 2>&1
+python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_config4/traffic.json gpurun_out/prof_${T}_roulette/traffic.json >> "$E/prof.log" 2>&1
 cp profiles/traffic.json "$E/traffic_merged.json"
 python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
 python3 bench.py > "$E/bench.json" 2> "$E/bench.err"
@@ -26,7 +27,11 @@ python3 bench.py --absorb 0.5 --min-bounces 1 > "$E/bench_roulette_b1_p0.5.json"
 python3 bench.py --unbiased --no-extra-views > "$E/bench_unbiased.json" 2>> "$E/bench.err"
 python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-extra-views > "$E/bench_2ranks_same_gpu_plumbing.json" 2>> "$E/bench.err"
 python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
-for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_roulette ${T}_unbiased; do
+python3 bench.py --scene mesh160x160 --unbiased --no-extra-views --steps 5 --warmup 2 > "$E/bench_unbiased_mesh160x160.json" 2>> "$E/bench.err"
+python3 tools/async_timing.py > "$E/async_host_buffers.txt" 2>&1
+python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
+[ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
+for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased; do
   P=gpurun_out/prof_$t
   cp $P/summary.txt "$E/${t}_rocprofv3_summary.txt"
   cp $P/traffic.json "$E/${t}_traffic.json"
