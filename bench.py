@@ -479,10 +479,14 @@ def main():
             r.render(cam, hrp, backward=backward, unbiased=unb)
         dt3 = (time.perf_counter() - t3) / n_host
         r.wait(r.render_async(cam, hrp, backward=backward, unbiased=unb))
+        bufs = [(np.zeros((a.height, a.width, 3), dtype=np.float32), np.zeros((scene.n_params, 3), dtype=np.float64)) for _ in range(2)]
+        for im, _g in bufs:
+            im.fill(0.0)                  # (touched once: a render loop keeps its two sets of buffers)
         t3 = time.perf_counter()
         prev_h = None
-        for _ in range(n_host):
-            h = r.render_async(cam, hrp, backward=backward, unbiased=unb)
+        for it in range(n_host):
+            h = r.render_async(cam, hrp, backward=backward, unbiased=unb, img_out=bufs[it & 1][0],
+                               grads_out=bufs[it & 1][1] if backward else None)
             if prev_h is not None:
                 r.wait(prev_h, want_stats=False)
             prev_h = h

@@ -586,15 +586,22 @@ class HipRenderer:
         return img, grads, stats.as_dict()
 
     def render_async(self, cam: Camera, rp: RenderParams, backward: bool = False, adjoint: Optional[np.ndarray] = None,
-                     f64: bool = False, unbiased: bool = False):
-        """drt_hip_render_async: enqueue one host-buffer frame -> a handle for wait().  At most two frames in flight."""
+                     f64: bool = False, unbiased: bool = False, img_out: Optional[np.ndarray] = None,
+                     grads_out: Optional[np.ndarray] = None):
+        """drt_hip_render_async: enqueue one host-buffer frame -> a handle for wait().  At most two frames in flight.
+        img_out / grads_out: caller-owned arrays the results are written into (a render loop keeps two sets and spares
+        itself a 3 MB allocation and its page faults per frame)."""
         assert self.scene is not None
         flags = rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC | RENDER_TIMING)
         flags |= (RENDER_BACKWARD if backward else 0) | (RENDER_F64 if f64 else 0) | (RENDER_UNBIASED if unbiased else 0)
         d = rp.to_desc()
         d.flags = flags
-        img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
-        grads = np.zeros((self.scene.n_params, 3), dtype=np.float64) if backward else None
+        img = img_out if img_out is not None else np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        assert img.dtype == np.float32 and img.shape == (cam.height, cam.width, 3) and img.flags.c_contiguous
+        grads = None
+        if backward:
+            grads = grads_out if grads_out is not None else np.zeros((self.scene.n_params, 3), dtype=np.float64)
+            assert grads.dtype == np.float64 and grads.shape == (self.scene.n_params, 3) and grads.flags.c_contiguous
         adj_ptr = None
         if adjoint is not None:
             adjoint = np.ascontiguousarray(adjoint, dtype=np.float32)

@@ -19,11 +19,12 @@ for _ in range(n):
 print(f"drt_hip_render: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per frame")
 r.wait(r.render_async(cam, rp, backward=True))
 ts, tw = [], []
+bufs = [(np.zeros((512, 512, 3), np.float32), np.zeros((4, 3), np.float64)) for _ in range(2)]
 t0 = time.perf_counter()
 prev = None
-for _ in range(n):
+for it in range(n):
     a = time.perf_counter()
-    h = r.render_async(cam, rp, backward=True)
+    h = r.render_async(cam, rp, backward=True, img_out=bufs[it & 1][0], grads_out=bufs[it & 1][1])
     b = time.perf_counter()
     if prev is not None:
         r.wait(prev, want_stats=False)

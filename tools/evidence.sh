@@ -8,7 +8,7 @@ mkdir -p "$E"
 bash tools/profile.sh $T cornell:512x512x64:d8:fwdbwd > "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_streaming cornell:512x512x64:d8:fwdbwd --bounces-per-launch 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_mesh mesh160x160:512x512x64:d8:fwdbwd --scene mesh160x160 >> "$E/prof.log" 2>&1
-bash tools/profile.sh ${T}_config5 cornell_specular:1024x1024x16:d16:fwdbwd --config 5 --width 1024 --height 1024 --spp 16 >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_config5 cornell_specular:2048x2048x128:d16:fwdbwd --config 5 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_config4 mesh160x160:1024x1024x32:d8:fwdbwd --config 4 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0.5 --min-bounces 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_unbiased cornell:512x512x64:d8:unbiased --unbiased >> "$E/prof.log" 2>&1
@@ -25,7 +25,7 @@ python3 bench.py --config 5 --spp 1024 --steps 3 --warmup 1 --no-cpu-baseline --
 python3 bench.py --scene mesh160x160 > "$E/bench_mesh160x160_512x512x64.json" 2>> "$E/bench.err"
 python3 bench.py --absorb 0.5 --min-bounces 1 > "$E/bench_roulette_b1_p0.5.json" 2>> "$E/bench.err"
 python3 bench.py --unbiased --no-extra-views > "$E/bench_unbiased.json" 2>> "$E/bench.err"
-python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-extra-views > "$E/bench_2ranks_same_gpu_plumbing.json" 2>> "$E/bench.err"
+python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{" > "$E/bench_2ranks_same_gpu_plumbing.json"
 python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
 python3 bench.py --scene mesh160x160 --unbiased --no-extra-views --steps 5 --warmup 2 > "$E/bench_unbiased_mesh160x160.json" 2>> "$E/bench.err"
 python3 tools/async_timing.py > "$E/async_host_buffers.txt" 2>&1
