@@ -241,7 +241,8 @@ __device__ inline double pow_r(double x, double y) { return pow(x, y); }
 __device__ inline void sincospi_r(float x, float* s, float* c) { sincospif(x, s, c); }
 __device__ inline void sincospi_r(double x, double* s, double* c) { sincospi(x, s, c); }
 // sin and cos of phi = 2 pi u for the 31-bit draw r, f32: drt_sincos.h (also compiled on the host by its known-answer test)
-__device__ inline void sincos_2pi_u31(uint32_t r, double* s, double* c) { sincospi(2.0 * ((double)r / DRT_RAND_MAX_D), s, c); }
+__device__ inline double u01_f64(uint32_t r) { return (double)r / DRT_RAND_MAX_D; }   // random.hpp:9
+__device__ inline void sincos_2pi_u31(uint32_t r, double* s, double* c) { sincospi(2.0 * u01_f64(r), s, c); }
 template <typename R> __device__ inline V3<R> normalize(V3<R> a) { return a * rsqrt_r(dot(a, a)); }
 // vector.hpp:602-606
 template <typename R> __device__ inline V3<R> reflect(V3<R> v, V3<R> n) { return n * (R(2) * dot(n, v)) - v; }

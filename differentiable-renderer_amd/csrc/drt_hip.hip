@@ -745,7 +745,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 // the kinds of the reference's own scene are compiled in (no per-shape branches); any other
                 // analytic scene reads its kinds from the program
                 static const bool sig_env = !(getenv("DRT_HIP_PATH_SIG") && atoi(getenv("DRT_HIP_PATH_SIG")) == 0);
-                const bool cornell_sig = sig_env && sizeof(R) == 4 && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
+                // (f64 too: the verification mode runs the same program with full-precision reciprocals and square roots)
+                static const bool sig64_env = !(getenv("DRT_HIP_PATH_SIG_F64") && atoi(getenv("DRT_HIP_PATH_SIG_F64")) == 0);
+                const bool cornell_sig = sig_env && (sizeof(R) == 4 || sig64_env) && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
                 unsigned long long* ptotal = path_finish ? (unsigned long long*)ctx->segtotal[ctx->slot].p : (unsigned long long*)nullptr;
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
@@ -976,10 +978,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                    (const R4*)ctx->gpath.p, gfilm);
             } else if (unbiased && D > 0) {
                 // forward radiance from the tape, then the adjoint rounds (see drt_kernels.h)
+                if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                 if (film)
                     hipLaunchKernelGGL(k_radiance<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene, d_params,
                                        tape, nv, lacc);
                 hipLaunchKernelGGL(k_adj_init<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, tape, nv, d_adjoint, cs);
+                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                st->launches[DRT_K_BACKWARD]++;
                 for (int r = 0; r < D; ++r) {
                     const int s = r + 1;
                     HIPCHK(ctx, hipMemsetAsync(counts + (size_t)s * max_regions, 0,
@@ -990,6 +995,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     hipLaunchKernelGGL((k_adj_vertex<R, SPEC, TAILV>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, d_scene, d_params, cs, \
                        bvh.tri_shade, ra[s & 1], rb[s & 1], rid[s & 1], nv, counts + (size_t)s * max_regions, bvh, hit,      \
                        (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p)
+                    // (timed with the backward pass: it re-samples the chain vertex and queues the suffix's first ray)
+                    if ((rc = timing_begin(ctx, timing, DRT_K_BACKWARD)) != DRT_OK) return rc;
                     if (shade_tail) {
                         HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
                         if (ctx->has_specular) DRT_LAUNCH_ADJ_VERTEX(true, true);
@@ -998,6 +1005,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         if (ctx->has_specular) DRT_LAUNCH_ADJ_VERTEX(true, false);
                         else DRT_LAUNCH_ADJ_VERTEX(false, false);
                     }
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                    st->launches[DRT_K_BACKWARD]++;
 #undef DRT_LAUNCH_ADJ_VERTEX
                     bool chains_done = false;
                     if (D > 2 * DRT_POLL_EVERY && r >= 2) {
@@ -1033,13 +1042,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         HitRec<R>* sv_hit = k == s ? cs.nx_hit : (HitRec<R>*)nullptr;
                         if (!fused) {
                             if (!lists_from_shade) {
+                                if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT)) != DRT_OK) return rc;
                                 hipLaunchKernelGGL(k_intersect<R>, dim3(gk2), dim3(DRT_BLOCK), 0, ctx->stream, a, d_scene,
                                                    ra[cur], rb[cur], hit_k, ck, bvh,
                                                    ctx->has_mesh ? (uint32_t*)ctx->cand.p : (uint32_t*)nullptr, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p,
                                                    (uint32_t*)ctx->cand_count.p, cand_cap, (unsigned long long*)ctx->segtotal[ctx->slot].p);
+                                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                                 st->launches[DRT_K_INTERSECT]++;
                             }
                             if (ctx->has_mesh) {
+                                if ((rc = timing_begin(ctx, timing, DRT_K_INTERSECT_MESH)) != DRT_OK) return rc;
                                 const uint32_t walk_lists = lists_from_shade ? a.n_regions : (uint32_t)gk2 * (DRT_BLOCK / DRT_WAVE);
                                 const uint32_t walk_group = lists_from_shade ? shade_list_group : 1u;
                                 hipLaunchKernelGGL(k_intersect_mesh<R>, dim3((int)std::min<uint64_t>(((uint64_t)a.n_paths + DRT_BLOCK - 1) / DRT_BLOCK, (uint64_t)ctx->n_cu * ctx->mesh_blocks_per_cu)), dim3(DRT_BLOCK), 0,
@@ -1047,11 +1059,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                                    (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p,
                                                    lists_from_shade ? region_size : cand_cap, walk_lists, walk_group,
                                                    coprime_multiplier((walk_lists + walk_group - 1) / walk_group), (unsigned long long*)ctx->segtotal[ctx->slot].p);
+                                if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                                 st->launches[DRT_K_INTERSECT_MESH]++;
                             }
                         }
                         TapeRec<R>* tape_k = tape + (size_t)k * a.n_paths;
                         const int gs = g;
+                        if ((rc = timing_begin(ctx, timing, DRT_K_SHADE)) != DRT_OK) return rc;
                         if (fused) {
                             if (ctx->has_specular) DRT_LAUNCH_SHADE(true, true, s, (const uint32_t*)cs.dbase);
                             else DRT_LAUNCH_SHADE(false, true, s, (const uint32_t*)cs.dbase);
@@ -1063,6 +1077,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                             if (ctx->has_specular) DRT_LAUNCH_SHADE(true, false, s, (const uint32_t*)cs.dbase);
                             else DRT_LAUNCH_SHADE(false, false, s, (const uint32_t*)cs.dbase);
                         }
+                        if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                         st->launches[DRT_K_SHADE]++;
                     }
                     if (s < D)
@@ -1081,7 +1096,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                            d_scene, d_params, tape, nv, cs, gpart, grad, g_rows, g_stride);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_BACKWARD]++;
+                    if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_gradreduce, dim3(g_rows > 0 ? g_rows : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, g_rows, grad, g_stride);
+                    if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_GRADREDUCE]++;
                     if (chains_done)
                         break;

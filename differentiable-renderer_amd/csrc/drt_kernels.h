@@ -102,9 +102,9 @@ __device__ inline uint32_t wave_rank(bool alive, uint32_t& n_alive)
 
 // uniform in [0,1] from a 31-bit draw, R = float: no fp64 (u and 1-u both from exact integers)
 __device__ inline float u01(float, uint32_t r) { return (float)r * (float)(1.0 / DRT_RAND_MAX_D); }
-__device__ inline double u01(double, uint32_t r) { return (double)r / DRT_RAND_MAX_D; }
+__device__ inline double u01(double, uint32_t r) { return u01_f64(r); }
 __device__ inline float one_minus_u01(float, uint32_t r) { return (float)(2147483647u - r) * (float)(1.0 / DRT_RAND_MAX_D); }
-__device__ inline double one_minus_u01(double, uint32_t r) { return 1.0 - (double)r / DRT_RAND_MAX_D; }
+__device__ inline double one_minus_u01(double, uint32_t r) { return 1.0 - u01_f64(r); }
 
 // Draw bookkeeping (draw order: SURVEY 3.1).  A path segment that starts at depth s has a BASE =
 // the index of its first BxDF draw (theta at depth s; the roulette draw of depth s, if any, comes

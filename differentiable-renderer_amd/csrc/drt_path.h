@@ -70,12 +70,14 @@ __device__ inline HitRec<float> path_closest_hit(const DevScene<float>* __restri
     return closest_hit_prog<SIG, NSIG>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
 }
 template <unsigned long long SIG, int NSIG>
-__device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<NSIG>&, double4 ra, double2 rb)
+__device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<NSIG, double>& recs, double4 ra, double2 rb)
 {
+    if (NSIG > 0)                                                  // the reference's own scene: the compiled-in program in f64
+        return closest_hit_sig<SIG, NSIG, double>(recs, mk<double>(ra.x, ra.y, ra.z), mk<double>(ra.w, rb.x, rb.y));
     const double4 ra1[1] = {ra};
     const double2 rb1[1] = {rb};
     HitRec<double> h1[1];
-    closest_hit_n<double, 1>(sc, sc->n_shapes, ra1, rb1, h1);      // the f64 verification mode keeps the literal loop
+    closest_hit_n<double, 1>(sc, sc->n_shapes, ra1, rb1, h1);      // any other scene: the literal loop
     return h1[0];
 }
 
@@ -140,12 +142,12 @@ struct PathVertex {
 
 template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG>
 __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
-                                   const R* __restrict__ params, const ProgRecs<(sizeof(R) == 4 ? NSIG : 0)>& recs, uint32_t key,
+                                   const R* __restrict__ params, const ProgRecs<NSIG, R>& recs, uint32_t key,
                                    R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
                                    typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
                                    bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr)
 {
-    const HitRec<R> h = path_closest_hit<SIG, (sizeof(R) == 4 ? NSIG : 0)>(sc, recs, ra, rb);
+    const HitRec<R> h = path_closest_hit<SIG, NSIG>(sc, recs, ra, rb);
     const bool hit = live && h.prim >= 0;
     const int prim = h.prim >= 0 ? h.prim : 0;                        // (a miss reads record 0, uses nothing of it)
     const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
@@ -293,11 +295,11 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
-    ProgRecs<(sizeof(R) == 4 ? NSIG : 0)> recs;
+    ProgRecs<NSIG, R> recs;
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
-    if (sizeof(R) == 4 && NSIG > 0)
-        recs.load(reinterpret_cast<const DevScene<float>*>(sc));
+    if (NSIG > 0)
+        recs.load(sc);
     if (sizeof(R) == 4 && NSIG == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {
@@ -482,7 +484,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
 // One walk = the bounce of k_path (path_bounce, forward-only) iterated while any lane of the wave still traces.
 template <typename R, bool SPEC, unsigned long long SIG, int NSIG>
 __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
-                                     const R* __restrict__ params, const ProgRecs<(sizeof(R) == 4 ? NSIG : 0)>& recs, uint32_t key,
+                                     const R* __restrict__ params, const ProgRecs<NSIG, R>& recs, uint32_t key,
                                      R pk_rr, R inv_p_rr, bool live, typename Q4<R>::T ra, typename Q2<R>::T rb, int kk,
                                      uint32_t& nd, uint32_t& n_seg, uint32_t& n_capped, V3<R>& L, PathVertex<R>& first, bool& any_vertex)
 {
@@ -565,11 +567,11 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
-    ProgRecs<(sizeof(R) == 4 ? NSIG : 0)> recs;
+    ProgRecs<NSIG, R> recs;
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
-    if (sizeof(R) == 4 && NSIG > 0)
-        recs.load(reinterpret_cast<const DevScene<float>*>(sc));
+    if (NSIG > 0)
+        recs.load(sc);
     if (sizeof(R) == 4 && NSIG == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {

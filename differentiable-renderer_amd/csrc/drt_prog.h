@@ -1,4 +1,4 @@
-// drt_prog.h -- the f32 "intersection program" of the analytic shapes: one record per shape with a KIND (general plane,
+// drt_prog.h -- the "intersection program" of the analytic shapes: one record per shape with a KIND (general plane,
 // axis plane, sphere), tested either from scalar registers with the kinds compiled in (k_path on the reference's own
 // scene) or from a kind-sorted copy in LDS (any other scene; also k_shade's tail in scenes with a mesh, where the
 // program covers the analytic shapes and the mesh records are left out).  Built by drt_hip_upload_scene (fill_scene).
@@ -13,9 +13,17 @@
 // yet 0.805 against 0.790 ms (41 interleaved rounds, twice).  (ii) The shape index in the four low mantissa bits of t and
 // the closest hit as a plain v_min3_u32 over those words: 28 vector instructions fewer, 0.827 against 0.844 ms, but the
 // hit point moves by up to 15 ulp of t and the library's routes stop agreeing to rounding.)
-__device__ inline void prog_accept(float t, int s, float& tmin, int& prim)
+// (f64, the verification mode: the same formulas with a full-precision reciprocal and square root; only the compiled-in
+// form -- the reference's own scene -- exists in f64, every other scene keeps the literal loop there)
+__device__ inline float prog_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double prog_rcp(double x) { return div_r(1.0, x); }
+__device__ inline float prog_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ inline double prog_sqrt(double x) { return sqrt_r(x); }
+
+template <typename R>
+__device__ inline void prog_accept(R t, int s, R& tmin, int& prim)
 {
-    if (t > 0.f && !(t >= tmin)) {          // shape.hpp:55 / pathtracer.hpp:80: first shape wins ties
+    if (t > R(0) && !(t >= tmin)) {          // shape.hpp:55 / pathtracer.hpp:80: first shape wins ties
         tmin = t;
         prim = s;
     }
@@ -25,8 +33,8 @@ __device__ inline void prog_accept(float t, int s, float& tmin, int& prim)
 // second time when it has seen an exact tie (below), and both evaluations must agree in all 32 bits whatever the
 // compiler's contraction choices would have been.  Returns false where the reference's predicate cannot hold
 // (sphere: negative discriminant).
-template <int KIND>
-__device__ inline bool prog_t(const float4 r, V3<float> o, V3<float> d, V3<float> inv_d, float& t)
+template <int KIND, typename R>
+__device__ inline bool prog_t(const typename Q4<R>::T r, V3<R> o, V3<R> d, V3<R> inv_d, R& t)
 {
     if (KIND == DRT_PK_AX) {
         t = (r.x - o.x) * inv_d.x;
@@ -35,28 +43,28 @@ __device__ inline bool prog_t(const float4 r, V3<float> o, V3<float> d, V3<float
     } else if (KIND == DRT_PK_AZ) {
         t = (r.x - o.z) * inv_d.z;
     } else if (KIND == DRT_PK_PLANE) {
-        const float h = fmaf(o.z, r.z, fmaf(o.y, r.y, o.x * r.x)) - r.w;
-        const float den = fmaf(d.z, r.z, fmaf(d.y, r.y, d.x * r.x));
-        t = h * __builtin_amdgcn_rcpf(-den);
+        const R h = fma_r(o.z, r.z, fma_r(o.y, r.y, o.x * r.x)) - r.w;
+        const R den = fma_r(d.z, r.z, fma_r(d.y, r.y, d.x * r.x));
+        t = h * prog_rcp(-den);
     } else {                                 // sphere: b' = oc.d, disc' = b'^2 - (oc.oc - r^2), t = -b' -+ sqrt(disc')
-        const V3<float> oc = mk<float>(o.x - r.x, o.y - r.y, o.z - r.z);
-        const float bh = fmaf(oc.z, d.z, fmaf(oc.y, d.y, oc.x * d.x));
-        const float cc = fmaf(-r.w, r.w, fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, oc.x * oc.x)));
-        const float disc = fmaf(bh, bh, -cc);
-        if (!(disc >= 0.f))                  // (NaN fails, as in the reference; the branch-free form -- sqrt of a negative
+        const V3<R> oc = mk<R>(o.x - r.x, o.y - r.y, o.z - r.z);
+        const R bh = fma_r(oc.z, d.z, fma_r(oc.y, d.y, oc.x * d.x));
+        const R cc = fma_r(-r.w, r.w, fma_r(oc.z, oc.z, fma_r(oc.y, oc.y, oc.x * oc.x)));
+        const R disc = fma_r(bh, bh, -cc);
+        if (!(disc >= R(0)))                 // (NaN fails, as in the reference; the branch-free form -- sqrt of a negative
             return false;                    // = NaN, which fails `t > 0` -- was measured 4 % slower)
-        const float sq = __builtin_amdgcn_sqrtf(disc);
-        const float t1 = -bh - sq, t2 = sq - bh;
-        t = t1 > 0.f ? t1 : t2;
+        const R sq = prog_sqrt(disc);
+        const R t1 = -bh - sq, t2 = sq - bh;
+        t = t1 > R(0) ? t1 : t2;
     }
     return true;
 }
 
-template <int KIND>
-__device__ inline void prog_test(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float& tmin, int& prim)
+template <int KIND, typename R>
+__device__ inline void prog_test(const typename Q4<R>::T r, int s, V3<R> o, V3<R> d, V3<R> inv_d, R& tmin, int& prim)
 {
-    float t;
-    if (prog_t<KIND>(r, o, d, inv_d, t))
+    R t;
+    if (prog_t<KIND, R>(r, o, d, inv_d, t))
         prog_accept(t, s, tmin, prim);
 }
 
@@ -65,7 +73,7 @@ template <int KIND>
 __device__ inline void prog_test_tie(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float& tmin, int& prim, bool& tie)
 {
     float t;
-    if (prog_t<KIND>(r, o, d, inv_d, t)) {
+    if (prog_t<KIND, float>(r, o, d, inv_d, t)) {
         tie = tie || t == tmin;
         prog_accept(t, s, tmin, prim);
     }
@@ -76,7 +84,7 @@ template <int KIND>
 __device__ inline void prog_resolve_tie(const float4 r, int s, V3<float> o, V3<float> d, V3<float> inv_d, float tmin, int& prim)
 {
     float t;
-    if (prog_t<KIND>(r, o, d, inv_d, t) && t == tmin && s < prim)
+    if (prog_t<KIND, float>(r, o, d, inv_d, t) && t == tmin && s < prim)
         prim = s;
 }
 
@@ -90,38 +98,52 @@ struct ProgLds {               // the kind-sorted program in LDS (scenes whose k
     int kind_begin[8];
 };
 
-template <int NSIG>
+template <int NSIG, typename R = float>
 struct ProgRecs {
-    float4 r[NSIG > 0 ? NSIG : 1];
+    typename Q4<R>::T r[NSIG > 0 ? NSIG : 1];
     const ProgLds* lds;
-    __device__ inline void load(const DevScene<float>* __restrict__ sc)
+    __device__ inline void load(const DevScene<R>* __restrict__ sc)
     {
 #pragma unroll
         for (int s = 0; s < NSIG; ++s)
-            r[s] = *reinterpret_cast<const float4*>(sc->prog[s]);
+            r[s] = *reinterpret_cast<const typename Q4<R>::T*>(sc->prog[s]);
     }
 };
+
+// the compiled-in form, f32 or f64: NSIG records in scalar registers, kinds from SIG
+template <unsigned long long SIG, int NSIG, typename R>
+__device__ inline HitRec<R> closest_hit_sig(const ProgRecs<NSIG, R>& recs, V3<R> o, V3<R> d)
+{
+    const V3<R> inv_d = mk<R>(prog_rcp(d.x), prog_rcp(d.y), prog_rcp(d.z));
+    R tmin = (R)INFINITY;
+    int prim = -1;
+#pragma unroll
+    for (int s = 0; s < NSIG; ++s) {
+        constexpr unsigned long long sig = SIG;
+        const int kind = (int)((sig >> (3 * s)) & 7ull);
+        const typename Q4<R>::T r = recs.r[s];
+        if (kind == DRT_PK_AX) prog_test<DRT_PK_AX, R>(r, s, o, d, inv_d, tmin, prim);
+        else if (kind == DRT_PK_AY) prog_test<DRT_PK_AY, R>(r, s, o, d, inv_d, tmin, prim);
+        else if (kind == DRT_PK_AZ) prog_test<DRT_PK_AZ, R>(r, s, o, d, inv_d, tmin, prim);
+        else if (kind == DRT_PK_PLANE) prog_test<DRT_PK_PLANE, R>(r, s, o, d, inv_d, tmin, prim);
+        else prog_test<DRT_PK_SPHERE, R>(r, s, o, d, inv_d, tmin, prim);
+    }
+    HitRec<R> h;
+    h.t = tmin;
+    h.prim = prim;
+    return h;
+}
 
 template <unsigned long long SIG, int NSIG>
 __device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs,
                                                  V3<float> o, V3<float> d)
 {
+    if (NSIG > 0)
+        return closest_hit_sig<SIG, NSIG, float>(recs, o, d);
     const V3<float> inv_d = mk<float>(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     float tmin = INFINITY;
     int prim = -1;
-    if (NSIG > 0) {
-#pragma unroll
-        for (int s = 0; s < NSIG; ++s) {
-            constexpr unsigned long long sig = SIG;
-            const int kind = (int)((sig >> (3 * s)) & 7ull);
-            const float4 r = recs.r[s];
-            if (kind == DRT_PK_AX) prog_test<DRT_PK_AX>(r, s, o, d, inv_d, tmin, prim);
-            else if (kind == DRT_PK_AY) prog_test<DRT_PK_AY>(r, s, o, d, inv_d, tmin, prim);
-            else if (kind == DRT_PK_AZ) prog_test<DRT_PK_AZ>(r, s, o, d, inv_d, tmin, prim);
-            else if (kind == DRT_PK_PLANE) prog_test<DRT_PK_PLANE>(r, s, o, d, inv_d, tmin, prim);
-            else prog_test<DRT_PK_SPHERE>(r, s, o, d, inv_d, tmin, prim);
-        }
-    } else {
+    {
         // kinds not compiled in: the records sorted by kind (upload), one counted loop per kind -- no branch on the kind,
         // no scalar load: every lane reads the SAME record from LDS (a broadcast read), the next record is requested
         // while the current one is tested.  Inside a kind the scene order is kept, but an exact tie between shapes of

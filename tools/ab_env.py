@@ -12,14 +12,17 @@ if os.environ.get("AB_ENV_CHILD"):
     rp = pkg.RenderParams(spp=int(os.environ.get("AB_SPP", "64")), min_bounces=8, absorb=1.0, seed=1)
     r = pkg.HipRenderer(0, lib_path=os.path.abspath(os.environ["AB_LIB"]) if os.environ.get("AB_LIB") else None)
     r.upload_scene(scene)
+    UNB, F64 = bool(int(os.environ.get("AB_UNBIASED", "0"))), bool(int(os.environ.get("AB_F64", "0")))
     for _ in range(3):
-        r.render(cam, rp, backward=True)
+        r.render(cam, rp, backward=True, unbiased=UNB, f64=F64)
     res = []
     for _ in range(7):
-        _, g, st = r.render(cam, rp, backward=True, timing=True)
+        img, g, st = r.render(cam, rp, backward=True, timing=True, unbiased=UNB, f64=F64)
         res.append([st["kernels"][k]["ms"] for k in pkg.KERNEL_NAMES] + [st["ms_total"]])
     m = np.median(np.array(res), 0)
-    print(os.environ.get("AB_LABEL", "").ljust(52), " ".join(f"{v:9.3f}" for v in m), f" grad0 {g[0][0]:.6g}")
+    print(os.environ.get("AB_LABEL", "").ljust(52), " ".join(f"{v:9.3f}" for v in m), f" grad0 {g[0][0]:.6g}",
+          "sha", __import__("hashlib").sha1(np.ascontiguousarray(img).tobytes() + np.ascontiguousarray(g).tobytes()).hexdigest()[:10],
+          "segments", st.get("segments"))
     sys.exit(0)
 args = sys.argv[1:]
 scene, lib = "mesh160x160", ""
