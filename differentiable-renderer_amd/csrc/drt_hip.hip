@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1788,8 +1789,8 @@ __global__ void __launch_bounds__(DRT_BLOCK) k_add_f64(double* __restrict__ dst,
         dst[i] += src[i];
 }
 
-// A group context: every phase on ALL members before the next one, so n devices run concurrently under this one
-// host thread.  The gradient: members that share a device are added to their leader on that device (stream-ordered
+// A group context: every phase on ALL members before the next one, so n devices run concurrently under one call
+// (the launch phase from one host thread per member, the others from the caller's).  The gradient: members that share a device are added to their leader on that device (stream-ordered
 // through events), then ONE ncclAllReduce over the leaders -- the single collective of the path.
 static int render_group(drt_hip_ctx* g, const drt_camera_desc* cam, const drt_render_params* rp, const float* adjoint_rgb,
                         float* out_rgb, double* out_param_grad, drt_hip_stats* stats, int gimg_param, float* out_gimg)
@@ -1809,14 +1810,34 @@ static int render_group(drt_hip_ctx* g, const drt_camera_desc* cam, const drt_re
     std::vector<drt_hip_stats> mstats((size_t)n);
     auto member_fail = [&](int i, int rc) { g->err = "device " + std::to_string(g->members[i]->device) + ": " + g->members[i]->err; return rc; };
     int rc;
-    for (int i = 0; i < n; ++i) {
-        drt_render_params r = *rp;
-        r.n_shards = outer * n;
-        r.shard = outer_shard * n + i;
-        r.flags &= ~(uint32_t)(DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC);        // the group reduces below
-        if ((rc = render_launch(g->members[i], cam, &r, adjoint_rgb, out_rgb, out_param_grad, stats ? &mstats[i] : nullptr,
-                                gimg_param, out_gimg)) != DRT_OK)
-            return member_fail(i, rc);
+    {
+        // The launch phase can block the host -- a pageable adjoint image is copied synchronously, and deep roulette-terminated
+        // renders on the queue route ask the device every few bounces whether any path is still alive -- so every member
+        // enqueues its share from its own host thread: the devices start together whatever one member's launch waits for.
+        static const bool threads_env = !(getenv("DRT_HIP_GROUP_THREADS") && atoi(getenv("DRT_HIP_GROUP_THREADS")) == 0);
+        std::vector<int> rcs((size_t)n, DRT_OK);
+        auto launch_member = [&](int i) {
+            drt_render_params r = *rp;
+            r.n_shards = outer * n;
+            r.shard = outer_shard * n + i;
+            r.flags &= ~(uint32_t)(DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC);    // the group reduces below
+            rcs[(size_t)i] = render_launch(g->members[i], cam, &r, adjoint_rgb, out_rgb, out_param_grad,
+                                           stats ? &mstats[i] : nullptr, gimg_param, out_gimg);
+        };
+        if (threads_env && n > 1) {
+            std::vector<std::thread> workers;
+            for (int i = 1; i < n; ++i)
+                workers.emplace_back(launch_member, i);
+            launch_member(0);
+            for (std::thread& w : workers)
+                w.join();
+        } else {
+            for (int i = 0; i < n; ++i)
+                launch_member(i);
+        }
+        for (int i = 0; i < n; ++i)
+            if (rcs[(size_t)i] != DRT_OK)
+                return member_fail(i, rcs[(size_t)i]);
     }
     if (backward && gimg_param < 0) {
         const int words = g->members[0]->n_user_params * 3;

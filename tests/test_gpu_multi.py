@@ -54,6 +54,44 @@ def test_group_context_equals_one_context(pkg, hip):
         g.close()
 
 
+def test_group_members_launch_side_by_side_on_the_blocking_routes(pkg, hip):
+    """The launches that can block the host -- the queue route of a roulette-terminated render on a mesh scene asks the
+    device every few bounces whether a path is left, a pageable adjoint image is copied synchronously -- are issued from
+    one host thread per member (and, with DRT_HIP_GROUP_THREADS=0 in a fresh process, one after the other): same frame,
+    same gradients, same counts as one context."""
+    scene = pkg.scene_by_name("mesh12x16")
+    cam = pkg.cornell_camera(72, 64)
+    rp = pkg.RenderParams(spp=5, min_bounces=2, absorb=0.25, seed=21, band_rows=8)
+    adj = np.random.RandomState(5).uniform(0.2, 1.5, (64, 72, 3)).astype(np.float32)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True, adjoint=adj)
+    g = pkg.HipRenderer([0, 0, 0, 0])
+    try:
+        g.upload_scene(scene)
+        for _ in range(3):                                        # (threads are started per call)
+            gimg, ggrads, gst = g.render(cam, rp, backward=True, adjoint=adj)
+            np.testing.assert_array_equal(gimg, img)
+            np.testing.assert_allclose(ggrads, grads, rtol=1e-9)
+            assert gst["segments"] == st["segments"] and gst["paths"] == st["paths"]
+    finally:
+        g.close()
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as e; pkg = e.load_package();"
+            "scene = pkg.scene_by_name('mesh12x16'); cam = pkg.cornell_camera(72, 64);"
+            "rp = pkg.RenderParams(spp=5, min_bounces=2, absorb=0.25, seed=21, band_rows=8);"
+            "adj = np.random.RandomState(5).uniform(0.2, 1.5, (64, 72, 3)).astype(np.float32);"
+            "g = pkg.HipRenderer([0, 0, 0, 0]); g.upload_scene(scene); im, gr, st = g.render(cam, rp, backward=True, adjoint=adj);"
+            "print(float(im.sum()), repr(gr.ravel().tolist()), st['segments'])" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DRT_HIP_GROUP_THREADS="0"), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = out.stdout.strip().splitlines()[-1]
+    tot = float(line.split(" ", 1)[0])
+    segs = int(line.rsplit(" ", 1)[1])
+    gr = np.array(json.loads(line.split(" ", 1)[1].rsplit(" ", 1)[0]))
+    assert tot == float(img.sum()) and segs == st["segments"]
+    np.testing.assert_allclose(gr, grads.ravel(), rtol=1e-9)
+
+
 def test_group_as_one_shard_of_a_larger_job(pkg, hip):
     """rp.shard / n_shards address a GROUP as one node of a multi-node job: 2 'nodes' x 2 members tile the frame."""
     scene = pkg.cornell_box()
