@@ -43,7 +43,8 @@ struct RenderJob {
     drt_hip_stats* stats = nullptr;
     int gimg_param = -1;
     bool backward = false, dev_out = false, timing = false, want_segments = false, sync = true;
-    bool zero_copy = false;               // the image is written straight into the pinned block (drt_hip_render_async)
+    bool zero_copy = false;               // the image is written straight into the pinned block (drt_hip_render_async, one-stream form)
+    bool copy_kernel = false;             // image, gradients and totals go to the pinned block by ONE launch on the copy stream
     int n_shards = 1, shard = 0, band = 1;
     uint32_t n_local_pixels = 0;
     size_t n_count_words = 0;
@@ -1667,6 +1668,41 @@ __global__ void __launch_bounds__(DRT_WAVE) k_results_to_host(const double* __re
         h_totals[threadIdx.x] = totals[threadIdx.x];
 }
 
+// the same for the two-stream form, image included: the rows of this shard (full-frame layout on both sides), float by float
+// or, unsharded, 16 bytes per lane; a few blocks next to the following frame's kernels -- the PCIe link is the limit, not the CUs
+__global__ void __launch_bounds__(DRT_BLOCK) k_frame_to_host(const float* __restrict__ img, float* __restrict__ h_img, uint32_t row_floats,
+                                                            uint32_t n_local_rows, uint32_t band, uint32_t n_shards, uint32_t shard,
+                                                            const double* __restrict__ grad, int n_grad,
+                                                            const unsigned long long* __restrict__ totals, double* __restrict__ h_grad,
+                                                            unsigned long long* __restrict__ h_totals)
+{
+    const uint64_t n = img ? (uint64_t)n_local_rows * row_floats : 0;
+    const uint64_t stride = (uint64_t)gridDim.x * DRT_BLOCK, first = (uint64_t)blockIdx.x * DRT_BLOCK + threadIdx.x;
+    if (n_shards <= 1 && (n & 3u) == 0) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(img);
+        float4* __restrict__ dst = reinterpret_cast<float4*>(h_img);
+        for (uint64_t i = first; i < n / 4; i += stride)
+            dst[i] = src[i];
+    } else {
+        for (uint64_t i = first; i < n; i += stride) {
+            const uint32_t lr = (uint32_t)(i / row_floats), c = (uint32_t)(i - (uint64_t)lr * row_floats);
+            uint32_t y = lr;
+            if (n_shards > 1) {
+                const uint32_t b = lr / band, r = lr - b * band;
+                y = (b * n_shards + shard) * band + r;
+            }
+            const size_t at = (size_t)y * row_floats + c;
+            h_img[at] = img[at];
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n_grad; i += DRT_BLOCK)
+            h_grad[i] = grad[i];
+        if (threadIdx.x < DRT_TOTAL_WORDS)
+            h_totals[threadIdx.x] = totals[threadIdx.x];
+    }
+}
+
 // phase 3: results on their way to the caller (device pointers: a copy on the stream; host buffers: DMA into the
 // context's pinned staging block -- only the rows of this shard)
 static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t cs = nullptr)
@@ -1696,6 +1732,22 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t c
         j.want_segments = j.stats && j.n_count_words;
         hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(DRT_WAVE), 0, cs, (const double*)ctx->grad[ctx->slot].p,
                            (j.backward && j.out_param_grad && with_grad) ? ctx->n_user_params * 3 : 0, (const uint8_t*)nullptr,
+                           (const unsigned long long*)ctx->segtotal[ctx->slot].p, (double*)(ctx->h_stage[ctx->slot] + j.off_grad),
+                           (unsigned long long*)ctx->h_stage[ctx->slot]);
+        HIPCHK(ctx, hipGetLastError());
+        return DRT_OK;
+    }
+    if (j.copy_kernel) {
+        // (asynchronous host-buffer render, two-stream form: everything of the frame crosses the link in one launch on the
+        //  copy stream while the next frame's kernels run)
+        ctx->h_segments = 0;
+        j.want_segments = j.stats && j.n_count_words;
+        const bool img = j.out_rgb && j.n_local_pixels;
+        static const int copy_blocks = getenv("DRT_HIP_COPY_BLOCKS") ? std::max(1, atoi(getenv("DRT_HIP_COPY_BLOCKS"))) : 64;
+        hipLaunchKernelGGL(k_frame_to_host, dim3(copy_blocks), dim3(DRT_BLOCK), 0, cs, img ? (const float*)j.d_out : (const float*)nullptr,
+                           (float*)(ctx->h_stage[ctx->slot] + j.off_img), (uint32_t)j.cam.width * 3u,
+                           (uint32_t)(j.n_local_pixels / (uint32_t)j.cam.width), (uint32_t)j.band, (uint32_t)j.n_shards, (uint32_t)j.shard,
+                           (const double*)ctx->grad[ctx->slot].p, (j.backward && j.out_param_grad && with_grad) ? ctx->n_user_params * 3 : 0,
                            (const unsigned long long*)ctx->segtotal[ctx->slot].p, (double*)(ctx->h_stage[ctx->slot] + j.off_grad),
                            (unsigned long long*)ctx->h_stage[ctx->slot]);
         HIPCHK(ctx, hipGetLastError());
@@ -1993,19 +2045,31 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     }
     ctx->slot = slot;
     static drt_hip_stats sink;            // (render_launch only notes that totals are wanted; drt_hip_wait fills the caller's)
-    // Everything of the frame is enqueued on the context's ONE stream: the finishing kernels write the image straight into
-    // the frame's pinned block (zero-copy: 3 MB over PCIe inside a kernel that was reading 45 MB of partial sums anyway),
-    // a small launch sends gradients and totals after it, an event marks the end.  (A first version copied on a second,
-    // high-priority stream: 0.85 ms per frame under ROCm 7.2's runtime, but 1.3 ms -- slower than the synchronous call --
-    // when the process had loaded PyTorch's bundled ROCm 7.0 runtime first, as bench.py does.)
-    ctx->zero_copy_next = true;
+    // The frame's kernels run on the context's first stream and leave image, gradients and totals in the device buffers of the
+    // frame's slot; ONE copy launch on the second stream (k_frame_to_host: zero-copy stores into the pinned block -- no DMA
+    // engine, no hipMemcpy) carries them across the link while the next frame's kernels run on the first; an event marks the
+    // end.  Config 3, per frame: 0.84-0.87 ms against 0.834 on device pointers and 1.10 for the synchronous call.
+    // (Measured before it, round 3: the same copy as hipMemcpyAsync on the second stream -- 0.85 ms under ROCm 7.2's runtime
+    // but 1.3 ms, slower than the synchronous call, when the process had loaded PyTorch's bundled ROCm 7.0 runtime first, as
+    // bench.py does; and everything on ONE stream, the finishing kernels storing the image straight into the pinned block
+    // (DRT_HIP_ASYNC_COPY=inline, still there): 0.89-0.92 ms -- the 3 MB cross the link inside the frame's critical path.)
+    static const bool two_streams = !(getenv("DRT_HIP_ASYNC_COPY") && !strcmp(getenv("DRT_HIP_ASYNC_COPY"), "inline"));
+    ctx->zero_copy_next = !two_streams;
     int rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, &sink, -1, nullptr);
     ctx->zero_copy_next = false;
     if (rc != DRT_OK)
         abort_comm_after_failure(ctx, rp);
     if (rc == DRT_OK) rc = render_reduce(ctx);
-    if (rc == DRT_OK) rc = render_collect(ctx, true);
-    if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], ctx->stream) != hipSuccess) {
+    hipStream_t done_on = ctx->stream;
+    if (rc == DRT_OK && two_streams) {
+        ctx->job.copy_kernel = true;
+        hipError_t e = hipEventRecord(ctx->ev_rendered[slot], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rendered[slot], 0);
+        if (e != hipSuccess) { ctx->err = std::string("render_async: ") + hipGetErrorString(e); rc = DRT_ERR_HIP; }
+        done_on = ctx->copy_stream;
+    }
+    if (rc == DRT_OK) rc = render_collect(ctx, true, done_on);
+    if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], done_on) != hipSuccess) {
         ctx->err = "render_async: hipEventRecord failed";
         rc = DRT_ERR_HIP;
     }

@@ -80,11 +80,11 @@ def test_group_members_launch_side_by_side_on_the_blocking_routes(pkg, hip):
             "rp = pkg.RenderParams(spp=5, min_bounces=2, absorb=0.25, seed=21, band_rows=8);"
             "adj = np.random.RandomState(5).uniform(0.2, 1.5, (64, 72, 3)).astype(np.float32);"
             "g = pkg.HipRenderer([0, 0, 0, 0]); g.upload_scene(scene); im, gr, st = g.render(cam, rp, backward=True, adjoint=adj);"
-            "print(float(im.sum()), repr(gr.ravel().tolist()), st['segments'])" % ROOT)
+            "print('RESULT', float(im.sum()), repr(gr.ravel().tolist()), st['segments'])" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DRT_HIP_GROUP_THREADS="0"), capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = out.stdout.strip().splitlines()[-1]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]   # (RCCL prints a banner at exit)
     tot = float(line.split(" ", 1)[0])
     segs = int(line.rsplit(" ", 1)[1])
     gr = np.array(json.loads(line.split(" ", 1)[1].rsplit(" ", 1)[0]))
