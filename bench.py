@@ -471,7 +471,7 @@ def main():
     host_buffers = None
     if extra:
         hrp = pkg.RenderParams(spp=a.spp, min_bounces=a.min_bounces, absorb=a.absorb, seed=1, batch_paths=a.batch_paths)
-        n_host = max(2, min(a.steps, 10))
+        n_host = max(2, min(2 * a.steps, 40))     # (a pipeline: enough frames that its fill and drain do not set the rate)
         unb = a.unbiased and backward
         r.render(cam, hrp, backward=backward, unbiased=unb)
         t3 = time.perf_counter()
