@@ -214,6 +214,24 @@ def test_async_host_renders_match_the_synchronous_call_bit_for_bit(pkg, hip):
     r = hip.wait(h)
     np.testing.assert_array_equal(r[0], rref[0])
     np.testing.assert_array_equal(r[1], rref[1])
+    # the copy launch's other shapes: a row-band shard (rows of other shards stay untouched: zero), a frame whose float
+    # count is not a multiple of four, forward only, and frames of different sizes alternating between the two slots
+    hip.upload_scene(scene)
+    odd = pkg.cornell_camera(37, 29)
+    for c, rp, bw in ((cam, pkg.RenderParams(spp=3, min_bounces=3, absorb=0.4, seed=8, shard=1, n_shards=3, band_rows=8), True),
+                      (odd, pkg.RenderParams(spp=5, min_bounces=2, absorb=0.3, seed=9), True),
+                      (odd, pkg.RenderParams(spp=5, min_bounces=2, absorb=0.3, seed=9, shard=2, n_shards=4, band_rows=4), True),
+                      (cam, rps[2], False)):
+        want = hip.render(c, rp, backward=bw)
+        h_a = hip.render_async(c, rp, backward=bw)
+        h_b = hip.render_async(cam, rps[3], backward=True)          # (the other slot, another size)
+        got_a, got_b = hip.wait(h_a), hip.wait(h_b)
+        np.testing.assert_array_equal(got_a[0], want[0])
+        if bw:
+            np.testing.assert_array_equal(got_a[1], want[1])
+        assert got_a[2]["segments"] == want[2]["segments"]
+        np.testing.assert_array_equal(got_b[0], ref[3][0])
+        np.testing.assert_array_equal(got_b[1], ref[3][1])
 
 
 def test_allreduce_on_the_second_stream_gives_the_same_gradients(pkg):
