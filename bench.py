@@ -123,6 +123,8 @@ def parse_args(argv):
                     help="library all-reduce on the context's second stream, overlapping the next step (async, default) or "
                          "in stream order between two steps (stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--ref-seconds", type=float, default=8.0,
+                    help="target duration of the sample the reference itself (oracle/_ref/ref_harness, when present) is timed on; 0 = skip")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the oracle on every host core (independent row-band processes)")
     a = ap.parse_args(argv)
@@ -438,7 +440,7 @@ def main():
         t1 = time.perf_counter()
         ref = oracle.render(scene, ccam, crp, backward=backward)
         dt = time.perf_counter() - t1
-        cpu_baseline = {"value": round(ref["stats"]["segments"] / dt * 1e-6, 3), "unit": "Mray/s",
+        cpu_baseline = {"value": float(f"{ref['stats']['segments'] / dt * 1e-6:.4g}"), "unit": "Mray/s",
                         "cores": 1, "kind": "port",
                         "sample": f"same scene, frame {cw}x{ch} of {a.width}x{a.height}, {cs} of the {a.spp} spp, "
                                   f"{depth_text}, {'fwd+bwd' if backward else 'fwd'}: "
@@ -449,6 +451,40 @@ def main():
             img_d, g_d, _ = r.render(ccam, crp, backward=True)
             gerr = float(np.abs(g_d - ref["grads"]).max() / np.abs(ref["grads"]).max())
             cpu_baseline["grad_max_rel_err_vs_cpu"] = gerr
+        # ... and THE REFERENCE ITSELF where its binary travelled with the snapshot (oracle/_ref/ref_harness: the unmodified
+        # reference headers behind oracle/ref_harness.cpp's driver, compiled in the build container by oracle/Makefile):
+        # the same workload on a sample sized for ~ref_seconds, timed by the harness around its render loop, and the
+        # device's gradients of that very sample against the reference's own backward()
+        if oracle.have_reference() and a.ref_seconds > 0:
+            try:
+                pw2 = 8 if scene.meshes else 32
+                prp = pkg.RenderParams(spp=1, min_bounces=a.min_bounces, absorb=a.absorb, seed=1)
+                pil = oracle.render_reference(scene, pkg.cornell_camera(pw2, pw2), prp, backward=backward)
+                rate2 = pil["stats"]["segments"] / max(1e-6, pil["stats"]["seconds"])
+                per_path2 = max(1e-9, pil["stats"]["segments"] / (pw2 * pw2))
+                budget2 = max(1.0, a.ref_seconds * rate2 / per_path2)
+                rw, rh, rs_ = a.width, a.height, 1
+                if budget2 >= rw * rh:
+                    rs_ = int(max(1, min(a.spp, budget2 // (rw * rh))))
+                else:
+                    f2 = (budget2 / (rw * rh)) ** 0.5
+                    rw, rh = max(8, int(rw * f2)), max(8, int(rh * f2))
+                rcam = pkg.cornell_camera(rw, rh)
+                rrp = pkg.RenderParams(spp=rs_, min_bounces=a.min_bounces, absorb=a.absorb, seed=1)
+                res = oracle.render_reference(scene, rcam, rrp, backward=backward)
+                rsec = max(1e-6, res["stats"]["seconds"])
+                cpu_baseline["reference"] = {
+                    "value": float(f"{res['stats']['segments'] / rsec * 1e-6:.4g}"), "unit": "Mray/s", "cores": 1, "kind": "reference",
+                    "sample": f"same scene, frame {rw}x{rh} of {a.width}x{a.height}, {rs_} of the {a.spp} spp, {depth_text}, "
+                              f"{'fwd+bwd' if backward else 'fwd'}: {res['stats']['segments']} rays in {rsec:.1f} s "
+                              f"(the unmodified reference headers, double, 1 thread; oracle/_ref/ref_harness)"}
+                img_r, g_r, _ = r.render(rcam, rrp, backward=backward)
+                cpu_baseline["reference"]["image_max_abs_err_vs_reference"] = float(np.abs(img_r - res["image"]).max())
+                if backward:
+                    cpu_baseline["reference"]["grad_max_rel_err_vs_reference"] = float(
+                        np.abs(g_r - res["grads"]).max() / max(1e-300, np.abs(res["grads"]).max()))
+            except Exception as exc:        # (the checker's binary is optional; the port above is the baseline)
+                cpu_baseline["reference"] = {"error": f"{type(exc).__name__}: {exc}"}
         if a.cpu_all_cores:
             # the reference is single-threaded by construction (global rand()); this is N independent
             # processes, each rendering its interleaved row bands of the same sample
