@@ -214,6 +214,29 @@ def test_matches_oracle_on_random_scenes(pkg, hip, oracle):
         check_f32_heavy_tailed(hip, cam, rp, adj, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"])
 
 
+def test_matches_the_reference_binary_live(pkg, hip, oracle):
+    """Where oracle/_ref/ref_harness travelled with the snapshot (the unmodified reference headers behind our driver,
+    compiled in the build container; nothing of /root/reference is read here): fresh scenes that are in no fixture, the
+    device against the REFERENCE'S OWN forward and backward() -- f64 mode to 1e-9 with identical segment counts, f32 mode
+    flip-aware -- for both integration operators of integrate.hpp."""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/ref_harness is not here")
+    for seed, unbiased in ((301, False), (302, False), (303, True)):
+        scene = pkg.random_scene(seed) if seed != 302 else pkg.cornell_box(front_specular=True)
+        cam = pkg.Camera(30, 22).look_at((0.05, 0.1, -0.15), (0, 0.15, 1)) if seed != 302 else pkg.cornell_camera(30, 22)
+        rp = pkg.RenderParams(spp=4, min_bounces=2, absorb=0.3, seed=seed)
+        adj = np.random.RandomState(seed).uniform(0.1, 1, (22, 30, 3)).astype(np.float32)
+        ref = oracle.render_reference(scene, cam, rp, backward=True, adjoint=adj, tracer_mode=2 if unbiased else 0,
+                                      zero_dir_miss=unbiased)           # (as oracle/gen_golden.py runs the two operators)
+        hip.upload_scene(scene)
+        img, grads, stats = hip.render(cam, rp, backward=True, adjoint=adj, f64=True, unbiased=unbiased)
+        assert stats["segments"] == ref["stats"]["segments"]
+        assert grad_rel_err(grads, ref["grads"]) < 1e-9
+        np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+        if not unbiased:
+            check_f32_heavy_tailed(hip, cam, rp, adj, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"])
+
+
 def test_edge_cases(pkg, hip, oracle):
     scene = pkg.cornell_box()
     hip.upload_scene(scene)
