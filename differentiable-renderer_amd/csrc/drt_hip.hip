@@ -60,6 +60,7 @@ struct RenderJob {
 struct drt_hip_ctx {
     int device = 0;
     int n_cu = 256;
+    uint64_t device_mem = (uint64_t)288 << 30;   // bytes of HBM (hipDeviceProp_t::totalGlobalMem)
     int mesh_blocks_per_cu = 4;           // resident blocks of k_intersect_mesh per CU (occupancy query): its persistent grid
     hipStream_t stream = nullptr;
     std::string err;
@@ -505,7 +506,22 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         }
         path_regen = 1.7 * mean_len + 0.5 < (double)longest;
     }
-    uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : (uint64_t)1 << 24;
+    // Batch = the paths that are in flight at once on the queue route.  The BVH walk wants it LARGE: its launches end in a
+    // tail of ~0.1 ms whatever their size (the list counters run dry, every wave finishes what it holds), so config 4 at full
+    // size (1024^2 x 256 spp) takes 115 / 101 / 98 / 96 ms with 2^24 / 2^26 / 2^27 / 2^28 paths per batch and one GPU's
+    // share of it (33.5 M paths) 14.3 ms in two batches, 13.1 in one.  Every path in flight owns ~0.2 KB of queue lanes,
+    // tape and candidate records (twice that in f64): the default is the largest power of two whose buffers fit in an eighth
+    // of the device's memory, at most 32 GB -- 2^27 paths (27 GB) for a depth-8 f32 render on a 288 GB part.
+    uint64_t cap_default = (uint64_t)1 << 24;
+    {
+        const uint64_t f = sizeof(R) / 4;
+        const uint64_t per_path = f * (112u + 8u * (uint64_t)(D > 0 ? D : 1) + (ctx->has_mesh ? 36u : 0u) + (unbiased ? 110u : 0u)) + 24u;
+        const uint64_t budget = std::min<uint64_t>(ctx->device_mem / 8, (uint64_t)32 << 30);
+        cap_default = (uint64_t)1 << 22;
+        while (cap_default < ((uint64_t)1 << 28) && 2 * cap_default * per_path <= budget)
+            cap_default *= 2;
+    }
+    uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : cap_default;
     if (use_path && rp->batch_paths <= 0)
         cap = total_paths;                 // no per-path memory: one batch covers the frame
     if (const char* e = getenv("DRT_HIP_BATCH_PATHS")) {
@@ -1202,8 +1218,10 @@ int drt_hip_create(int device_id, drt_hip_ctx** out)
     drt_hip_ctx* ctx = new drt_hip_ctx();
     ctx->device = device_id;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->n_cu = prop.multiProcessorCount;
+        ctx->device_mem = (uint64_t)prop.totalGlobalMem;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return DRT_ERR_HIP;

@@ -160,7 +160,8 @@ typedef struct drt_render_params {
                                band_rows rows dealt round-robin to n_shards; this call renders
                                the bands of `shard`. n_shards <= 1 renders everything. */
     uint32_t flags;         /* DRT_RENDER_* */
-    int64_t batch_paths;    /* paths in flight per wavefront batch, <=0 = default */
+    int64_t batch_paths;    /* paths in flight per wavefront batch, <=0 = default: the largest power of two whose
+                             * buffers (~0.2 KB per path) fit in an eighth of the device's memory, at most 32 GB */
     int32_t bounces_per_launch; /* scenes of analytic shapes: bounces a shade launch takes a ray through in
                                registers before survivors are compacted back into the queue (1 = the
                                classic one-launch-per-bounce wavefront, HBM-bound; up to 8). <= 0 = automatic:

@@ -9,7 +9,7 @@ if os.environ.get("AB_ENV_CHILD"):
     import __graft_entry__ as e
     pkg = e.load_package()
     scene = pkg.scene_by_name(os.environ.get("AB_SCENE", "mesh160x160")); cam = pkg.cornell_camera(512, 512)
-    rp = pkg.RenderParams(spp=int(os.environ.get("AB_SPP", "64")), min_bounces=8, absorb=1.0, seed=1)
+    rp = pkg.RenderParams(spp=int(os.environ.get("AB_SPP", "64")), min_bounces=8, absorb=1.0, seed=1, batch_paths=int(os.environ.get("AB_BATCH", "0")))
     r = pkg.HipRenderer(0, lib_path=os.path.abspath(os.environ["AB_LIB"]) if os.environ.get("AB_LIB") else None)
     r.upload_scene(scene)
     UNB, F64 = bool(int(os.environ.get("AB_UNBIASED", "0"))), bool(int(os.environ.get("AB_F64", "0")))
