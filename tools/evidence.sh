@@ -29,6 +29,7 @@ python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-
 python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
 python3 bench.py --scene mesh160x160 --unbiased --no-extra-views --steps 5 --warmup 2 > "$E/bench_unbiased_mesh160x160.json" 2>> "$E/bench.err"
 python3 tools/async_timing.py > "$E/async_host_buffers.txt" 2>&1
+python3 tools/fuzz_reference.py 150 11 > "$E/fuzz_vs_reference.txt" 2>&1
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
 [ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
 for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased; do

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Random render configurations against THE REFERENCE ITSELF, live (run on the GPU box; needs oracle/_ref/ref_harness -- the
+unmodified reference headers behind oracle/ref_harness.cpp, compiled in the build container, shipped as a binary): the
+device's f64 mode must reproduce the reference's image, its backward() gradients and its ray count -- 1e-9, identical
+counts -- for both integration operators of integrate.hpp; the f32 mode is reported beside it.
+Usage: tools/fuzz_reference.py [n_cases] [seed]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+
+pkg = e.load_package()
+oracle = e.load_oracle()
+if not oracle.have_reference():
+    print("oracle/_ref/ref_harness is not here: nothing to compare against")
+    sys.exit(2)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+r = pkg.HipRenderer(0)
+scenes = ["cornell", "cornell_specular", "cornell_walls", "cornell_emissive_wall", "cornell_mirror_wall", "random3", "random7",
+          "random19", "mesh6x8", "mesh10x12f5"]
+worst64 = worst32 = 0.0
+t0 = time.time()
+for case in range(n_cases):
+    name = scenes[rs.randint(len(scenes))]
+    scene = pkg.scene_by_name(name)
+    mesh = name.startswith("mesh")
+    w, h = (int(rs.randint(6, 40)), int(rs.randint(6, 32))) if mesh else (int(rs.randint(8, 96)), int(rs.randint(8, 72)))
+    cam = pkg.cornell_camera(w, h) if not name.startswith("random") else pkg.Camera(w, h).look_at((0.1, 0.0, -0.2), (0, 0.2, 1))
+    fixed = rs.rand() < 0.5
+    b = int(rs.randint(1, 7))
+    p = 1.0 if fixed else float(rs.choice([0.2, 0.35, 0.5, 0.8]))
+    rp = pkg.RenderParams(spp=int(rs.randint(1, 5 if mesh else 13)), min_bounces=b, absorb=p, seed=int(rs.randint(1 << 30)))
+    unbiased = rs.rand() < 0.35
+    adjoint = rs.uniform(0.2, 1.5, (h, w, 3)).astype(np.float32) if rs.rand() < 0.4 else None
+    ref = oracle.render_reference(scene, cam, rp, backward=True, adjoint=adjoint, tracer_mode=2 if unbiased else 0,
+                                  zero_dir_miss=unbiased)
+    r.upload_scene(scene)
+    img, g, st = r.render(cam, rp, backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
+    img32, g32, st32 = r.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
+    assert st["segments"] == ref["stats"]["segments"], (case, name, rp, unbiased, st["segments"], ref["stats"]["segments"])
+    scale = max(1e-300, float(np.abs(ref["grads"]).max()))
+    e64 = float(np.abs(g - ref["grads"]).max() / scale)
+    e32 = float(np.abs(g32 - ref["grads"]).max() / scale)
+    assert e64 < 1e-9, (case, name, rp, unbiased, e64)
+    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    assert np.isfinite(img32).all() and np.isfinite(g32).all()
+    worst64, worst32 = max(worst64, e64), max(worst32, e32)
+    print(f"{case:3d} {name:22s} {w:3d}x{h:<3d} spp {rp.spp:2d} b{b} p{p:g} {'unb' if unbiased else 'bia'} "
+          f"{'adj' if adjoint is not None else '   '} rays {st['segments']:8d} (f32 {st32['segments'] - st['segments']:+d})  "
+          f"grad vs reference: f64 mode {e64:.1e}  f32 mode {e32:.1e}   reference {ref['stats']['seconds'] * 1e3:7.0f} ms", flush=True)
+print(f"FUZZ VS REFERENCE OK: {n_cases} cases in {time.time() - t0:.0f} s; worst gradient deviation from the reference's backward(): "
+      f"f64 mode {worst64:.2e}, f32 mode {worst32:.2e} (f32: single flipped paths of heavy-tailed scenes included)")
