@@ -1114,6 +1114,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                                            d_scene, d_params, tape, nv, cs, gpart, grad, g_rows, g_stride);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                     st->launches[DRT_K_BACKWARD]++;
+                    std::swap(cs.cv_a, cs.nx_a);                // the suffix's first vertex is the chain's next one
+                    std::swap(cs.cv_b, cs.nx_b);
+                    std::swap(cs.cv_hit, cs.nx_hit);
                     if ((rc = timing_begin(ctx, timing, DRT_K_GRADREDUCE)) != DRT_OK) return rc;
                     hipLaunchKernelGGL(k_gradreduce, dim3(g_rows > 0 ? g_rows : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart, gp, g_rows, grad, g_stride);
                     if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;

@@ -1864,8 +1864,10 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
         HitRec<R> h = cs.cv_hit[i];
-        if (h.prim < 0)
+        if (h.prim < 0) {
+            cs.nx_hit[i] = h;                                   // (cv and nx change places after this launch: stays finished)
             continue;
+        }
         const uint32_t ids = cs.ids[i];
         const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
         const R4 gk = cs.g[i];
@@ -1896,9 +1898,8 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
                 R4 o = gk;
                 o.x = gn.x; o.y = gn.y; o.z = gn.z;
                 cs.g[i] = o;
-                cs.cv_a[i] = cs.nx_a[i];
-                cs.cv_b[i] = cs.nx_b[i];
-                cs.cv_hit[i] = cs.nx_hit[i];
+                // (the chain's next vertex -- the suffix's first ray and its hit -- is in nx already, saved by the shade launch
+                //  of depth s; the launcher lets cv and nx change places instead of 32 bytes per path being copied here)
                 // draws the suffix consumed after its base (see k_adj_init)
                 const bool last_null = (tape[(size_t)(K - 1) * N + i].ids & 0xFFFFu) == DRT_ID_NONE;
                 const int top = (K < a.depth_cap || a.cap_is_roulette) ? K : a.depth_cap - 1;
@@ -1910,7 +1911,7 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
         }
         if (!go_on) {
             h.prim = -2;
-            cs.cv_hit[i] = h;
+            cs.nx_hit[i] = h;
         }
     }
 
