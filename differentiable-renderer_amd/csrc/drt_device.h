@@ -95,14 +95,14 @@ __device__ inline uint32_t pid_unpack(double v) { return (uint32_t)v; }
 //                                           bit 31 set   = leaf: first << 3 | count (0 = no child)
 //   node[i][2] = (q_lo.x, q_lo.y, q_lo.z, q_hi.x)   one byte per child in each word
 //   node[i][3] = (q_hi.y, q_hi.z, -, -)
-//   tri_a/b/c[j] (leaf order) = (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, global index, flat index, -)
+//   tri[j][0..2] (leaf order) = (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, global index, flat index, -): ONE 48-byte record per
+//                triangle -- as three arrays a leaf visit touched three cache lines, as records one or two, and a line
+//                is what a visit pays for (walk 4.17 -> 4.01 ms, profiles/r03_walk_experiments.txt)
 //   tri_shade[g] (global triangle order) = (normal.xyz, material | emitter << 16)
 template <typename R>
 struct DevBvh {
     const uint4* node;                  // [n_nodes][4]
-    const typename Q4<R>::T* tri_a;
-    const typename Q4<R>::T* tri_b;
-    const typename Q4<R>::T* tri_c;
+    const typename Q4<R>::T* tri;       // [n_tris][3]
     const typename Q4<R>::T* tri_shade;
     uint32_t n_nodes, n_top, n_tris, pad;
     R lo[3], hi[3];                     // bounds of all triangles (padded like the node boxes): K2's analytic pass uses

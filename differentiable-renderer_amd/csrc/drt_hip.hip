@@ -226,9 +226,11 @@ int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_
     }
     int rc;
     if ((rc = upload_array<uint4>(ctx, nodes, &out->node)) != DRT_OK) return rc;
-    if ((rc = upload_array(ctx, ta, &out->tri_a)) != DRT_OK) return rc;
-    if ((rc = upload_array(ctx, tb, &out->tri_b)) != DRT_OK) return rc;
-    if ((rc = upload_array(ctx, tc, &out->tri_c)) != DRT_OK) return rc;
+    {   // one record of three 16-byte words per triangle: a leaf's triangles are one or two cache lines, not three
+        std::vector<R4> t3(ta.size() * 3);
+        for (size_t j = 0; j < ta.size(); ++j) { t3[j * 3] = ta[j]; t3[j * 3 + 1] = tb[j]; t3[j * 3 + 2] = tc[j]; }
+        if ((rc = upload_array(ctx, t3, &out->tri)) != DRT_OK) return rc;
+    }
     if ((rc = upload_array(ctx, ts, &out->tri_shade)) != DRT_OK) return rc;
     out->n_nodes = (uint32_t)b.nodes.size();
     out->n_top = b.top;

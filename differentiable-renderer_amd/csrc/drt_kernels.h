@@ -658,9 +658,10 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j)
                 if (j < count) {
-                    ta[j] = bvh.tri_a[first + j];
-                    tb[j] = bvh.tri_b[first + j];
-                    tcc[j] = bvh.tri_c[first + j];
+                    const R4* __restrict__ tp = bvh.tri + (size_t)(first + j) * 3;
+                    ta[j] = tp[0];
+                    tb[j] = tp[1];
+                    tcc[j] = tp[2];
                 }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j)
