@@ -522,6 +522,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         cap_default = (uint64_t)1 << 22;
         while (cap_default < ((uint64_t)1 << 28) && 2 * cap_default * per_path <= budget)
             cap_default *= 2;
+        // (a device that other work has filled: no more than half of what is free now, unless the buffers exist already)
+        if (!use_path && rp->batch_paths <= 0 && (uint64_t)ctx->ray_a[0].cap < std::min<uint64_t>(cap_default, total_paths) * 16u * f) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                while (cap_default > ((uint64_t)1 << 22) && cap_default * per_path > (uint64_t)free_b / 2)
+                    cap_default /= 2;
+        }
     }
     uint64_t cap = rp->batch_paths > 0 ? (uint64_t)rp->batch_paths : cap_default;
     if (use_path && rp->batch_paths <= 0)
