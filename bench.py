@@ -338,10 +338,9 @@ def main():
     # for the BVH walk (divergent, latency-bound: neither roof is near -- both fractions are printed).  The other
     # view stays beside it (`hbm` / `valu`).
     issue_bound = register_resident or dominant == "intersect_mesh"
-    top = valu_view if (issue_bound and valu_view) else (hbm_view if not issue_bound else
-                                                         {"achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": None,
-                                                          "note": "no rocprofv3 PMC profile of this workload in profiles/traffic.json: "
-                                                                  "run tools/profile.sh on it"})
+    # (no rocprofv3 PMC profile of this workload in profiles/traffic.json -- tools/profile.sh makes one --: the HBM view, which
+    #  needs none, is what the top level carries then)
+    top = valu_view if (issue_bound and valu_view) else hbm_view
     roofline = {"bound": ("valu-issue (paths are register-resident: the kernel moves almost no bytes)" if register_resident
                           else ("latency (divergent BVH walk out of L2): far from both the HBM and the vector-issue roof" if dominant == "intersect_mesh" else "hbm")),
                 "kernel": "k_" + dominant, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
