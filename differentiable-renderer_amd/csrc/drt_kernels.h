@@ -454,7 +454,6 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
     //  with two regions per image row that is the same eight ROWS for every sample, and the counters whose rows cross
     //  the mesh hold most of the work.)
     typedef typename Q4<R>::T R4;
-    typedef typename Q2<R>::T R2;
     constexpr uint32_t LDS_NODES = DRT_BVH_LDS_NODES;
     __shared__ uint4 s_node[LDS_NODES][4];
     __shared__ uint32_t s_stack[DRT_BVH_STACK][DRT_BLOCK];
@@ -1305,7 +1304,6 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t n_waves = gridDim.x * (DRT_BLOCK / DRT_WAVE);
     const size_t N = a.n_paths;
-    const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
     uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
     if (TAIL && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)     // the walk's list counters (it runs after this kernel)

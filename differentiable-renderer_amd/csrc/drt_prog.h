@@ -138,6 +138,7 @@ template <unsigned long long SIG, int NSIG>
 __device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs,
                                                  V3<float> o, V3<float> d)
 {
+    (void)sc;
     if (NSIG > 0)
         return closest_hit_sig<SIG, NSIG, float>(recs, o, d);
     const V3<float> inv_d = mk<float>(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
