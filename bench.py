@@ -307,12 +307,27 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     depth_text = f"roulette from bounce {a.min_bounces} with absorption {a.absorb:g}" if a.roulette else f"depth {a.depth}"
     depth_key = f"rr{a.absorb:g}b{a.min_bounces}" if a.roulette else f"d{a.depth}"
-    workload_key = f"{a.scene}:{a.width}x{a.height}x{a.spp}:{depth_key}:{'fwd' if a.forward_only else 'fwdbwd'}"
-    if os.path.exists(tpath) and not a.unbiased and a.bounces_per_launch == 0:
+    mode_key = "unbiased" if a.unbiased else ("fwd" if a.forward_only else "fwdbwd")
+    workload_key = f"{a.scene}:{a.width}x{a.height}x{a.spp}:{depth_key}:{mode_key}"
+    pmc_note = None
+    if os.path.exists(tpath) and a.bounces_per_launch == 0:
         try:
             tj = json.load(open(tpath))
-            entry_w = (tj.get("workloads") or {}).get(workload_key) or (tj if tj.get("workload") == workload_key else {})
-            pmc = entry_w.get(dominant) or {}
+            wl = tj.get("workloads") or {}
+            entry_w = wl.get(workload_key) or (tj if tj.get("workload") == workload_key else {})
+            pmc = dict(entry_w.get(dominant) or {})
+            if not pmc and stats["batches"] == 1:
+                # not profiled at this size: the same scene, depth and mode at ANOTHER frame size -- the kernels' instruction and
+                # byte counts per launch are proportional to the camera samples (same paths per sample, same launches per step)
+                for key, ent in sorted(wl.items()):
+                    sc, dims, dk_, md = key.split(":")
+                    if sc == a.scene and dk_ == depth_key and md == mode_key and ent.get(dominant):
+                        w_, h_, s_ = (int(x) for x in dims.split("x"))
+                        scale = (a.width * a.height * a.spp) / float(w_ * h_ * s_)
+                        pmc = {k2: (v2 * scale if k2.endswith("_per_launch") or k2 in ("fetch_raw_bytes", "write_bytes") else v2)
+                               for k2, v2 in ent[dominant].items() if isinstance(v2, (int, float))}
+                        pmc_note = f"PMC counts of '{key}' scaled by the camera samples ({scale:g} x): this size was not profiled"
+                        break
         except Exception:
             pmc = {}
     dk = per_kernel.get(dominant, {"achieved_GBs": 0.0, "launches_per_step": 1, "ms_per_step": 0.0})
@@ -349,6 +364,7 @@ def main():
                 "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json, rocprofv3 --pmc, FETCH_SIZE "
                                 "doubled per the gfx950 correction) over the live launch time" if traffic else None,
                 "avg_launch_ms": round(launch_ms, 4),
+                "pmc_note": pmc_note,
                 "hbm": hbm_view, "valu": valu_view,
                 "kernels": per_kernel}
     if dominant == "intersect_mesh" and pmc.get("lane_stats"):

@@ -12,9 +12,10 @@ bash tools/profile.sh ${T}_config5 cornell_specular:2048x2048x128:d16:fwdbwd --c
 bash tools/profile.sh ${T}_config4 mesh160x160:1024x1024x32:d8:fwdbwd --config 4 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0.5 --min-bounces 1 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_unbiased cornell:512x512x64:d8:unbiased --unbiased >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_fwd cornell:512x512x64:d8:fwd --config 2 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_unbiased_mesh mesh160x160:512x512x64:d8:unbiased  --scene mesh160x160 --unbiased >> "$E/prof.log" 2>&1
 # bench.py quotes PMC numbers only for the workloads profiled above (one entry each)
-python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_config4/traffic.json gpurun_out/prof_${T}_roulette/traffic.json gpurun_out/prof_${T}_unbiased/traffic.json gpurun_out/prof_${T}_unbiased_mesh/traffic.json >> "$E/prof.log" 2>&1
+python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_config4/traffic.json gpurun_out/prof_${T}_roulette/traffic.json gpurun_out/prof_${T}_unbiased/traffic.json gpurun_out/prof_${T}_unbiased_mesh/traffic.json gpurun_out/prof_${T}_fwd/traffic.json >> "$E/prof.log" 2>&1
 cp profiles/traffic.json "$E/traffic_merged.json"
 python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
 python3 bench.py > "$E/bench.json" 2> "$E/bench.err"
@@ -33,7 +34,7 @@ python3 tools/async_timing.py > "$E/async_host_buffers.txt" 2>&1
 python3 tools/fuzz_reference.py 150 11 > "$E/fuzz_vs_reference.txt" 2>&1
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
 [ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
-for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh; do
+for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh ${T}_fwd; do
   P=gpurun_out/prof_$t
   cp $P/summary.txt "$E/${t}_rocprofv3_summary.txt"
   cp $P/traffic.json "$E/${t}_traffic.json"
