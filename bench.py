@@ -316,17 +316,18 @@ def main():
             wl = tj.get("workloads") or {}
             entry_w = wl.get(workload_key) or (tj if tj.get("workload") == workload_key else {})
             pmc = dict(entry_w.get(dominant) or {})
-            if not pmc and stats["batches"] == 1:
-                # not profiled at this size: the same scene, depth and mode at ANOTHER frame size -- the kernels' instruction and
-                # byte counts per launch are proportional to the camera samples (same paths per sample, same launches per step)
+            if not pmc:
+                # not profiled at this size: the same scene, depth and mode at ANOTHER frame size -- instructions and bytes per
+                # UNIT of the kernel's work (segments, candidate rays) do not depend on the frame
+                my_units = per_kernel.get(dominant, {}).get("units_per_step", 0) / max(1, per_kernel.get(dominant, {}).get("launches_per_step", 1))
                 for key, ent in sorted(wl.items()):
                     sc, dims, dk_, md = key.split(":")
-                    if sc == a.scene and dk_ == depth_key and md == mode_key and ent.get(dominant):
-                        w_, h_, s_ = (int(x) for x in dims.split("x"))
-                        scale = (a.width * a.height * a.spp) / float(w_ * h_ * s_)
+                    e2 = ent.get(dominant) or {}
+                    if sc == a.scene and dk_ == depth_key and md == mode_key and e2.get("units_per_launch") and my_units > 0:
+                        scale = my_units / float(e2["units_per_launch"])
                         pmc = {k2: (v2 * scale if k2.endswith("_per_launch") or k2 in ("fetch_raw_bytes", "write_bytes") else v2)
-                               for k2, v2 in ent[dominant].items() if isinstance(v2, (int, float))}
-                        pmc_note = f"PMC counts of '{key}' scaled by the camera samples ({scale:g} x): this size was not profiled"
+                               for k2, v2 in e2.items() if isinstance(v2, (int, float))}
+                        pmc_note = f"PMC counts of '{key}' carried over per unit of work ({scale:g} x per launch): this size was not profiled"
                         break
         except Exception:
             pmc = {}

@@ -100,4 +100,13 @@ for k, t in traffic.items():
                         # (MI355X_MICROARCH.md), 256 CUs x 4 SIMDs at 2.4 GHz -- 1.0 would be a saturated pipe
                         "valu_wave_activity": round(summary[k].get("SQ_ACTIVE_INST_VALU", 0.0) * 2.0 / (256 * 4 * us * 1e-6 * 2.4e9), 4),
                         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB -> bytes, FETCH x2 (gfx950)"}
+# units (segments, candidate rays, paths: drt_hip_stats.units) per launch, from the bench line of the traced run: what lets
+# bench.py carry the per-launch counts over to another frame size of the same scene (counts per UNIT do not depend on it)
+try:
+    bt = json.load(open(os.path.join(out, "bench_trace.json")))
+    for name, kd in (bt.get("roofline", {}).get("kernels") or {}).items():
+        if name in tj and isinstance(tj[name], dict) and kd.get("launches_per_step"):
+            tj[name]["units_per_launch"] = kd["units_per_step"] / kd["launches_per_step"]
+except Exception:
+    pass
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
