@@ -432,6 +432,36 @@ def main():
         if backward:
             fwd_view = dict(timed_variant(backward=False), note="forward only (BASELINE config 2 when the headline is config 3)")
 
+    # Two contexts on this device rendering the headline's frames alternately (no collective): the last, partly filled round of
+    # one frame's k_path grid is filled by the next frame's first -- what a render loop over several views gets
+    two_ctx_view = None
+    if extra and register_resident and not a.unbiased and world == 1:
+        try:
+            r2 = pkg.HipRenderer(0)
+            r2.upload_scene(scene)
+            prp = pkg.RenderParams(spp=a.spp, min_bounces=a.min_bounces, absorb=a.absorb, seed=1, batch_paths=a.batch_paths)
+            out2 = torch.zeros_like(out_rgb)
+            g2 = torch.zeros_like(grads[0])
+            pair = ((r, out_rgb, grads[0]), (r2, out2, g2))
+
+            def both(n):
+                for i in range(n):
+                    rr, oo, gg = pair[i & 1]
+                    rr.render_device(cam, prp, oo.data_ptr(), gg.data_ptr() if backward else 0, backward=backward)
+                r.synchronize()
+                r2.synchronize()
+            both(4)
+            n2 = max(4, min(2 * a.steps, 40))
+            t6 = time.perf_counter()
+            both(n2)
+            dt6 = (time.perf_counter() - t6) / n2
+            two_ctx_view = {"value": round(total_segments / dt6 * 1e-6, 2), "unit": "Mray/s", "ms_per_step": round(dt6 * 1e3, 4),
+                            "note": "the same frames rendered alternately by TWO contexts on this device (each on its own stream, "
+                                    "no collective): consecutive k_path grids overlap"}
+            r2.close()
+        except Exception as exc:
+            two_ctx_view = {"error": f"{type(exc).__name__}: {exc}"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         oracle = entry.load_oracle()
@@ -595,7 +625,7 @@ def main():
                        "capped_paths_per_step": stats["capped_paths"]},
             "weak_scaling": weak_scaling,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
-            "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view,
+            "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view, "two_contexts": two_ctx_view,
         }
         print(json.dumps(line), flush=True)
     # teardown in the same order on every rank: the library's communicator first (all ranks are still here), then the
