@@ -85,6 +85,17 @@ struct drt_hip_ctx {
     DevBvh<double> bvh_d{};
     std::vector<void*> mesh_allocs;
 
+    // FRAMES THAT OVERLAP.  A k_path grid ends with a last, partly filled round of waves, and the next frame's grid, on the same
+    // stream, cannot start before it is over: 5-6 % of a fixed-depth frame, 25 % of a roulette-terminated one
+    // (tools/two_frames.py).  Renders that do not wait for their results (device pointers without DRT_RENDER_SYNC) therefore
+    // put the k_path launches of consecutive frames on TWO streams of their own, alternating, each with its own set of
+    // partial-sum buffers; the finishing launch of every frame stays on the context's stream, in frame order, behind an
+    // event -- what the caller sees (outputs written in stream order) does not change.
+    hipStream_t path_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_path[2] = {nullptr, nullptr};
+    bool overlap_next = false;            // set around render_launch by the callers whose renders do not wait
+    bool slot_used[2] = {false, false};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
+    DevBuf fpart2, gpart2, counts2;       // k_path's partial sums of the odd frames
     DevBuf ray_a[2], ray_b[2], ray_id[2], hit, hit2, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[2], film, gpart, grad[2], adjoint, out[2];   // [2]: one set per frame in flight (drt_hip_render_async), slot 0 otherwise
     std::vector<hipEvent_t> event_pool;
@@ -592,9 +603,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     ChainState<R> cs;
     memset(&cs, 0, sizeof cs);
     size_t cw = (size_t)(D + 1) * max_regions;   // counts[depth][region] of one batch
+    const bool overlap_ok = ctx->overlap_next && use_path && !timing && gimg_param < 0 && ctx->path_stream[0] && ctx->ev_copied[0];
+    DevBuf& fpart_buf = overlap_ok && ctx->slot ? ctx->fpart2 : ctx->fpart;
+    DevBuf& gpart_buf = overlap_ok && ctx->slot ? ctx->gpart2 : ctx->gpart;
+    DevBuf& counts_buf = overlap_ok && ctx->slot ? ctx->counts2 : ctx->counts;
     if (use_path) {
         cw = 2 * path_waves;                     // [segments | capped paths] per wave
-        if ((rc = ensure(ctx, ctx->fpart, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, fpart_buf, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
         if (gimg_param >= 0)
             if ((rc = ensure(ctx, ctx->gpix, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
     } else {
@@ -637,7 +652,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     if ((rc = ensure(ctx, ctx->nv, N * sizeof(uint32_t))) != DRT_OK) return rc;
     }
     *n_count_words = cw;
-    if ((rc = ensure(ctx, ctx->counts, cw * sizeof(uint32_t))) != DRT_OK) return rc;
+    if ((rc = ensure(ctx, counts_buf, cw * sizeof(uint32_t))) != DRT_OK) return rc;
     if ((rc = ensure(ctx, ctx->segtotal[ctx->slot], DRT_TOTAL_WORDS * sizeof(unsigned long long))) != DRT_OK) return rc;   // segments, queue rays read, written, capped, K2 rays, walked candidates
     // a k_path launch that covers the whole frame is followed by ONE finishing launch that WRITES image, gradients and
     // totals (k_path_finish); every other route accumulates into zeroed buffers
@@ -660,7 +675,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         // rows per block: 24 for the register paths (<= 8 parameters), else one per parameter channel (LDS accumulators)
         const size_t rows = ctx->n_params <= DRT_FAST_PARAMS ? (size_t)DRT_FAST_PARAMS * 3
                                                              : (size_t)std::min(ctx->n_params, DRT_LDS_PARAMS) * 3;
-        if ((rc = ensure(ctx, ctx->gpart, blocks * rows * sizeof(double))) != DRT_OK) return rc;
+        if ((rc = ensure(ctx, gpart_buf, blocks * rows * sizeof(double))) != DRT_OK) return rc;
     }
 
     BatchArgs a;
@@ -703,7 +718,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     TapeRec<R>* tape = (TapeRec<R>*)ctx->tape.p;
     uint32_t* nv = (uint32_t*)ctx->nv.p;
     double* grad = (double*)ctx->grad[ctx->slot].p;
-    double* gpart = (double*)ctx->gpart.p;
+    double* gpart = (double*)gpart_buf.p;
     const int n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
     // gradient partials: gpart[block][g_stride], rows [0, g_rows) are reduced over the blocks by K7
     const bool g_general = ctx->n_params > DRT_FAST_PARAMS;
@@ -742,7 +757,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
             a.Sb = ((uint32_t)spp - s0) < Sb ? ((uint32_t)spp - s0) : Sb;
             a.n_paths = a.Pb * a.Sb;
             a.n_regions = (a.n_paths + region_size - 1) / region_size;
-            uint32_t* counts = (uint32_t*)ctx->counts.p;   // reused by every batch (stream order)
+            uint32_t* counts = (uint32_t*)counts_buf.p;   // reused by every batch (stream order)
             if (use_path) {
                 // ---- the whole batch in ONE launch: camera -> path -> radiance sums + gradient partials
                 PathArgs pa;
@@ -766,7 +781,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 pa.inv_W = 1.0 / (double)a.W; pa.inv_H = 1.0 / (double)a.H;
                 const size_t n_waves = (size_t)pa.n_groups * pa.n_ranges;
                 const int gpath = (int)((n_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
-                double* fpart = film ? (double*)ctx->fpart.p : (double*)nullptr;
+                double* fpart = film ? (double*)fpart_buf.p : (double*)nullptr;
                 double* gpix = gimg_param >= 0 ? (double*)ctx->gpix.p : (double*)nullptr;   // gradient image partials
                 pa.gimg_param = gimg_param;
                 // the kinds of the reference's own scene are compiled in (no per-shape branches); any other
@@ -776,14 +791,29 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 static const bool sig64_env = !(getenv("DRT_HIP_PATH_SIG_F64") && atoi(getenv("DRT_HIP_PATH_SIG_F64")) == 0);
                 const bool cornell_sig = sig_env && (sizeof(R) == 4 || sig64_env) && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
                 unsigned long long* ptotal = path_finish ? (unsigned long long*)ctx->segtotal[ctx->slot].p : (unsigned long long*)nullptr;
+                // (frames that overlap: this frame's grid goes to the slot's own stream, behind whoever still uses the slot's
+                //  buffers, and the finishing launch on the context's stream waits for it.  Scene and parameter uploads block
+                //  until they are done, so the grid needs nothing from the context's stream -- unless the call brings an adjoint
+                //  image, which the caller may have produced in that stream's order: then the frame keeps its place in it.)
+                hipStream_t ks = ctx->stream;
+                const bool overlap = overlap_ok && path_finish;
+                if (overlap) {
+                    ks = ctx->path_stream[ctx->slot];
+                    if (d_adjoint) {
+                        HIPCHK(ctx, hipEventRecord(ctx->ev_begin[ctx->slot], ctx->stream));
+                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_begin[ctx->slot], 0));
+                    }
+                    if (ctx->slot_used[ctx->slot])
+                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_copied[ctx->slot], 0));
+                }
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
     do {                                                                                                                 \
         if (path_regen)                                                                                                  \
-            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,          \
                                pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,         \
                                pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
     } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
@@ -799,9 +829,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     do {                                                                                                                      \
         if (cornell_sig)                                                                                                      \
             hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, DRT_SIG_CORNELL, DRT_NSIG_CORNELL>), dim3(gpath), dim3(DRT_BLOCK), 0, \
-                               ctx->stream, pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                   \
+                               ks, pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                            \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, 0ull, 0>), dim3(gpath), dim3(DRT_BLOCK), 0, ctx->stream, pa,      \
+            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, 0ull, 0>), dim3(gpath), dim3(DRT_BLOCK), 0, ks, pa,               \
                                d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                                    \
     } while (0)
                     if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }
@@ -820,6 +850,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #undef DRT_LAUNCH_PATH_SIG
 #undef DRT_LAUNCH_PATH
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
+                if (overlap) {
+                    HIPCHK(ctx, hipEventRecord(ctx->ev_path[ctx->slot], ks));
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_path[ctx->slot], 0));
+                }
                 st->launches[DRT_K_PATH]++;
                 st->path_bytes += (film ? (uint64_t)pa.n_ranges * a.Pb * 3 * sizeof(double) : 0) +
                                   (backward ? (uint64_t)gpath * DRT_FAST_PARAMS * 3 * sizeof(double) : 0) + 2 * n_waves * sizeof(uint32_t);
@@ -1238,6 +1272,21 @@ int drt_hip_create(int device_id, drt_hip_ctx** out)
         delete ctx;
         return DRT_ERR_HIP;
     }
+    {   // Every stream of the context is made HERE, in this order, before the process makes any other: which of them run
+        // side by side depends on the order HIP has seen them in (measured: the two k_path streams made later, next to the
+        // copy stream, never overlapped their grids; made here they do -- and the copy stream made later, after them, no
+        // longer overlapped its launch with the next frame: 0.81 -> 0.90 ms through host buffers).
+        static const bool overlap_env = !(getenv("DRT_HIP_OVERLAP_FRAMES") && atoi(getenv("DRT_HIP_OVERLAP_FRAMES")) == 0);
+        for (int i = 0; i < 2 && overlap_env; ++i)
+            if (hipStreamCreateWithFlags(&ctx->path_stream[i], hipStreamNonBlocking) != hipSuccess)
+                ctx->path_stream[i] = nullptr;
+        if (!ctx->path_stream[1]) ctx->path_stream[0] = nullptr;
+        // (highest priority: the copies and the all-reduce of frame i must not queue behind the kernels of frame i + 1)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+            ctx->copy_stream = nullptr;
+    }
     {   // the BVH walk is a persistent kernel whose waves own strided streams of rays: its grid must be exactly what
         // is resident at once (more blocks would run as a second round behind the first, at half the occupancy)
         int nb = 0;
@@ -1271,7 +1320,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->hit2, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->fpart2, &ctx->gpart2, &ctx->counts2, &ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->hit2, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal[0], &ctx->segtotal[1], &ctx->film, &ctx->gpart, &ctx->grad[0], &ctx->grad[1],
                       &ctx->adjoint, &ctx->out[0], &ctx->out[1]};
@@ -1292,6 +1341,11 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     }
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->path_stream[i]) { (void)hipStreamSynchronize(ctx->path_stream[i]); (void)hipStreamDestroy(ctx->path_stream[i]); }
+        if (ctx->ev_begin[i]) (void)hipEventDestroy(ctx->ev_begin[i]);
+        if (ctx->ev_path[i]) (void)hipEventDestroy(ctx->ev_path[i]);
+    }
     release(ctx->probe);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
@@ -1660,6 +1714,8 @@ static int ensure_copy_stream(drt_hip_ctx* ctx)
     for (int i = 0; i < 2; ++i) {
         if (!ctx->ev_rendered[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rendered[i], hipEventDisableTiming));
         if (!ctx->ev_copied[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming));
+        if (!ctx->ev_begin[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_begin[i], hipEventDisableTiming));
+        if (!ctx->ev_path[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_path[i], hipEventDisableTiming));
     }
     return DRT_OK;
 }
@@ -1991,14 +2047,20 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     // render only waits for the all-reduce of the render before the previous one (long finished)
     const bool ar_async = rp && gimg_param < 0 && (rp->flags & DRT_RENDER_ALLREDUCE_ASYNC) && (rp->flags & DRT_RENDER_BACKWARD) &&
                           (rp->flags & DRT_RENDER_DEVICE_OUT) && ctx->comm;
-    if (ar_async) {
+    // Device-pointer renders that do not wait (no DRT_RENDER_SYNC, no statistics): consecutive frames alternate between the
+    // context's two sets of per-frame buffers, so that their k_path grids can overlap (render_impl: path_stream)
+    const bool dev_async = rp && gimg_param < 0 && (rp->flags & DRT_RENDER_DEVICE_OUT) &&
+                           !(rp->flags & (DRT_RENDER_SYNC | DRT_RENDER_TIMING)) && !stats;
+    if (ar_async || dev_async) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         if ((rc = ensure_copy_stream(ctx)) != DRT_OK) return rc;
         ctx->slot = (int)(ctx->dev_frames & 1);
-        if (ctx->dev_frames >= 2)
+        if (ar_async && ctx->slot_used[ctx->slot])
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[ctx->slot], 0));
     }
+    ctx->overlap_next = ar_async || dev_async;
     rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
+    ctx->overlap_next = false;
     if (rc != DRT_OK) {
         abort_comm_after_failure(ctx, rp);
         ctx->slot = 0;
@@ -2011,6 +2073,7 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         if (e != hipSuccess) { ctx->err = std::string("render: ") + hipGetErrorString(e); ctx->slot = 0; return DRT_ERR_HIP; }
         if ((rc = render_reduce(ctx, ctx->copy_stream)) == DRT_OK) rc = render_collect(ctx, true, ctx->copy_stream);
         if (rc == DRT_OK && hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream) != hipSuccess) rc = DRT_ERR_HIP;
+        if (rc == DRT_OK) ctx->slot_used[slot] = true;
         ++ctx->dev_frames;
         if (rc == DRT_OK && ctx->job.sync)
             HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
@@ -2018,9 +2081,15 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         ctx->slot = 0;
         return rc;
     }
-    if ((rc = render_reduce(ctx)) != DRT_OK) return rc;
-    if ((rc = render_collect(ctx)) != DRT_OK) return rc;
-    return render_finish(ctx);
+    if ((rc = render_reduce(ctx)) == DRT_OK) rc = render_collect(ctx);
+    if (rc == DRT_OK && dev_async) {            // the slot's buffers are free once the stream has come this far
+        if (hipEventRecord(ctx->ev_copied[ctx->slot], ctx->stream) != hipSuccess) rc = DRT_ERR_HIP;
+        else ctx->slot_used[ctx->slot] = true;
+        ++ctx->dev_frames;
+    }
+    if (rc == DRT_OK) rc = render_finish(ctx);
+    ctx->slot = 0;
+    return rc;
 }
 
 extern "C" {

@@ -23,7 +23,9 @@
  * across the ABI; the caller owns every host buffer; the context owns device memory and its
  * stream; a context is not thread-safe; calls are synchronous unless DRT_RENDER_DEVICE_OUT is
  * set (then outputs are device pointers, written on the context's stream, and the call returns
- * after enqueueing unless DRT_RENDER_SYNC is also set).
+ * after enqueueing unless DRT_RENDER_SYNC is also set; the path kernels of consecutive such frames
+ * may run side by side on streams of the context's own -- the outputs are still written in the
+ * order of the context's stream, and a device adjoint image is read in that order too).
  *
  *   drt_hip_create_group    the same path on SEVERAL GPUs of one node from one process (SURVEY 8b:
  *   drt_hip_comm_init_rank  "ctx owns device memory/streams/RCCL comms"): the rows of the frame are

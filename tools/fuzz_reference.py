@@ -41,16 +41,20 @@ for case in range(n_cases):
     r.upload_scene(scene)
     img, g, st = r.render(cam, rp, backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
     img32, g32, st32 = r.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
-    assert st["segments"] == ref["stats"]["segments"], (case, name, rp, unbiased, st["segments"], ref["stats"]["segments"])
+    # (the device ends a path at depth 64 -- DRT_MAX_DEPTH -- and says so in capped_paths; the reference goes on: with an
+    #  absorption of 0.2 one path in half a million gets there, its remaining segments are missing from the device's count and,
+    #  under the unbiased operator, its later suffixes draw other numbers)
+    capped = st["capped_paths"]
+    assert capped > 0 or st["segments"] == ref["stats"]["segments"], (case, name, rp, unbiased, st["segments"], ref["stats"]["segments"])
     scale = max(1e-300, float(np.abs(ref["grads"]).max()))
     e64 = float(np.abs(g - ref["grads"]).max() / scale)
     e32 = float(np.abs(g32 - ref["grads"]).max() / scale)
-    assert e64 < 1e-9, (case, name, rp, unbiased, e64)
+    assert e64 < (1e-9 if capped == 0 else 1e-6), (case, name, rp, unbiased, e64, capped)
     np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
     assert np.isfinite(img32).all() and np.isfinite(g32).all()
     worst64, worst32 = max(worst64, e64), max(worst32, e32)
     print(f"{case:3d} {name:22s} {w:3d}x{h:<3d} spp {rp.spp:2d} b{b} p{p:g} {'unb' if unbiased else 'bia'} "
-          f"{'adj' if adjoint is not None else '   '} rays {st['segments']:8d} (f32 {st32['segments'] - st['segments']:+d})  "
+          f"{'adj' if adjoint is not None else '   '} rays {st['segments']:8d} (f32 {st32['segments'] - st['segments']:+d}{', %d capped at depth 64: %+d rays' % (capped, st['segments'] - ref['stats']['segments']) if capped else ''})  "
           f"grad vs reference: f64 mode {e64:.1e}  f32 mode {e32:.1e}   reference {ref['stats']['seconds'] * 1e3:7.0f} ms", flush=True)
 print(f"FUZZ VS REFERENCE OK: {n_cases} cases in {time.time() - t0:.0f} s; worst gradient deviation from the reference's backward(): "
       f"f64 mode {worst64:.2e}, f32 mode {worst32:.2e} (f32: single flipped paths of heavy-tailed scenes included)")
