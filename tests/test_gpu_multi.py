@@ -234,6 +234,64 @@ def test_async_host_renders_match_the_synchronous_call_bit_for_bit(pkg, hip):
         np.testing.assert_array_equal(got_b[1], ref[3][1])
 
 
+def test_device_frames_overlap_and_stay_in_order(pkg):
+    """Device-pointer renders that do not wait: the k_path grids of consecutive frames run on two streams of the context's
+    own (alternating sets of partial-sum buffers), every frame's finishing launch on the context's stream in frame order.
+    Results equal the synchronous call bit for bit -- separate output buffers, ONE output buffer written by every frame (the
+    last frame must be what is left), a parameter update between two frames, a device adjoint image -- for the fixed-depth
+    and the roulette-terminated kernel."""
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)                 # (PyTorch's runtime before the library's, as in bench.py)
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(128, 96)
+    r = pkg.HipRenderer(0)
+    hip = pkg.HipRenderer(0)                   # (the synchronous renders it is compared with)
+    try:
+        r.upload_scene(scene)
+        hip.upload_scene(scene)
+        for b, p in ((4, 1.0), (1, 0.4)):
+            rps = [pkg.RenderParams(spp=6, min_bounces=b, absorb=p, seed=s) for s in range(1, 8)]
+            ref = [hip.render(cam, rp, backward=True) for rp in rps]
+            outs = [torch.zeros((96, 128, 3), dtype=torch.float32, device=dev) for _ in rps]
+            grads = [torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev) for _ in rps]
+            for rp, o, g in zip(rps, outs, grads):
+                r.render_device(cam, rp, o.data_ptr(), g.data_ptr())
+            r.synchronize()
+            for (rimg, rgr, _), o, g in zip(ref, outs, grads):
+                np.testing.assert_array_equal(o.cpu().numpy(), rimg)
+                np.testing.assert_array_equal(g.cpu().numpy(), rgr)
+            one_o, one_g = outs[0], grads[0]
+            for rp in rps:                                     # every frame into the same buffers: frame order decides
+                r.render_device(cam, rp, one_o.data_ptr(), one_g.data_ptr())
+            r.synchronize()
+            np.testing.assert_array_equal(one_o.cpu().numpy(), ref[-1][0])
+            np.testing.assert_array_equal(one_g.cpu().numpy(), ref[-1][1])
+        # a parameter update between two frames in flight, and a device adjoint image
+        rp = pkg.RenderParams(spp=6, min_bounces=4, absorb=1.0, seed=3)
+        newp = np.array(scene.params) * 0.6 + 0.1
+        before = hip.render(cam, rp, backward=True)
+        hip.update_params(newp)
+        adj = np.random.RandomState(2).uniform(0.2, 1.4, (96, 128, 3)).astype(np.float32)
+        after = hip.render(cam, rp, backward=True, adjoint=adj)
+        o1, o2 = (torch.zeros((96, 128, 3), dtype=torch.float32, device=dev) for _ in range(2))
+        g1, g2 = (torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev) for _ in range(2))
+        d_adj = torch.from_numpy(adj).to(dev)
+        torch.cuda.synchronize()
+        r.render_device(cam, rp, o1.data_ptr(), g1.data_ptr())
+        r.update_params(newp)
+        r.render_device(cam, rp, o2.data_ptr(), g2.data_ptr(), adjoint_ptr=d_adj.data_ptr())
+        r.render_device(cam, rp, o1.data_ptr(), 0, backward=False)          # (forward only, the other set of buffers again)
+        r.synchronize()
+        np.testing.assert_array_equal(g1.cpu().numpy(), before[1])
+        np.testing.assert_array_equal(o2.cpu().numpy(), after[0])
+        np.testing.assert_array_equal(g2.cpu().numpy(), after[1])
+        np.testing.assert_array_equal(o1.cpu().numpy(), after[0])
+    finally:
+        r.close()
+        hip.close()
+
+
 def test_allreduce_on_the_second_stream_gives_the_same_gradients(pkg):
     """DRT_RENDER_ALLREDUCE_ASYNC (device buffers, a communicator): all-reduce and gradient copy run on the context's second
     stream, the steps alternate between two gradient sets; after drt_hip_synchronize every step's gradient equals the
