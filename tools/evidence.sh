@@ -32,6 +32,9 @@ python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
 python3 bench.py --scene mesh160x160 --unbiased --no-extra-views --steps 5 --warmup 2 > "$E/bench_unbiased_mesh160x160.json" 2>> "$E/bench.err"
 python3 tools/async_timing.py > "$E/async_host_buffers.txt" 2>&1
 python3 tools/fuzz_reference.py 150 11 > "$E/fuzz_vs_reference.txt" 2>&1
+python3 tools/fuzz_overlap.py 300 1 2>&1 | grep -v amdgpu > "$E/fuzz_overlap.txt"
+(echo "## frames overlapping (default)"; python3 tools/one_ctx_frames.py 2>&1 | grep -v amdgpu; echo "## DRT_HIP_OVERLAP_FRAMES=0"; DRT_HIP_OVERLAP_FRAMES=0 python3 tools/one_ctx_frames.py 2>&1 | grep -v amdgpu) > "$E/one_ctx_frames.txt"
+python3 tools/two_frames.py cornell 2>&1 | grep -v amdgpu > "$E/two_frames.txt"
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
 [ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
 for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh ${T}_fwd; do
