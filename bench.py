@@ -122,6 +122,8 @@ def parse_args(argv):
     ap.add_argument("--allreduce", default="async", choices=["async", "stream"],
                     help="library all-reduce on the context's second stream, overlapping the next step (async, default) or "
                          "in stream order between two steps (stream)")
+    ap.add_argument("--preheat-ms", type=float, default=60.0,
+                    help="setup: drive the step loop for this long before the warm-up steps (device clocks out of idle); 0 = none")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--ref-seconds", type=float, default=8.0,
                     help="target duration of the sample the reference itself (oracle/_ref/ref_harness, when present) is timed on; 0 = skip")
@@ -230,6 +232,19 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # Setup, before the W warm-up steps: the device comes out of idle at low clocks and takes some tens of milliseconds of
+    # load to reach its operating point (measured on config 3, ms per frame over 5 / 10 / 20 frames from a cold start: 0.865 /
+    # 0.803 / 0.758, then flat) -- W = 5 steps of 0.8 ms do not get it there, and the timed region of K = 20 steps would
+    # measure the ramp.  So the loop is driven for --preheat-ms (default 60) first; reported in the line (`preheat_ms`).
+    preheat_frames = 0
+    if a.preheat_ms > 0:
+        tp = time.perf_counter()
+        while (time.perf_counter() - tp) * 1e3 < a.preheat_ms and preheat_frames < 400:
+            step()
+            preheat_frames += 1
+            if preheat_frames % 8 == 0:
+                fence()
+        fence()
     for _ in range(a.warmup):
         step()
     fence()
@@ -625,6 +640,7 @@ def main():
                        "capped_paths_per_step": stats["capped_paths"]},
             "weak_scaling": weak_scaling,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
+            "preheat_ms": a.preheat_ms, "preheat_frames": preheat_frames,
             "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view, "two_contexts": two_ctx_view,
         }
         print(json.dumps(line), flush=True)
