@@ -238,11 +238,22 @@ def main():
     # measure the ramp.  So the loop is driven for --preheat-ms (default 60) first; reported in the line (`preheat_ms`).
     preheat_frames = 0
     if a.preheat_ms > 0:
+        # (the same number of frames on every rank -- each carries a collective: one frame is timed, the slowest rank's time
+        #  decides)
+        step()
+        fence()
         tp = time.perf_counter()
-        while (time.perf_counter() - tp) * 1e3 < a.preheat_ms and preheat_frames < 400:
+        step()
+        fence()
+        t_frame = time.perf_counter() - tp
+        if use_dist:
+            tt = torch.tensor([t_frame], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_frame = float(tt.item())
+        preheat_frames = int(max(1, min(400, a.preheat_ms * 1e-3 / max(t_frame, 1e-6))))
+        for i in range(preheat_frames):
             step()
-            preheat_frames += 1
-            if preheat_frames % 8 == 0:
+            if (i + 1) % 8 == 0:
                 fence()
         fence()
     for _ in range(a.warmup):
