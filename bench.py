@@ -587,23 +587,24 @@ def main():
             r.render(cam, hrp, backward=backward, unbiased=unb)
         dt3 = (time.perf_counter() - t3) / n_host
         r.wait(r.render_async(cam, hrp, backward=backward, unbiased=unb))
-        bufs = [(np.zeros((a.height, a.width, 3), dtype=np.float32), np.zeros((scene.n_params, 3), dtype=np.float64)) for _ in range(2)]
+        n_fly = pkg.FRAMES_IN_FLIGHT
+        bufs = [(np.zeros((a.height, a.width, 3), dtype=np.float32), np.zeros((scene.n_params, 3), dtype=np.float64)) for _ in range(n_fly)]
         for im, _g in bufs:
-            im.fill(0.0)                  # (touched once: a render loop keeps its two sets of buffers)
+            im.fill(0.0)                  # (touched once: a render loop keeps a set of buffers per frame in flight)
         t3 = time.perf_counter()
-        prev_h = None
+        flying = []
         for it in range(n_host):
-            h = r.render_async(cam, hrp, backward=backward, unbiased=unb, img_out=bufs[it & 1][0],
-                               grads_out=bufs[it & 1][1] if backward else None)
-            if prev_h is not None:
-                r.wait(prev_h, want_stats=False)
-            prev_h = h
-        r.wait(prev_h, want_stats=False)
+            flying.append(r.render_async(cam, hrp, backward=backward, unbiased=unb, img_out=bufs[it % n_fly][0],
+                                         grads_out=bufs[it % n_fly][1] if backward else None))
+            if len(flying) == n_fly:
+                r.wait(flying.pop(0), want_stats=False)
+        while flying:
+            r.wait(flying.pop(0), want_stats=False)
         dt3a = (time.perf_counter() - t3) / n_host
         host_buffers = {"value": round(total_segments / dt3a * 1e-6, 2), "unit": "Mray/s",
                         "ms_per_step": round(dt3a * 1e3, 4),
                         "frac_of_value": round((total_segments / dt3a * 1e-6) / value, 4) if value > 0 else None,
-                        "note": "drt_hip_render_async + drt_hip_wait with host out_rgb / out_param_grad, two frames in flight "
+                        "note": "drt_hip_render_async + drt_hip_wait with host out_rgb / out_param_grad, up to four frames in flight "
                                 "(PCIe D2H of image and gradients included, overlapped with the next frame's kernels)",
                         "sync": {"value": round(total_segments / dt3 * 1e-6, 2), "ms_per_step": round(dt3 * 1e3, 4),
                                  "note": "drt_hip_render: returns with the results in the caller's buffers"}}

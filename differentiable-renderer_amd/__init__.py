@@ -35,6 +35,7 @@ RENDER_F64 = 0x10
 RENDER_UNBIASED = 0x20
 RENDER_ALLREDUCE = 0x40
 RENDER_ALLREDUCE_ASYNC = 0x80
+FRAMES_IN_FLIGHT = 4          # drt_hip_render_async: DRT_HIP_FRAMES_IN_FLIGHT
 MAX_DEPTH = 64
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]
@@ -588,8 +589,8 @@ class HipRenderer:
     def render_async(self, cam: Camera, rp: RenderParams, backward: bool = False, adjoint: Optional[np.ndarray] = None,
                      f64: bool = False, unbiased: bool = False, img_out: Optional[np.ndarray] = None,
                      grads_out: Optional[np.ndarray] = None):
-        """drt_hip_render_async: enqueue one host-buffer frame -> a handle for wait().  At most two frames in flight.
-        img_out / grads_out: caller-owned arrays the results are written into (a render loop keeps two sets and spares
+        """drt_hip_render_async: enqueue one host-buffer frame -> a handle for wait().  At most FRAMES_IN_FLIGHT (4) frames
+        in flight.  img_out / grads_out: caller-owned arrays the results are written into (a render loop keeps a set per frame in flight and spares
         itself a 3 MB allocation and its page faults per frame)."""
         assert self.scene is not None
         flags = rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC | RENDER_TIMING)

@@ -94,10 +94,10 @@ struct drt_hip_ctx {
     hipStream_t path_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_path[2] = {nullptr, nullptr};
     bool overlap_next = false;            // set around render_launch by the callers whose renders do not wait
-    bool slot_used[2] = {false, false};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
+    bool slot_used[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
     DevBuf fpart2, gpart2, counts2;       // k_path's partial sums of the odd frames
     DevBuf ray_a[2], ray_b[2], ray_id[2], hit, hit2, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
-        ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[2], film, gpart, grad[2], adjoint, out[2];   // [2]: one set per frame in flight (drt_hip_render_async), slot 0 otherwise
+        ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[DRT_HIP_FRAMES_IN_FLIGHT], film, gpart, grad[DRT_HIP_FRAMES_IN_FLIGHT], adjoint, out[DRT_HIP_FRAMES_IN_FLIGHT];   // one set per frame in flight (drt_hip_render_async; device frames that do not wait alternate between the first two), slot 0 otherwise
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
     std::vector<TimedLaunch> timed;
@@ -106,14 +106,15 @@ struct drt_hip_ctx {
     // pinned staging of everything a host-buffer render returns: [segments 8 B | grads | image | gradient
     // image] arrive by DMA in one go, then plain memcpys into the caller's (pageable) buffers -- a
     // pageable hipMemcpy of the 3 MB image alone cost 1 ms
-    uint8_t* h_stage[2] = {nullptr, nullptr};
-    size_t h_stage_cap[2] = {0, 0};
+    uint8_t* h_stage[DRT_HIP_FRAMES_IN_FLIGHT] = {};
+    size_t h_stage_cap[DRT_HIP_FRAMES_IN_FLIGHT] = {};
     // asynchronous host-buffer renders (drt_hip_render_async / drt_hip_wait): up to two frames in flight; frame t uses set
     // t & 1, its results travel to the pinned block on copy_stream while the next frame's kernels run on `stream`
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_rendered[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
-    RenderJob pending[2];
-    bool in_flight[2] = {false, false};
+    hipEvent_t ev_rendered[DRT_HIP_FRAMES_IN_FLIGHT] = {}, ev_copied[DRT_HIP_FRAMES_IN_FLIGHT] = {};
+    RenderJob pending[DRT_HIP_FRAMES_IN_FLIGHT];
+    bool in_flight[DRT_HIP_FRAMES_IN_FLIGHT] = {};
+    hipEvent_t overlap_wait = nullptr;    // what the frame's k_path waits for before it writes its set of partial-sum buffers
     uint64_t next_ticket = 1;
     bool zero_copy_next = false;          // set around the render_launch of an asynchronous host-buffer render
     uint64_t dev_frames = 0;              // renders made with DRT_RENDER_ALLREDUCE_ASYNC (their gradient set alternates)
@@ -604,9 +605,9 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     memset(&cs, 0, sizeof cs);
     size_t cw = (size_t)(D + 1) * max_regions;   // counts[depth][region] of one batch
     const bool overlap_ok = ctx->overlap_next && use_path && !timing && gimg_param < 0 && ctx->path_stream[0] && ctx->ev_copied[0];
-    DevBuf& fpart_buf = overlap_ok && ctx->slot ? ctx->fpart2 : ctx->fpart;
-    DevBuf& gpart_buf = overlap_ok && ctx->slot ? ctx->gpart2 : ctx->gpart;
-    DevBuf& counts_buf = overlap_ok && ctx->slot ? ctx->counts2 : ctx->counts;
+    DevBuf& fpart_buf = overlap_ok && (ctx->slot & 1) ? ctx->fpart2 : ctx->fpart;
+    DevBuf& gpart_buf = overlap_ok && (ctx->slot & 1) ? ctx->gpart2 : ctx->gpart;
+    DevBuf& counts_buf = overlap_ok && (ctx->slot & 1) ? ctx->counts2 : ctx->counts;
     if (use_path) {
         cw = 2 * path_waves;                     // [segments | capped paths] per wave
         if ((rc = ensure(ctx, fpart_buf, (size_t)path_ranges * 3 * Pb * sizeof(double))) != DRT_OK) return rc;
@@ -797,14 +798,15 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 //  image, which the caller may have produced in that stream's order: then the frame keeps its place in it.)
                 hipStream_t ks = ctx->stream;
                 const bool overlap = overlap_ok && path_finish;
+                const int lane2 = ctx->slot & 1;                // which of the two k_path streams / sets of partial sums
                 if (overlap) {
-                    ks = ctx->path_stream[ctx->slot];
+                    ks = ctx->path_stream[lane2];
                     if (d_adjoint) {
-                        HIPCHK(ctx, hipEventRecord(ctx->ev_begin[ctx->slot], ctx->stream));
-                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_begin[ctx->slot], 0));
+                        HIPCHK(ctx, hipEventRecord(ctx->ev_begin[lane2], ctx->stream));
+                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_begin[lane2], 0));
                     }
-                    if (ctx->slot_used[ctx->slot])
-                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_copied[ctx->slot], 0));
+                    if (ctx->overlap_wait)
+                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->overlap_wait, 0));
                 }
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
@@ -851,8 +853,8 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #undef DRT_LAUNCH_PATH
                 if ((rc = timing_end(ctx, timing)) != DRT_OK) return rc;
                 if (overlap) {
-                    HIPCHK(ctx, hipEventRecord(ctx->ev_path[ctx->slot], ks));
-                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_path[ctx->slot], 0));
+                    HIPCHK(ctx, hipEventRecord(ctx->ev_path[lane2], ks));
+                    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_path[lane2], 0));
                 }
                 st->launches[DRT_K_PATH]++;
                 st->path_bytes += (film ? (uint64_t)pa.n_ranges * a.Pb * 3 * sizeof(double) : 0) +
@@ -1322,10 +1324,14 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)hipEventDestroy(ctx->ev_done);
     DevBuf* bufs[] = {&ctx->fpart2, &ctx->gpart2, &ctx->counts2, &ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->hit2, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
-                      &ctx->ch_w, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->segtotal[0], &ctx->segtotal[1], &ctx->film, &ctx->gpart, &ctx->grad[0], &ctx->grad[1],
-                      &ctx->adjoint, &ctx->out[0], &ctx->out[1]};
+                      &ctx->ch_w, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->film, &ctx->gpart, &ctx->adjoint};
     for (DevBuf* b : bufs)
         release(*b);
+    for (int i = 0; i < DRT_HIP_FRAMES_IN_FLIGHT; ++i) {
+        release(ctx->segtotal[i]);
+        release(ctx->grad[i]);
+        release(ctx->out[i]);
+    }
     release_mesh(ctx);
     if (ctx->d_scene_f) (void)hipFree(ctx->d_scene_f);
     if (ctx->d_scene_d) (void)hipFree(ctx->d_scene_d);
@@ -1333,7 +1339,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     if (ctx->d_params_d) (void)hipFree(ctx->d_params_d);
     if (ctx->h_probe)
         (void)hipHostFree(ctx->h_probe);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < DRT_HIP_FRAMES_IN_FLIGHT; ++i) {
         if (ctx->h_stage[i])
             (void)hipHostFree(ctx->h_stage[i]);
         if (ctx->ev_rendered[i]) (void)hipEventDestroy(ctx->ev_rendered[i]);
@@ -1711,9 +1717,11 @@ static int ensure_copy_stream(drt_hip_ctx* ctx)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < DRT_HIP_FRAMES_IN_FLIGHT; ++i) {
         if (!ctx->ev_rendered[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rendered[i], hipEventDisableTiming));
         if (!ctx->ev_copied[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; ++i) {
         if (!ctx->ev_begin[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_begin[i], hipEventDisableTiming));
         if (!ctx->ev_path[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_path[i], hipEventDisableTiming));
     }
@@ -2039,8 +2047,9 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         return DRT_ERR_INVALID;
     if (!ctx->members.empty())
         return render_group(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
-    if (ctx->in_flight[0] || ctx->in_flight[1])
-        return fail(ctx, DRT_ERR_INVALID, "render: asynchronous frames are in flight -- drt_hip_wait for them first");
+    for (int i = 0; i < DRT_HIP_FRAMES_IN_FLIGHT; ++i)
+        if (ctx->in_flight[i])
+            return fail(ctx, DRT_ERR_INVALID, "render: asynchronous frames are in flight -- drt_hip_wait for them first");
     int rc;
     // DRT_RENDER_ALLREDUCE_ASYNC (device buffers, a communicator): the all-reduce and the copy of the reduced gradient run on
     // the context's second stream while the NEXT render's kernels run on the first; the two gradient sets alternate, and a
@@ -2059,8 +2068,10 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[ctx->slot], 0));
     }
     ctx->overlap_next = ar_async || dev_async;
+    ctx->overlap_wait = (ar_async || dev_async) && ctx->slot_used[ctx->slot] ? ctx->ev_copied[ctx->slot] : nullptr;
     rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
     ctx->overlap_next = false;
+    ctx->overlap_wait = nullptr;
     if (rc != DRT_OK) {
         abort_comm_after_failure(ctx, rp);
         ctx->slot = 0;
@@ -2134,9 +2145,9 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     if (rp && (rp->flags & (DRT_RENDER_DEVICE_OUT | DRT_RENDER_TIMING)))
         return fail(ctx, DRT_ERR_INVALID, "render_async: host buffers only, no per-kernel timing (use drt_hip_render)");
     const uint64_t t = ctx->next_ticket;
-    const int slot = (int)(t & 1);
+    const int slot = (int)(t % DRT_HIP_FRAMES_IN_FLIGHT);
     if (ctx->in_flight[slot])
-        return fail(ctx, DRT_ERR_INVALID, "render_async: two frames are in flight already -- drt_hip_wait for the older one first");
+        return fail(ctx, DRT_ERR_INVALID, "render_async: four frames are in flight already -- drt_hip_wait for the oldest one first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
         const int rc0 = ensure_copy_stream(ctx);
@@ -2154,8 +2165,17 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     // (DRT_HIP_ASYNC_COPY=inline, still there): 0.89-0.92 ms -- the 3 MB cross the link inside the frame's critical path.)
     static const bool two_streams = !(getenv("DRT_HIP_ASYNC_COPY") && !strcmp(getenv("DRT_HIP_ASYNC_COPY"), "inline"));
     ctx->zero_copy_next = !two_streams;
+    // (the k_path grids of consecutive frames overlap -- render_impl: path_stream --: frame t shares its stream and its set of
+    //  partial sums with frame t - 2, whose finishing launch, on the context's stream, must have read them)
+    ctx->overlap_next = two_streams;
+    {
+        const int before = (int)((t + DRT_HIP_FRAMES_IN_FLIGHT - 2) % DRT_HIP_FRAMES_IN_FLIGHT);
+        ctx->overlap_wait = two_streams && t > 2 && ctx->slot_used[before] ? ctx->ev_rendered[before] : nullptr;
+    }
     int rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, &sink, -1, nullptr);
     ctx->zero_copy_next = false;
+    ctx->overlap_next = false;
+    ctx->overlap_wait = nullptr;
     if (rc != DRT_OK)
         abort_comm_after_failure(ctx, rp);
     if (rc == DRT_OK) rc = render_reduce(ctx);
@@ -2178,6 +2198,7 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         ctx->slot = 0;
         return rc;
     }
+    ctx->slot_used[slot] = true;
     ctx->pending[slot] = ctx->job;
     ctx->in_flight[slot] = true;
     ctx->next_ticket = t + 1;
@@ -2190,8 +2211,8 @@ int drt_hip_wait(drt_hip_ctx* ctx, uint64_t ticket, drt_hip_stats* stats)
 {
     if (!ctx)
         return DRT_ERR_INVALID;
-    const int slot = (int)(ticket & 1);
-    if (ticket == 0 || ticket >= ctx->next_ticket || !ctx->in_flight[slot] || ticket + 2 < ctx->next_ticket)
+    const int slot = (int)(ticket % DRT_HIP_FRAMES_IN_FLIGHT);
+    if (ticket == 0 || ticket >= ctx->next_ticket || !ctx->in_flight[slot] || ticket + DRT_HIP_FRAMES_IN_FLIGHT < ctx->next_ticket)
         return fail(ctx, DRT_ERR_INVALID, "wait: no such frame in flight");
     ctx->slot = slot;
     ctx->job = ctx->pending[slot];

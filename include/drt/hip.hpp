@@ -278,9 +278,9 @@ private:
     uint64_t m_scene_key = 0;
     std::vector<double> m_params;      // the parameter values the device holds
 public:
-    // host buffers of the (at most two) frames in flight: kept, so that a frame costs no 3 MB allocation
-    std::vector<float> frame_pool[2];
-    std::vector<double> grad_pool[2];
+    // host buffers of the (at most DRT_HIP_FRAMES_IN_FLIGHT) frames in flight: kept, so that a frame costs no 3 MB allocation
+    std::vector<float> frame_pool[DRT_HIP_FRAMES_IN_FLIGHT];
+    std::vector<double> grad_pool[DRT_HIP_FRAMES_IN_FLIGHT];
     unsigned submitted = 0;
 private:
     bool m_has_scene = false;
@@ -398,7 +398,7 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
 // that renders frame after frame (several views or mini-batches per optimisation step, a turntable) submits the next
 // frame before it collects the previous one:
 //     auto a = drt::hip::submit(scene, cam, tracer, spp, img_a, opt);
-//     auto b = drt::hip::submit(scene, cam, tracer, spp, img_b, opt);   // at most two in flight per device context
+//     auto b = drt::hip::submit(scene, cam, tracer, spp, img_b, opt);   // at most four in flight per device context
 //     a.get();  b.get();             // img_* filled, gradients ADDED into param.grad() (vector.hpp:185-188) at get()
 // (drt_hip_render_async / drt_hip_wait: frame i's results travel to a pinned block while frame i + 1's kernels run.)
 // One device (opt.devices[0]); the frames of one context belong to one thread; the scene's geometry must not change
@@ -457,7 +457,7 @@ private:
     uint64_t m_ticket = 0;
     Vector<T, 3>* m_img = nullptr;
     bool m_backward = false;
-    float* m_frame = nullptr;                   // written by drt_hip_wait: buffers of the context's pool (two frames in flight)
+    float* m_frame = nullptr;                   // written by drt_hip_wait: buffers of the context's pool (a set per frame in flight)
     double* m_grads = nullptr;
     std::size_t m_npix = 0;
     std::vector<uint8_t> m_requires_grad;
@@ -486,7 +486,7 @@ inline Pending<T> submit(const Scene<T>& scene, const Camera<T>& cam, const Path
     f.m_requires_grad = flat.requires_grad;
     f.m_handles = flat.handles;
     Context& ctx = pooled_context(opt.devices);
-    const unsigned slot = ctx.submitted & 1u;   // (the library refuses a third frame in flight: its buffers are free again)
+    const unsigned slot = ctx.submitted % DRT_HIP_FRAMES_IN_FLIGHT;   // (the library refuses a fifth frame in flight: its buffers are free again)
     if (ctx.frame_pool[slot].size() < npix * 3) ctx.frame_pool[slot].resize(npix * 3);
     if (ctx.grad_pool[slot].size() < flat.requires_grad.size() * 3) ctx.grad_pool[slot].resize(flat.requires_grad.size() * 3);
     f.m_frame = ctx.frame_pool[slot].data();

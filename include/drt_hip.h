@@ -245,13 +245,16 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad,
                    drt_hip_stats* stats);
+#define DRT_HIP_FRAMES_IN_FLIGHT 4
+
 /* The same call WITHOUT the wait at its end, for callers that render frame after frame (the loop of src/render.cpp:72-90
  * inside an optimisation loop): drt_hip_render_async enqueues the frame and returns a ticket; the results travel to a
  * pinned block of the context on a second stream while the NEXT frame's kernels run, and drt_hip_wait(ticket) hands them
  * to out_rgb / out_param_grad (plain memcpy) and fills `stats` (totals only; no per-kernel times).  Buffer lifetime: out_rgb,
  * out_param_grad must stay valid until drt_hip_wait returns -- they are written THERE, by the calling thread; adjoint_rgb is
- * consumed before drt_hip_render_async returns.  At most TWO frames are in flight (a third drt_hip_render_async before the
- * oldest was waited for returns DRT_ERR_INVALID), tickets are waited for in order of issue, and drt_hip_render /
+ * consumed before drt_hip_render_async returns.  At most DRT_HIP_FRAMES_IN_FLIGHT (four) frames are in flight (one more
+ * drt_hip_render_async before the oldest was waited for returns DRT_ERR_INVALID; with three or four in flight the path
+ * kernels of consecutive frames overlap), tickets are waited for in order of issue, and drt_hip_render /
  * drt_hip_render_gradient_image refuse to run while frames are in flight.  Host buffers only; a plain (non-group) context.
  * Results are bit-identical to drt_hip_render's. */
 int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,

@@ -3,6 +3,7 @@
 // frame through the MI355X wavefront pipeline.  Scene, camera and flags are the reference's
 // (render.cpp:26-69).  --backend cpu keeps the per-ray loop on the host API for comparison.
 #include <chrono>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 
@@ -90,32 +91,36 @@ int main(int argc, const char* argv[])
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count());
         }
         if (args.repeat > 2 && args.devices.size() == 1) {
-            // the same frames with two in flight (drt::hip::submit / Pending::get): frame i's copy to the host overlaps
-            // frame i + 1's kernels.  (The first two frames set up the second set of buffers: timed from the third on.)
-            std::vector<Vector<double, 3>> img2(width * height, Vector<double, 3>(0.));
+            // the same frames with up to four in flight (drt::hip::submit / Pending::get): a frame's copy to the host overlaps
+            // the next frames' kernels, and the path kernels of consecutive frames overlap.  (The first frames set up the
+            // sets of buffers: timed from the fifth on.)
+            const int slots = DRT_HIP_FRAMES_IN_FLIGHT;
+            std::vector<std::vector<Vector<double, 3>>> imgs((std::size_t)slots, std::vector<Vector<double, 3>>(width * height, Vector<double, 3>(0.)));
             auto zero_grads = [&]() {
                 for (Vector<T, 3, true>* p : {&red, &green, &white, &emission})
                     p->grad() = Vector<T, 3>(0.);
             };
-            const int n_pipe = args.repeat + 2;
+            const int n_pipe = args.repeat + slots;
             auto tp = std::chrono::steady_clock::now();
-            hip::Pending<T> prev;
+            std::deque<hip::Pending<T>> flying;
             for (int it = 0; it < n_pipe; ++it) {
-                if (it == 2)
+                if (it == slots)
                     tp = std::chrono::steady_clock::now();
-                hip::Pending<T> cur = hip::submit(scene, cam, tracer, args.samples, (it & 1) ? img2.data() : img.data(), opt);
-                if (prev.valid()) {
+                flying.push_back(hip::submit(scene, cam, tracer, args.samples, imgs[(std::size_t)(it % slots)].data(), opt));
+                if ((int)flying.size() >= slots) {
                     zero_grads();
-                    prev.get();
+                    flying.front().get();
+                    flying.pop_front();
                 }
-                prev = std::move(cur);
             }
-            zero_grads();
-            prev.get();
+            while (!flying.empty()) {
+                zero_grads();
+                flying.front().get();
+                flying.pop_front();
+            }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count() / args.repeat;
-            if ((n_pipe - 1) & 1)
-                img = img2;                    // (the last frame went to img2)
-            std::printf("pipelined (two frames in flight): %.3f ms per frame\n", ms);
+            img = imgs[(std::size_t)((n_pipe - 1) % slots)];
+            std::printf("pipelined (up to %d frames in flight): %.3f ms per frame\n", slots - 1, ms);
         }
     } else {
         // the reference's loop on the host API, drawing the same per-path RNG streams

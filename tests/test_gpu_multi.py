@@ -175,32 +175,37 @@ def test_bench_single_rank_under_torchrun_uses_the_library_collective():
 
 
 def test_async_host_renders_match_the_synchronous_call_bit_for_bit(pkg, hip):
-    """drt_hip_render_async / drt_hip_wait: two frames in flight, the copies of frame i overlap frame i + 1's kernels;
+    """drt_hip_render_async / drt_hip_wait: up to four frames in flight, the copies of frame i overlap the next frames' kernels;
     images, gradients and segment counts equal drt_hip_render's exactly; the documented refusals hold."""
     scene = pkg.cornell_box()
     cam = pkg.cornell_camera(96, 64)
     hip.upload_scene(scene)
-    rps = [pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=s) for s in (1, 2, 3, 4, 5)]
+    rps = [pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=s) for s in range(1, 12)]
     ref = [hip.render(cam, rp, backward=True) for rp in rps]
-    handles, got = [], []
-    for i, rp in enumerate(rps):
-        handles.append(hip.render_async(cam, rp, backward=True))
-        if len(handles) == 2:                              # frame i is enqueued, frame i - 1 is collected
+    for depth in (2, 3, pkg.FRAMES_IN_FLIGHT):             # frames kept in flight (from three on their path kernels overlap)
+        handles, got = [], []
+        for i, rp in enumerate(rps):
+            handles.append(hip.render_async(cam, rp, backward=True))
+            if len(handles) == depth:                      # frame i is enqueued, frame i - depth + 1 is collected
+                got.append(hip.wait(handles.pop(0)))
+        while handles:
             got.append(hip.wait(handles.pop(0)))
-    got.append(hip.wait(handles.pop(0)))
-    for (img, grads, st), (rimg, rgrads, rst) in zip(got, ref):
-        np.testing.assert_array_equal(img, rimg)
-        np.testing.assert_array_equal(grads, rgrads)
-        assert st["segments"] == rst["segments"] and st["paths"] == rst["paths"]
-    # a third frame while two are in flight, a synchronous render while frames are in flight, an unknown ticket: refused
+        for (img, grads, st), (rimg, rgrads, rst) in zip(got, ref):
+            np.testing.assert_array_equal(img, rimg)
+            np.testing.assert_array_equal(grads, rgrads)
+            assert st["segments"] == rst["segments"] and st["paths"] == rst["paths"]
+    # one frame more than FRAMES_IN_FLIGHT, a synchronous render while frames are in flight, an unknown ticket: refused
+    more = [hip.render_async(cam, rps[i], backward=True) for i in range(2, pkg.FRAMES_IN_FLIGHT)]
     h1 = hip.render_async(cam, rps[0], backward=True)
     h2 = hip.render_async(cam, rps[1], backward=True)
-    with pytest.raises(pkg.DrtHipError, match="two frames are in flight"):
+    with pytest.raises(pkg.DrtHipError, match="frames are in flight"):
         hip.render_async(cam, rps[2], backward=True)
     with pytest.raises(pkg.DrtHipError, match="in flight"):
         hip.render(cam, rps[2], backward=True)
     with pytest.raises(pkg.DrtHipError, match="no such frame"):
         hip.wait((h2[0] + 5, h2[1], h2[2]))
+    for hm in more:
+        hip.wait(hm)
     a = hip.wait(h1)
     b = hip.wait(h2)
     np.testing.assert_array_equal(a[0], ref[0][0])
