@@ -809,19 +809,19 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->overlap_wait, 0));
                 }
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
-#define DRT_LAUNCH_PATH(SPEC, NP, NC, SIG, NSIG)                                                                          \
+#define DRT_LAUNCH_PATH(SPEC, NP, NC, SG)                                                                                 \
     do {                                                                                                                 \
         if (path_regen)                                                                                                  \
-            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,          \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,                 \
                                pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SIG, NSIG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,         \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,                \
                                pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
     } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
     do {                                                                                   \
-        if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, NC, DRT_SIG_CORNELL, DRT_NSIG_CORNELL); \
-        else DRT_LAUNCH_PATH(SPEC, NP, NC, 0ull, 0);                                       \
+        if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, NC, SigCornell);                        \
+        else DRT_LAUNCH_PATH(SPEC, NP, NC, SigNone);                                       \
     } while (0)
                 // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
                 const bool three = ctx->max_colour_param < 3;
@@ -830,10 +830,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
 #define DRT_LAUNCH_UNB(SPEC, NP)                                                                                              \
     do {                                                                                                                      \
         if (cornell_sig)                                                                                                      \
-            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, DRT_SIG_CORNELL, DRT_NSIG_CORNELL>), dim3(gpath), dim3(DRT_BLOCK), 0, \
+            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, SigCornell>), dim3(gpath), dim3(DRT_BLOCK), 0,                    \
                                ks, pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                            \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, 0ull, 0>), dim3(gpath), dim3(DRT_BLOCK), 0, ks, pa,               \
+            hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, SigNone>), dim3(gpath), dim3(DRT_BLOCK), 0, ks, pa,               \
                                d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                                    \
     } while (0)
                     if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }

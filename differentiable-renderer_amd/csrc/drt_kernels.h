@@ -1140,7 +1140,7 @@ __device__ inline uint32_t next_region(const BatchArgs& a, const uint32_t* __res
 // the literal loop in the f64 verification mode
 __device__ inline HitRec<float> tail_closest_hit(const DevScene<float>* __restrict__ sc, const ProgRecs<0>& recs, float4 ra, float2 rb)
 {
-    return closest_hit_prog<0ull, 0>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
+    return closest_hit_prog<SigNone>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
 }
 __device__ inline HitRec<double> tail_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<0>&, double4 ra, double2 rb)
 {

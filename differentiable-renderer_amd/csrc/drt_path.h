@@ -31,7 +31,7 @@
 //     sphere          half-b form of shape.hpp:78-103 (b = 2 b', disc = 4 disc': exact power-of-two scalings)
 // The shape loop is fully unrolled over DRT_PROG_MAX records whose kinds are either read from the scene (uniform
 // branches on a scalar mask, records by scalar loads the compiler hoists out of the bounce loop) or, for the
-// topology of the reference's own scene, fixed at compile time (template SIG: no branches at all).
+// topology of the reference's own scene, fixed at compile time (template SG: no branches at all).
 #pragma once
 
 #include "drt_kernels.h"
@@ -64,16 +64,16 @@ __device__ inline uint32_t path_global_pixel(const PathArgs& a, uint32_t lp)
     return y * (uint32_t)a.W + x;
 }
 
-template <unsigned long long SIG, int NSIG>
-__device__ inline HitRec<float> path_closest_hit(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs, float4 ra, float2 rb)
+template <typename SG>
+__device__ inline HitRec<float> path_closest_hit(const DevScene<float>* __restrict__ sc, const ProgRecs<SG::n>& recs, float4 ra, float2 rb)
 {
-    return closest_hit_prog<SIG, NSIG>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
+    return closest_hit_prog<SG>(sc, recs, mk<float>(ra.x, ra.y, ra.z), mk<float>(ra.w, rb.x, rb.y));
 }
-template <unsigned long long SIG, int NSIG>
-__device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<NSIG, double>& recs, double4 ra, double2 rb)
+template <typename SG>
+__device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __restrict__ sc, const ProgRecs<SG::n, double>& recs, double4 ra, double2 rb)
 {
-    if (NSIG > 0)                                                  // the reference's own scene: the compiled-in program in f64
-        return closest_hit_sig<SIG, NSIG, double>(recs, mk<double>(ra.x, ra.y, ra.z), mk<double>(ra.w, rb.x, rb.y));
+    if (SG::n > 0)                                                 // a compiled-in program in f64
+        return closest_hit_sig<SG, double>(recs, mk<double>(ra.x, ra.y, ra.z), mk<double>(ra.w, rb.x, rb.y));
     const double4 ra1[1] = {ra};
     const double2 rb1[1] = {rb};
     HitRec<double> h1[1];
@@ -87,34 +87,100 @@ __device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __rest
      (unsigned long long)DRT_PK_PLANE << 9 | (unsigned long long)DRT_PK_AZ << 12 | (unsigned long long)DRT_PK_AZ << 15 |  \
      (unsigned long long)DRT_PK_AY << 18 | (unsigned long long)DRT_PK_AY << 21 | (unsigned long long)DRT_PK_SPHERE << 24)
 #define DRT_NSIG_CORNELL 9
+typedef KindSig<DRT_SIG_CORNELL, 0ull, 0ull, 0ull, DRT_NSIG_CORNELL> SigCornell;
 
 // per-lane gradient state: NP parameters (0 = none), of which only the first NC can be a BxDF's colour (the others are
-// emission-only parameters: their tangent is identically 0 and is not carried -- the reference's scene has three
-// albedos and one emission, render.cpp:26-29)
-template <typename R, int NP, int NC>
-struct Tangents {
-    V3<R> dT[NC > 0 ? NC : 1];      // dT/dc_p of the current path
-    V3<R> acc[NP > 0 ? NP : 1];     // gradient sums of this lane
+// emission-only parameters: the reference's scene has three albedos and one emission, render.cpp:26-29).
+//
+// The throughput is a PRODUCT, T = prod_j colour_{p_j} m_j, so its tangent with respect to a colour parameter needs no
+// per-vertex update at all (rounds 2-3 carried dT/dc_p per parameter and moved it with 9 fma + 9 selects per bounce):
+//     dT_ch / dc_{p,ch} = T_ch n_p / c_{p,ch} ,      n_p = how many vertices of the path scattered on colour p
+// -- one 8-bit counter per parameter (a path has at most DRT_MAX_DEPTH = 64 vertices), one packed add per bounce.  A colour
+// channel that is ZERO (the reference's red = (0.5, 0, 0), render.cpp:26) has no quotient: the lane's T therefore leaves the
+// zero factors out (they are replaced by 1: `colnz`) and counts them per channel instead (`zc`, 8 bits each):
+//     T_real,ch       = zc_ch == 0 ? T_ch : 0
+//     dT_ch/dc_{p,ch} = c_{p,ch} != 0 ? T_real,ch n_p / c_{p,ch}
+//                                     : (n_p == 1 and zc_ch == 1 ? T_ch : 0)     (d/dc of c^n at 0: 1 for n = 1, else 0)
+// Evaluated where a path meets a light: once per sample.  Same sums as the reference's backward functors
+// (vector.hpp:418-484) in closed form; the image is unchanged bit for bit (a channel without zero factors sees the very
+// same multiplications), gradients to f32 rounding.  |c| < 1e-18 counts as zero (its quotient would overflow).
+template <typename R>
+struct TangentLds {              // per colour parameter, wave-uniform except where indexed by the lane's colour id
+    R colnz[DRT_FAST_PARAMS][4];         // the colour with zero channels replaced by 1
+    R invc[DRT_FAST_PARAMS][4];          // 1 / c per channel, 0 where the channel is zero
+    uint32_t inc[DRT_FAST_PARAMS][4];    // counter increments of a bounce on this colour: n_p (low, high word), zc; [3] = zero-channel bits
 };
 
-// an emissive vertex reached with prefix throughput T (and tangents dT): radiance and gradients
+template <typename R>
+__device__ inline void stage_tangents(TangentLds<R>& tl, const SceneLds<R>& lds)
+{
+    // (after stage_scene's barrier; parameters beyond the scene's own read as (1, 1, 1))
+    if (threadIdx.x < DRT_FAST_PARAMS) {
+        const int p = threadIdx.x;
+        const bool in = p < lds.sc.n_params;
+        uint32_t zinc = 0, zbits = 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const R c = in ? lds.params[p * 3 + ch] : R(1);
+            const bool zero = abs_r(c) < R(1e-18);
+            tl.colnz[p][ch] = zero ? R(1) : c;
+            tl.invc[p][ch] = zero ? R(0) : R(1) / c;
+            zinc |= zero ? 1u << (8 * ch) : 0u;
+            zbits |= zero ? 1u << ch : 0u;
+        }
+        tl.colnz[p][3] = R(0);
+        tl.invc[p][3] = R(0);
+        tl.inc[p][0] = p < 4 ? 1u << (8 * p) : 0u;
+        tl.inc[p][1] = p >= 4 ? 1u << (8 * (p - 4)) : 0u;
+        tl.inc[p][2] = zinc;
+        tl.inc[p][3] = zbits;
+    }
+    __syncthreads();
+}
+
+template <typename R, int NP, int NC>
+struct Tangents {
+    uint32_t cnt[NC > 4 ? 2 : 1];   // n_p of the current path, 8 bits per colour parameter
+    uint32_t zc;                    // zero factors met per channel, 8 bits each
+    V3<R> acc[NP > 0 ? NP : 1];     // gradient sums of this lane
+    __device__ inline void new_path() { cnt[0] = 0; if (NC > 4) cnt[NC > 4 ? 1 : 0] = 0; zc = 0; }
+};
+
+// an emissive vertex reached with prefix throughput T: radiance and gradients
 //   L     += T E / p_k                                   (pathtracer.hpp:113-114, 133)
 //   d/dc_p += g dT_p E / p_k      d/dE += g T / p_k       (vector.hpp:418-484 in closed form)
 template <typename R, int NP, int NC>
-__device__ inline void add_emission(const SceneLds<R>& lds, const R* __restrict__ params, uint32_t eid, R inv_pk, V3<R> T,
-                                    V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
+__device__ inline void add_emission(const SceneLds<R>& lds, const TangentLds<R>& tl, const R* __restrict__ params, uint32_t eid, R inv_pk,
+                                    V3<R> T, V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
 {
     const V3<R> E = load_param<R, (NP > 0)>(lds, params, (int)eid) * inv_pk;
-    L = L + T * E;
+    V3<R> Tr = T;
+    if (NC > 0)                     // a channel that met a zero colour is dark
+        Tr = mk<R>((tg.zc & 0xFFu) ? R(0) : T.x, (tg.zc & 0xFF00u) ? R(0) : T.y, (tg.zc & 0xFF0000u) ? R(0) : T.z);
+    L = L + Tr * E;
     if (NP > 0) {
-        const V3<R> gE = g * E, gT = g * T * inv_pk;
+        if (NC > 0)
+            asm volatile("" ::: "memory");    // (keeps the reads of `tl` below where they are: see there)
+        const V3<R> gE = g * E, gT = g * Tr * inv_pk;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const bool own = eid == (uint32_t)p;
             const V3<R> a0 = mk<R>(tg.acc[p].x + (own ? gT.x : R(0)), tg.acc[p].y + (own ? gT.y : R(0)), tg.acc[p].z + (own ? gT.z : R(0)));
-            if (p < NC)
-                tg.acc[p] = mk<R>(fma_r(tg.dT[p].x, gE.x, a0.x), fma_r(tg.dT[p].y, gE.y, a0.y), fma_r(tg.dT[p].z, gE.z, a0.z));
-            else
+            if (p < NC) {
+                const uint32_t n = (tg.cnt[p >> 2] >> (8 * (p & 3))) & 0xFFu;
+                const R nf = (R)(int)n;
+                // (read where they are used, once per sample: hoisted out of the sample loop these twelve wave-uniform words
+                //  cost the kernel its fifth wave per SIMD)
+                V3<R> dT = mk<R>(Tr.x * (nf * tl.invc[p][0]), Tr.y * (nf * tl.invc[p][1]), Tr.z * (nf * tl.invc[p][2]));
+                const uint32_t zb = __builtin_amdgcn_readfirstlane(tl.inc[p][3]);
+                if (zb) {
+                    const bool one = n == 1u;
+                    if (zb & 1u) dT.x = (one && (tg.zc & 0xFFu) == 0x1u) ? T.x : R(0);
+                    if (zb & 2u) dT.y = (one && (tg.zc & 0xFF00u) == 0x100u) ? T.y : R(0);
+                    if (zb & 4u) dT.z = (one && (tg.zc & 0xFF0000u) == 0x10000u) ? T.z : R(0);
+                }
+                tg.acc[p] = mk<R>(fma_r(dT.x, gE.x, a0.x), fma_r(dT.y, gE.y, a0.y), fma_r(dT.z, gE.z, a0.z));
+            } else
                 tg.acc[p] = a0;
         }
     }
@@ -140,14 +206,14 @@ struct PathVertex {
     bool hit, scattered;       // the ray hit something / something with a BxDF
 };
 
-template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG>
-__device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
-                                   const R* __restrict__ params, const ProgRecs<NSIG, R>& recs, uint32_t key,
+template <typename R, bool SPEC, int NP, int NC, typename SG>
+__device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, const TangentLds<R>& tl, const DevScene<R>* __restrict__ sc,
+                                   const R* __restrict__ params, const ProgRecs<SG::n, R>& recs, uint32_t key,
                                    R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
                                    typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
                                    bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr)
 {
-    const HitRec<R> h = path_closest_hit<SIG, NSIG>(sc, recs, ra, rb);
+    const HitRec<R> h = path_closest_hit<SG>(sc, recs, ra, rb);
     const bool hit = live && h.prim >= 0;
     const int prim = h.prim >= 0 ? h.prim : 0;                        // (a miss reads record 0, uses nothing of it)
     const V3<R> o = mk<R>(ra.x, ra.y, ra.z);
@@ -155,6 +221,8 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     const V3<R> P = o + d * h.t;                                      // pathtracer.hpp:83
     const DevShape<R>& sh = lds.sc.shapes[prim];
     const V3<R> ctr = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
+    // (f32: (P - c) / r with 1 / r from a table would save the rsq and the select -- and moves sphere normals by a few ulp,
+    //  which flips one grazing path of the 64 x 48 x 8 smoke frame: measured, not kept; the literal form stays)
     const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
     const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
     const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
@@ -173,7 +241,7 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     }
     if (wave_any(emits && has_bxdf)) {
         if (emits && has_bxdf)
-            add_emission<R, NP, NC>(lds, params, eid, inv_pk, T, g, L, tg);
+            add_emission<R, NP, NC>(lds, tl, params, eid, inv_pk, T, g, L, tg);
     }
     // the BxDF: sample, evaluate (pathtracer.hpp:91-111)
     const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
@@ -186,18 +254,17 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     const bool rr_kills = next_rr && rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold;
     alive = hit && has_bxdf && !next_cap && !rr_kills;
     capped = hit && has_bxdf && next_cap && !a.cap_is_roulette && !rr_kills;
-    // throughput and tangents move on only in lanes whose path goes on (the others stay frozen for the light's turn)
-    const V3<R> col = load_param<R, (NP > 0)>(lds, params, has_bxdf ? (int)cid : 0);
+    // the throughput moves on only in lanes whose path goes on (the others stay frozen for the light's turn); with
+    // gradients it leaves zero colour channels out and counts them, and counts the bounce for its colour (see Tangents)
+    const int cidx = has_bxdf ? (int)cid : 0;
+    const V3<R> col = NC > 0 ? mk<R>(tl.colnz[cidx][0], tl.colnz[cidx][1], tl.colnz[cidx][2]) : load_param<R, (NP > 0)>(lds, params, cidx);
     const V3<R> cmv = col * mk_;
     const V3<R> cm = mk<R>(alive ? cmv.x : R(1), alive ? cmv.y : R(1), alive ? cmv.z : R(1));
     if (NC > 0) {
-        const V3<R> Tm = T * mk_;
-#pragma unroll
-        for (int p = 0; p < NC; ++p) {
-            const bool mine = alive && cid == (uint32_t)p;
-            tg.dT[p] = mk<R>(fma_r(tg.dT[p].x, cm.x, mine ? Tm.x : R(0)), fma_r(tg.dT[p].y, cm.y, mine ? Tm.y : R(0)),
-                             fma_r(tg.dT[p].z, cm.z, mine ? Tm.z : R(0)));
-        }
+        tg.cnt[0] += alive ? tl.inc[cidx][0] : 0u;
+        if (NC > 4)
+            tg.cnt[NC > 4 ? 1 : 0] += alive ? tl.inc[cidx][1] : 0u;
+        tg.zc += alive ? tl.inc[cidx][2] : 0u;
     }
     T = T * cm;
     const V3<R> no = P + wo * R(1e-3);                                // pathtracer.hpp:99
@@ -250,7 +317,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // bookkeeping, the camera code runs whenever some lane starts over, the light's emission is added when the lane's
 // path ends.  ~35 % more instructions per bounce, but roulette-terminated renders (the reference's defaults, -b 1
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
-template <typename R, bool SPEC, int NP, int NC, unsigned long long SIG, int NSIG, bool REGEN = false>
+template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
@@ -262,7 +329,11 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     typedef typename Q2<R>::T R2;
     __shared__ SceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+    __shared__ TangentLds<R> s_tl;
     stage_scene(lds, sc, params);
+    const TangentLds<R>& tl = s_tl;
+    if (NC > 0)
+        stage_tangents(s_tl, lds);
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t w = grid_wave();                       // wave of the grid = group + n_groups * range
@@ -295,12 +366,12 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
-    ProgRecs<NSIG, R> recs;
+    ProgRecs<SG::n, R> recs;
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
-    if (NSIG > 0)
+    if (SG::n > 0)
         recs.load(sc);
-    if (sizeof(R) == 4 && NSIG == 0) {
+    if (sizeof(R) == 4 && SG::n == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {
             s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
@@ -321,11 +392,8 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
         uint32_t end_ids = DRT_ID_NONE;                   // emission parameter of the light the path ended on
         R end_inv_pk = R(1);
-        if (NC > 0) {
-#pragma unroll
-            for (int p = 0; p < NC; ++p)
-                tg.dT[p] = mk<R>(R(0), R(0), R(0));
-        }
+        if (NC > 0)
+            tg.new_path();
         for (int kk = 0; kk < a.depth_cap; ++kk) {
             const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
             if (n_live == 0)
@@ -338,7 +406,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const bool next_cap = (kk + 1) >= a.depth_cap;
             bool alive, capped, on_light;
             uint32_t light;
-            path_bounce<R, SPEC, NP, NC, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
+            path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
                                                     ra, rb, T, L, tg, alive, capped, on_light, light);
             // A light without a BxDF ends the path: T and dT stay as they are in this lane, so its emission is added
             // ONCE PER SAMPLE, after the bounce loop, for all lanes together -- not here, where every bounce a few lanes
@@ -351,7 +419,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         }
         if (wave_any(end_ids != DRT_ID_NONE)) {
             if (end_ids != DRT_ID_NONE)
-                add_emission<R, NP, NC>(lds, params, end_ids, end_inv_pk, T, g, L, tg);
+                add_emission<R, NP, NC>(lds, tl, params, end_ids, end_inv_pk, T, g, L, tg);
         }
         fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
     }
@@ -365,11 +433,8 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         ra.x = ra.y = ra.z = ra.w = R(0);
         rb.x = rb.y = R(0);
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
-        if (NC > 0) {
-#pragma unroll
-            for (int p = 0; p < NC; ++p)
-                tg.dT[p] = mk<R>(R(0), R(0), R(0));
-        }
+        if (NC > 0)
+            tg.new_path();
         const int first_rr = a.min_bounces > 1 ? a.min_bounces : 1;
         for (;;) {
             // ---- lanes without a path start their next sample -- once enough of them wait (the whole wave walks
@@ -384,11 +449,8 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
                     live = a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
                     T = mk<R>(R(1), R(1), R(1));
                     L = mk<R>(R(0), R(0), R(0));
-                    if (NC > 0) {
-#pragma unroll
-                        for (int p = 0; p < NC; ++p)
-                            tg.dT[p] = mk<R>(R(0), R(0), R(0));
-                    }
+                    if (NC > 0)
+                        tg.new_path();
                 }
             }
             const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
@@ -408,7 +470,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const bool next_cap = (kk + 1) >= a.depth_cap;
             bool alive, capped, on_light;
             uint32_t light;
-            path_bounce<R, SPEC, NP, NC, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
+            path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
                                                     ra, rb, T, L, tg, alive, capped, on_light, light);
             if (!a.cap_is_roulette)
                 n_capped += (uint32_t)__popcll(wave_ballot(capped));
@@ -417,7 +479,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             if (wave_any(ended)) {
                 if (ended) {
                     if (on_light)
-                        add_emission<R, NP, NC>(lds, params, light, inv_pk, T, g, L, tg);
+                        add_emission<R, NP, NC>(lds, tl, params, light, inv_pk, T, g, L, tg);
                     fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
                 }
             }
@@ -482,9 +544,9 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
 // then per vertex [roulette of its depth] theta phi -- including the roulette draw the reference spends AFTER a light
 // without BxDF (its zero-direction continuation is traced "faithfully" before it misses; oracle/ref_harness.cpp).
 // One walk = the bounce of k_path (path_bounce, forward-only) iterated while any lane of the wave still traces.
-template <typename R, bool SPEC, unsigned long long SIG, int NSIG>
-__device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, const DevScene<R>* __restrict__ sc,
-                                     const R* __restrict__ params, const ProgRecs<NSIG, R>& recs, uint32_t key,
+template <typename R, bool SPEC, typename SG>
+__device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, const TangentLds<R>& tl, const DevScene<R>* __restrict__ sc,
+                                     const R* __restrict__ params, const ProgRecs<SG::n, R>& recs, uint32_t key,
                                      R pk_rr, R inv_p_rr, bool live, typename Q4<R>::T ra, typename Q2<R>::T rb, int kk,
                                      uint32_t& nd, uint32_t& n_seg, uint32_t& n_capped, V3<R>& L, PathVertex<R>& first, bool& any_vertex)
 {
@@ -504,7 +566,7 @@ __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, 
         bool alive, capped, on_light;
         uint32_t light;
         PathVertex<R> v;
-        path_bounce<R, SPEC, 0, 0, SIG, NSIG>(a, lds, sc, params, recs, key, pk, inv_pk, nd, next_rr, next_cap, live, g1, ra, rb, T, L,
+        path_bounce<R, SPEC, 0, 0, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, nd, next_rr, next_cap, live, g1, ra, rb, T, L,
                                               none, alive, capped, on_light, light, &v);
         // the roulette of the next depth is drawn unless a user cap ends the path first (pathtracer.hpp:128 behind the cap test)
         const uint32_t rr_drawn = (next_rr && (!next_cap || a.cap_is_roulette)) ? 1u : 0u;
@@ -517,7 +579,7 @@ __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, 
         }
         if (wave_any(live && on_light)) {
             if (live && on_light)
-                add_emission<R, 0, 0>(lds, params, light, inv_pk, T, g1, L, none);
+                add_emission<R, 0, 0>(lds, tl, params, light, inv_pk, T, g1, L, none);
         }
         if (!a.cap_is_roulette)
             n_capped += (uint32_t)__popcll(wave_ballot(live && capped));
@@ -526,7 +588,7 @@ __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, 
     }
 }
 
-template <typename R, bool SPEC, int NP, unsigned long long SIG, int NSIG>
+template <typename R, bool SPEC, int NP, typename SG>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
                 double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
@@ -539,6 +601,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     __shared__ SceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
     stage_scene(lds, sc, params);
+    const TangentLds<R>& tl = *reinterpret_cast<const TangentLds<R>*>(&lds);   // (forward-only walks never touch it)
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t w = grid_wave();
@@ -567,12 +630,12 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
-    ProgRecs<NSIG, R> recs;
+    ProgRecs<SG::n, R> recs;
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
-    if (NSIG > 0)
+    if (SG::n > 0)
         recs.load(sc);
-    if (sizeof(R) == 4 && NSIG == 0) {
+    if (sizeof(R) == 4 && SG::n == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {
             s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
@@ -599,7 +662,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
             V3<R> L0;
             PathVertex<R> cur;
             bool in_chain;
-            unbiased_walk<R, SPEC, SIG, NSIG>(a, lds, sc, params, recs, key, pk_rr, inv_p_rr, live, ra, rb, 0, nd, n_seg, n_capped, L0,
+            unbiased_walk<R, SPEC, SG>(a, lds, tl, sc, params, recs, key, pk_rr, inv_p_rr, live, ra, rb, 0, nd, n_seg, n_capped, L0,
                                               cur, in_chain);
             fx += (double)L0.x; fy += (double)L0.y; fz += (double)L0.z;
             in_chain = in_chain && have;
@@ -648,7 +711,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
                 V3<R> Ls;
                 PathVertex<R> nxt;
                 bool any_vertex;
-                unbiased_walk<R, SPEC, SIG, NSIG>(a, lds, sc, params, recs, key, pk_rr, inv_p_rr, in_chain && go, sa, sb, cdepth + 1, nd,
+                unbiased_walk<R, SPEC, SG>(a, lds, tl, sc, params, recs, key, pk_rr, inv_p_rr, in_chain && go, sa, sb, cdepth + 1, nd,
                                                   n_seg, n_capped, Ls, nxt, any_vertex);
                 // ---- gradients of this vertex; the chain moves on to the suffix's first vertex
                 if (in_chain) {

@@ -88,10 +88,23 @@ __device__ inline void prog_resolve_tie(const float4 r, int s, V3<float> o, V3<f
         prim = s;
 }
 
-// The records of the program, as the bounce loop sees them.  SIG != 0 (kinds fixed at compile time, 3 bits per shape,
-// NSIG shapes): the NSIG records are loaded ONCE per wave, before the sample loop, and stay in scalar registers --
-// the loop body then contains no scalar load, no wait and no branch for the scene at all.  SIG == 0: kinds and
-// records are read from the scene inside the loop (uniform branches on the kind mask; scalar loads).
+// The kinds of a scene's shapes as a TYPE (3 bits per shape, 16 shapes per word, scene order): the template argument of
+// the compiled-in program.  n == 0: no signature -- the kind-sorted program in LDS.  The reference's own scene is
+// instantiated in the library (SigCornell); every other analytic scene gets its instantiation at run time (drt_jit.h:
+// hiprtc compiles k_path<..., KindSig<the scene's words>, ...> when the scene has rendered enough to pay for it).
+template <unsigned long long W0, unsigned long long W1, unsigned long long W2, unsigned long long W3, int N>
+struct KindSig {
+    static constexpr int n = N;
+    static __host__ __device__ constexpr int kind(int s)
+    {
+        return (int)(((s < 16 ? W0 : s < 32 ? W1 : s < 48 ? W2 : W3) >> (3 * (s & 15))) & 7ull);
+    }
+};
+typedef KindSig<0ull, 0ull, 0ull, 0ull, 0> SigNone;
+
+// The records of the program, as the bounce loop sees them.  SG::n > 0 (kinds fixed at compile time): the records are
+// loaded ONCE per wave, before the sample loop, and stay in scalar registers -- the loop body then contains no scalar
+// load, no wait and no branch for the scene at all.  SG::n == 0: the kind-sorted copy in LDS.
 struct ProgLds {               // the kind-sorted program in LDS (scenes whose kinds are not compiled in)
     float4 rec[DRT_PROG_SORTED_MAX];
     int shape[DRT_PROG_SORTED_MAX];
@@ -110,17 +123,16 @@ struct ProgRecs {
     }
 };
 
-// the compiled-in form, f32 or f64: NSIG records in scalar registers, kinds from SIG
-template <unsigned long long SIG, int NSIG, typename R>
-__device__ inline HitRec<R> closest_hit_sig(const ProgRecs<NSIG, R>& recs, V3<R> o, V3<R> d)
+// the compiled-in form, f32 or f64: SG::n records in scalar registers, kinds from SG
+template <typename SG, typename R>
+__device__ inline HitRec<R> closest_hit_sig(const ProgRecs<SG::n, R>& recs, V3<R> o, V3<R> d)
 {
     const V3<R> inv_d = mk<R>(prog_rcp(d.x), prog_rcp(d.y), prog_rcp(d.z));
     R tmin = (R)INFINITY;
     int prim = -1;
 #pragma unroll
-    for (int s = 0; s < NSIG; ++s) {
-        constexpr unsigned long long sig = SIG;
-        const int kind = (int)((sig >> (3 * s)) & 7ull);
+    for (int s = 0; s < SG::n; ++s) {
+        const int kind = SG::kind(s);
         const typename Q4<R>::T r = recs.r[s];
         if (kind == DRT_PK_AX) prog_test<DRT_PK_AX, R>(r, s, o, d, inv_d, tmin, prim);
         else if (kind == DRT_PK_AY) prog_test<DRT_PK_AY, R>(r, s, o, d, inv_d, tmin, prim);
@@ -134,13 +146,13 @@ __device__ inline HitRec<R> closest_hit_sig(const ProgRecs<NSIG, R>& recs, V3<R>
     return h;
 }
 
-template <unsigned long long SIG, int NSIG>
-__device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restrict__ sc, const ProgRecs<NSIG>& recs,
+template <typename SG>
+__device__ inline HitRec<float> closest_hit_prog(const DevScene<float>* __restrict__ sc, const ProgRecs<SG::n>& recs,
                                                  V3<float> o, V3<float> d)
 {
     (void)sc;
-    if (NSIG > 0)
-        return closest_hit_sig<SIG, NSIG, float>(recs, o, d);
+    if (SG::n > 0)
+        return closest_hit_sig<SG, float>(recs, o, d);
     const V3<float> inv_d = mk<float>(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     float tmin = INFINITY;
     int prim = -1;
