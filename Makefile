@@ -17,7 +17,8 @@ all: lib oracle host
 
 lib: $(LIB)
 $(LIB): $(PKG)/csrc/drt_hip.hip $(wildcard $(PKG)/csrc/*.h) include/drt_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude -o $@ $(PKG)/csrc/drt_hip.hip -lrccl
+	python3 $(PKG)/csrc/embed_sources.py
+	$(HIPCC) --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude -o $@ $(PKG)/csrc/drt_hip.hip -lrccl -lhiprtc
 
 oracle:
 	$(MAKE) -C oracle libdrt_oracle.so ref

@@ -15,6 +15,7 @@ import ctypes as C
 import math
 import os
 import subprocess
+import sys
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -39,7 +40,7 @@ FRAMES_IN_FLIGHT = 4          # drt_hip_render_async: DRT_HIP_FRAMES_IN_FLIGHT
 MAX_DEPTH = 64
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]
-ABI_VERSION = 5
+ABI_VERSION = 6
 UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3: "DRT_ERR_HIP",
@@ -88,18 +89,24 @@ class RenderParamsDesc(C.Structure):
                 ("bounces_per_launch", C.c_int32), ("reserved", C.c_int32)]
 
 
+PROGRAM_NAMES = {0: "none", 1: "sorted", 2: "builtin", 3: "specialised"}   # DRT_PROGRAM_*
+SPECIALISE_GENERIC, SPECIALISE_NEVER, SPECIALISE_AUTO, SPECIALISE_NOW = -1, 0, 1, 2               # drt_hip_set_specialisation
+
+
 class HipStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("batches", C.c_uint64),
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double * K_COUNT),
                 ("launches", C.c_uint64 * K_COUNT), ("units", C.c_uint64 * K_COUNT),
                 ("queue_rays_read", C.c_uint64), ("queue_rays_written", C.c_uint64),
-                ("capped_paths", C.c_uint64), ("bvh_bytes", C.c_uint64), ("path_bytes", C.c_uint64)]
+                ("capped_paths", C.c_uint64), ("bvh_bytes", C.c_uint64), ("path_bytes", C.c_uint64),
+                ("path_program", C.c_uint32), ("reserved", C.c_uint32), ("jit_ms", C.c_double)]
 
     def as_dict(self) -> dict:
         d = {"paths": int(self.paths), "segments": int(self.segments),
              "batches": int(self.batches), "ms_total": float(self.ms_total), "kernels": {},
              "queue_rays_read": int(self.queue_rays_read), "queue_rays_written": int(self.queue_rays_written),
-             "capped_paths": int(self.capped_paths), "bvh_bytes": int(self.bvh_bytes), "path_bytes": int(self.path_bytes)}
+             "capped_paths": int(self.capped_paths), "bvh_bytes": int(self.bvh_bytes), "path_bytes": int(self.path_bytes),
+             "path_program": PROGRAM_NAMES.get(int(self.path_program), str(int(self.path_program))), "jit_ms": float(self.jit_ms)}
         for k, name in enumerate(KERNEL_NAMES):
             d["kernels"][name] = {"ms": float(self.ms_kernel[k]), "launches": int(self.launches[k]),
                                   "units": int(self.units[k])}
@@ -433,7 +440,9 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + srcs + ["-lrccl"]
+           "-I" + os.path.join(REPO_ROOT, "include"), "-o", LIB_PATH] + srcs + ["-lrccl", "-lhiprtc"]
+    # the device headers as strings inside the library: hiprtc specialises k_path per scene at run time (csrc/drt_jit.h)
+    subprocess.run([sys.executable, os.path.join(PKG_DIR, "csrc", "embed_sources.py")], check=True)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -447,7 +456,7 @@ class DrtHipError(RuntimeError):
 _ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_create_group",
                 "drt_hip_group_size", "drt_hip_destroy",
                 "drt_hip_comm_unique_id", "drt_hip_comm_init_rank", "drt_hip_comm_size", "drt_hip_comm_destroy",
-                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_render", "drt_hip_render_async", "drt_hip_wait",
+                "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_set_specialisation", "drt_hip_render", "drt_hip_render_async", "drt_hip_wait",
                 "drt_hip_render_gradient_image", "drt_hip_stream",
                 "drt_hip_synchronize", "drt_hip_last_error", "drt_hip_kernel_name"]
 
@@ -474,6 +483,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.drt_hip_destroy.restype = None
     lib.drt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
     lib.drt_hip_update_params.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.drt_hip_set_specialisation.argtypes = [C.c_void_p, C.c_int]
     lib.drt_hip_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
     lib.drt_hip_render_async.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
@@ -547,6 +557,10 @@ class HipRenderer:
         desc, keep = scene.to_desc()
         self._check(self.lib.drt_hip_upload_scene(self.ctx, C.byref(desc)), "drt_hip_upload_scene")
         self.scene = scene
+
+    def set_specialisation(self, mode: int):
+        """When the scene gets a path kernel compiled for its own shape kinds: SPECIALISE_NEVER / _AUTO / _NOW."""
+        self._check(self.lib.drt_hip_set_specialisation(self.ctx, int(mode)), "drt_hip_set_specialisation")
 
     def update_params(self, params: np.ndarray):
         p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)

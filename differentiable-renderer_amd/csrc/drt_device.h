@@ -2,10 +2,15 @@
 // Written for CDNA4 only (wave64, no portability layer).
 #pragma once
 
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "drt_hip.h"
+#if defined(__HIPCC_RTC__) && !defined(INFINITY)
+#define INFINITY __builtin_huge_valf()
+#endif
 #include "drt_sincos.h"
 
 #define DRT_MAX_SHAPES 64
@@ -16,7 +21,6 @@
 #define DRT_ID_NONE 0xFFFFu
 #define DRT_BLOCK 256
 #define DRT_WAVE 64
-#define DRT_PROG_MAX 16          // shapes whose kinds fit the 64-bit signature (3 bits each; k_path's compiled-in program)
 #define DRT_PROG_SORTED_MAX DRT_MAX_SHAPES   // shapes the kind-sorted program in LDS covers (every analytic scene the ABI takes)
 enum { DRT_PK_PLANE = 0, DRT_PK_SPHERE = 1, DRT_PK_AX = 2, DRT_PK_AY = 3, DRT_PK_AZ = 4 };
 
@@ -46,13 +50,12 @@ struct DevScene {
     int n_items, pad_items;
     unsigned long long item_pair, item_sphere, item_skip;   // skip: a mesh record (one shape index, no test)
     R items[DRT_MAX_SHAPES][8];
-    // k_path's intersection program (drt_path.h): one record per shape, scene order, 3 kind bits per shape;
-    // prog_ok = the scene has no mesh (k_path applies); prog / prog_kinds cover the first DRT_PROG_MAX shapes only
-    unsigned long long prog_kinds;
+    // k_path's intersection program (drt_path.h, drt_prog.h): one record per analytic shape with a KIND.
+    // prog_ok = the scene has no mesh (k_path applies).
     int prog_ok, prog_sorted;     // prog_sorted: the kind-sorted copy below is valid for the ANALYTIC shapes (mesh records left out)
-    R prog[DRT_PROG_MAX][4];
-    // the same records SORTED BY KIND (scene order kept inside a kind) for scenes whose kinds are not compiled in:
-    // sorted[i] = (record.xyzw), sorted_shape[i] = its shape index, kind k occupies [kind_begin[k], kind_begin[k + 1])
+    // The records SORTED BY KIND (scene order kept inside a kind): sorted[i] = (record.xyzw), sorted_shape[i] = its shape
+    // index, kind k occupies [kind_begin[k], kind_begin[k + 1]).  The kind-sorted program walks them with one counted loop
+    // per kind; a compiled-in program (KindSig) knows every shape's position at compile time.
     R sorted[DRT_PROG_SORTED_MAX][4];
     int sorted_shape[DRT_PROG_SORTED_MAX];
     int kind_begin[8];

@@ -5,6 +5,7 @@
 #include "drt_kernels.h"
 #include "drt_path.h"
 #include "drt_bvh.h"
+#include "drt_jit.h"
 
 #include <rccl/rccl.h>
 
@@ -13,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,7 +72,15 @@ struct drt_hip_ctx {
     int max_colour_param = -1;            // largest parameter index that is some material's colour (device numbering)
     bool prog_ok = false;                 // k_path's intersection program covers the scene (drt_path.h)
     bool prog_sorted = false;             // the kind-sorted program covers the scene's analytic shapes (k_shade's tail)
-    unsigned long long prog_kinds = 0;
+    unsigned long long prog_sig[4] = {0, 0, 0, 0};   // the kinds of the scene's shapes, 3 bits each, 16 per word (KindSig, drt_prog.h)
+    // run-time specialisation of k_path for this scene's shape kinds (drt_jit.h)
+    std::string arch = "gfx950";          // hipDeviceProp_t::gcnArchName: what hiprtc compiles for
+    int jit_mode = 1;                     // DRT_HIP_JIT: 0 = never, 1 = once the scene has rendered enough to pay for the compile, 2 ("force") = at once
+    uint64_t scene_work = 0;              // path-bounces this scene has rendered through k_path (reset by upload_scene)
+    std::map<std::string, hipFunction_t> jit_fn;   // instantiations loaded on this device, by name expression (nullptr: failed)
+    std::vector<hipModule_t> jit_modules;
+    std::string jit_error;                // why the last specialisation failed (the kind-sorted program renders instead)
+    double jit_ms = 0;                    // compile + load time spent by this context
     int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)
     int n_user_params = 0;            // what the caller uploaded and gets gradients for
     std::vector<uint8_t> requires_grad;
@@ -265,8 +275,9 @@ int upload_bvh(drt_hip_ctx* ctx, const drt_bvh::Built& b, const std::vector<drt_
 }
 
 template <typename R>
-void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s)
+void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s, unsigned long long sig[4])
 {
+    sig[0] = sig[1] = sig[2] = sig[3] = 0;
     memset(&ds, 0, sizeof ds);
     ds.n_shapes = s->n_shapes;
     ds.n_materials = s->n_materials;
@@ -353,11 +364,7 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
             for (int j = 0; j < 4; ++j)
                 recs[i][j] = rec[j];
         }
-        if (i < DRT_PROG_MAX) {                 // the signature of the first 16 shapes (k_path's compiled-in program)
-            ds.prog_kinds |= (unsigned long long)kinds[i] << (3 * i);
-            for (int j = 0; j < 4; ++j)
-                ds.prog[i][j] = recs[i][j];
-        }
+        sig[i >> 4] |= (unsigned long long)kinds[i] << (3 * (i & 15));   // the scene's signature (KindSig, drt_prog.h)
     }
     {   // the kind-sorted copy (stable: scene order inside a kind)
         int n = 0;
@@ -462,6 +469,43 @@ int queue_length(drt_hip_ctx* ctx, const uint32_t* counts_row, uint32_t n_region
     *out = *ctx->h_probe;
     return DRT_OK;
 }
+// The instantiation `name_expr` of a kernel template of drt_path.h, compiled for this scene's KindSig by hiprtc and loaded
+// on this context's device (drt_jit.h).  nullptr: it could not be made (ctx->jit_error says why; the caller renders with
+// the kind-sorted program, same results).
+hipFunction_t jit_function(drt_hip_ctx* ctx, const std::string& name_expr)
+{
+    auto it = ctx->jit_fn.find(name_expr);
+    if (it != ctx->jit_fn.end())
+        return it->second;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipFunction_t fn = nullptr;
+    const drt_jit::Code& c = drt_jit::compile(ctx->arch, name_expr);
+    if (!c.ok) {
+        ctx->jit_error = c.log;
+    } else {
+        hipModule_t mod = nullptr;
+        hipError_t e = hipModuleLoadData(&mod, c.bin.data());
+        if (e == hipSuccess) {
+            ctx->jit_modules.push_back(mod);
+            e = hipModuleGetFunction(&fn, mod, c.lowered.c_str());
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fn = nullptr;
+            ctx->jit_error = std::string("loading ") + name_expr + ": " + hipGetErrorString(e);
+        }
+    }
+    if (!fn && getenv("DRT_HIP_JIT_VERBOSE"))
+        fprintf(stderr, "[drt_hip] specialisation failed: %s\n", ctx->jit_error.c_str());
+    ctx->jit_fn[name_expr] = fn;
+    ctx->jit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return fn;
+}
+// A compile costs ~0.5 s of host time and buys ~25 % of the kind-sorted program's time: it pays once the scene has rendered
+// a few seconds' worth of frames.  2^31 path-bounces are ~20 ms of rendering: small test frames never get there, a bench or an
+// optimisation loop does within its first frames.
+#define DRT_JIT_AFTER_WORK ((uint64_t)1 << 31)
+
 #define DRT_POLL_EVERY 4
 #define DRT_TOTAL_WORDS 8           // segtotal: segments, queue rays read, written, capped paths, K2 rays, walked candidates
 
@@ -790,7 +834,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                 static const bool sig_env = !(getenv("DRT_HIP_PATH_SIG") && atoi(getenv("DRT_HIP_PATH_SIG")) == 0);
                 // (f64 too: the verification mode runs the same program with full-precision reciprocals and square roots)
                 static const bool sig64_env = !(getenv("DRT_HIP_PATH_SIG_F64") && atoi(getenv("DRT_HIP_PATH_SIG_F64")) == 0);
-                const bool cornell_sig = sig_env && (sizeof(R) == 4 || sig64_env) && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_kinds == DRT_SIG_CORNELL;
+                // (DRT_HIP_BUILTIN_PROGRAM=0: the reference's scene is specialised at run time like any other -- a test that the
+                //  library's own build and hiprtc's agree bit for bit)
+                static const bool builtin_env = !(getenv("DRT_HIP_BUILTIN_PROGRAM") && atoi(getenv("DRT_HIP_BUILTIN_PROGRAM")) == 0);
+                const bool cornell_sig = sig_env && builtin_env && ctx->jit_mode >= 0 && (sizeof(R) == 4 || sig64_env) && ctx->n_shapes == DRT_NSIG_CORNELL && ctx->prog_sig[0] == DRT_SIG_CORNELL;
                 unsigned long long* ptotal = path_finish ? (unsigned long long*)ctx->segtotal[ctx->slot].p : (unsigned long long*)nullptr;
                 // (frames that overlap: this frame's grid goes to the slot's own stream, behind whoever still uses the slot's
                 //  buffers, and the finishing launch on the context's stream waits for it.  Scene and parameter uploads block
@@ -808,6 +855,29 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (ctx->overlap_wait)
                         HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->overlap_wait, 0));
                 }
+                // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
+                const bool three = ctx->max_colour_param < 3;
+                const bool tangents = backward || gimg_param >= 0;
+                // ---- a program of the scene's own (drt_jit.h): the instantiation for its KindSig, once it pays
+                hipFunction_t jit = nullptr;
+                ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(D > 0 ? D : 1);
+                // (f32 only: the f64 verification mode keeps the reference's literal shape loop for every scene but the reference's own)
+                if (!cornell_sig && sig_env && ctx->jit_mode > 0 && sizeof(R) == 4 &&
+                    (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK)) {
+                    const std::string sg = drt_jit::sig_type(ctx->prog_sig, ctx->n_shapes);
+                    const char* rt = sizeof(R) == 4 ? "float" : "double";
+                    const char* sp = ctx->has_specular ? "true" : "false";
+                    char name[384];
+                    if (unbiased)
+                        snprintf(name, sizeof name, "k_path_unbiased<%s, %s, %d, %s>", rt, sp, ctx->n_params > 4 ? 8 : 4, sg.c_str());
+                    else {
+                        const int np = tangents ? (ctx->n_params > 4 ? 8 : 4) : 0;
+                        const int nc = tangents ? (ctx->n_params > 4 ? 8 : (three ? 3 : 4)) : 0;
+                        snprintf(name, sizeof name, "k_path<%s, %s, %d, %d, %s, %s>", rt, sp, np, nc, sg.c_str(), path_regen ? "true" : "false");
+                    }
+                    jit = jit_function(ctx, name);
+                }
+                st->path_program = cornell_sig ? DRT_PROGRAM_BUILTIN : (jit ? DRT_PROGRAM_SPECIALISED : DRT_PROGRAM_SORTED);
                 if ((rc = timing_begin(ctx, timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SG)                                                                                 \
     do {                                                                                                                 \
@@ -823,10 +893,14 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         if (cornell_sig) DRT_LAUNCH_PATH(SPEC, NP, NC, SigCornell);                        \
         else DRT_LAUNCH_PATH(SPEC, NP, NC, SigNone);                                       \
     } while (0)
-                // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
-                const bool three = ctx->max_colour_param < 3;
-                const bool tangents = backward || gimg_param >= 0;
-                if (unbiased) {                             // the unbiased operator: fresh suffix paths per vertex, in registers
+                if (jit) {
+                    const DevScene<R>* a_scene = d_scene;
+                    const R* a_params = d_params;
+                    const float* a_adjoint = d_adjoint;
+                    void* args_path[] = {&pa, &a_scene, &a_params, &a_adjoint, &gpart, &fpart, &counts, &ptotal, &gpix};
+                    void* args_unb[] = {&pa, &a_scene, &a_params, &a_adjoint, &gpart, &fpart, &counts, &ptotal};
+                    HIPCHK(ctx, hipModuleLaunchKernel(jit, (unsigned)gpath, 1, 1, DRT_BLOCK, 1, 1, 0, ks, unbiased ? args_unb : args_path, nullptr));
+                } else if (unbiased) {                      // the unbiased operator: fresh suffix paths per vertex, in registers
 #define DRT_LAUNCH_UNB(SPEC, NP)                                                                                              \
     do {                                                                                                                      \
         if (cornell_sig)                                                                                                      \
@@ -839,7 +913,7 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                     if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }
                     else { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 4); else DRT_LAUNCH_UNB(false, 4); }
 #undef DRT_LAUNCH_UNB
-                } else if (tangents && ctx->n_params > 4) {        // 5 .. 8 parameters: 24 tangent + 24 gradient registers per lane
+                } else if (tangents && ctx->n_params > 4) {        // 5 .. 8 parameters
                     if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 8, 8);
                     else DRT_LAUNCH_PATH_SIG(false, 8, 8);
                 } else if (tangents) {
@@ -1269,7 +1343,11 @@ int drt_hip_create(int device_id, drt_hip_ctx** out)
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->n_cu = prop.multiProcessorCount;
         ctx->device_mem = (uint64_t)prop.totalGlobalMem;
+        if (prop.gcnArchName[0])
+            ctx->arch = prop.gcnArchName;
     }
+    if (const char* e = getenv("DRT_HIP_JIT"))
+        ctx->jit_mode = !strcmp(e, "force") ? DRT_SPECIALISE_NOW : (atoi(e) > 0 ? DRT_SPECIALISE_AUTO : (atoi(e) < 0 ? DRT_SPECIALISE_GENERIC : DRT_SPECIALISE_NEVER));
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return DRT_ERR_HIP;
@@ -1333,6 +1411,8 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         release(ctx->out[i]);
     }
     release_mesh(ctx);
+    for (hipModule_t m : ctx->jit_modules)
+        (void)hipModuleUnload(m);
     if (ctx->d_scene_f) (void)hipFree(ctx->d_scene_f);
     if (ctx->d_scene_d) (void)hipFree(ctx->d_scene_d);
     if (ctx->d_params_f) (void)hipFree(ctx->d_params_f);
@@ -1411,8 +1491,9 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     DevScene<double>* hd = new DevScene<double>();
     std::vector<float> pf;
     std::vector<double> pd;
-    fill_scene(*hf, pf, s);
-    fill_scene(*hd, pd, s);
+    unsigned long long sig[4];
+    fill_scene(*hf, pf, s, sig);
+    fill_scene(*hd, pd, s, sig);
     int rc = DRT_OK;
     auto up = [&](void** dst, const void* src, size_t bytes) -> int {
         if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
@@ -1432,7 +1513,8 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     const int n_dev_params = hf->n_params;   // user parameters + internal constants
     ctx->prog_ok = hf->prog_ok != 0;
     ctx->prog_sorted = hf->prog_sorted != 0;
-    ctx->prog_kinds = hf->prog_kinds;
+    for (int i = 0; i < 4; ++i)
+        ctx->prog_sig[i] = sig[i];
     ctx->max_colour_param = -1;
     for (int i = 0; i < hf->n_materials; ++i)
         ctx->max_colour_param = std::max(ctx->max_colour_param, hf->materials[i].param);
@@ -1505,6 +1587,7 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
             ctx->bvh_bytes = (uint64_t)built.nodes.size() * 64 + (uint64_t)tris.size() * 48;   // f32 image: nodes + three 16-byte triangle lanes
         }
     }
+    ctx->scene_work = 0;
     ctx->n_user_params = s->n_params;
     ctx->n_params = n_dev_params;      // + the internal constant of mirror materials, if any
     ctx->n_shapes = s->n_shapes;
@@ -1910,6 +1993,7 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true, hipEvent_t don
         st.queue_rays_written = h_tot[2];
         st.capped_paths = h_tot[3];
         st.bvh_bytes = ctx->has_mesh ? ctx->bvh_bytes : 0;
+        st.jit_ms = ctx->jit_ms;
         st.units[DRT_K_INTERSECT] = h_tot[4];              // rays k_intersect tested (mesh scenes: the camera rays only)
         st.units[DRT_K_INTERSECT_MESH] = h_tot[5];         // candidate rays the BVH walk took (those that reach the mesh bounds)
         st.units[DRT_K_SHADE] = st.launches[DRT_K_SHADE] ? st.segments : 0;
@@ -2027,6 +2111,7 @@ static int render_group(drt_hip_ctx* g, const drt_camera_desc* cam, const drt_re
             st.queue_rays_written += mstats[i].queue_rays_written;
             st.capped_paths += mstats[i].capped_paths;
             st.path_bytes += mstats[i].path_bytes;
+            st.jit_ms += mstats[i].jit_ms;
             for (int k = 0; k < DRT_K_COUNT; ++k) {
                 st.units[k] += mstats[i].units[k];
                 if (mstats[i].ms_kernel[k] > st.ms_kernel[k])
@@ -2360,6 +2445,18 @@ int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* s)
     return DRT_OK;
 }
 
+int drt_hip_set_specialisation(drt_hip_ctx* ctx, int mode)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (mode < DRT_SPECIALISE_GENERIC || mode > DRT_SPECIALISE_NOW)
+        return fail(ctx, DRT_ERR_INVALID, "set_specialisation: unknown mode");
+    ctx->jit_mode = mode;
+    for (drt_hip_ctx* m : ctx->members)
+        m->jit_mode = mode;
+    return DRT_OK;
+}
+
 int drt_hip_update_params(drt_hip_ctx* ctx, const double* params)
 {
     if (!ctx)
@@ -2437,6 +2534,22 @@ extern "C" int drt_hip_debug_walk_times(unsigned long long* out, int n_waves)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_times), (size_t)n_waves * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// hiprtc needs no device: the build container checks that the embedded headers still compile under it (tests/test_abi.py).
+// Returns the size of the code object, or a negative status with the compiler's output in `log`.
+extern "C" int drt_hip_debug_jit_compile(const char* arch, const char* name_expr, double* ms, char* log, int log_cap)
+{
+    if (!arch || !name_expr)
+        return DRT_ERR_INVALID;
+    const drt_jit::Code& c = drt_jit::compile(arch, name_expr);
+    if (ms)
+        *ms = c.ms;
+    if (log && log_cap > 0) {
+        strncpy(log, c.log.c_str(), (size_t)log_cap - 1);
+        log[log_cap - 1] = 0;
+    }
+    return c.ok ? (int)c.bin.size() : DRT_ERR_UNSUPPORTED;
+}
 
 const char* drt_hip_last_error(drt_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

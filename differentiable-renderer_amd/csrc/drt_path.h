@@ -29,9 +29,9 @@
 //                     (the products with 0 and +-1 are exact, rcp is odd), 2 instead of 9 VALU and the three
 //                     rcp(d_a) are shared by all axis planes of the scene
 //     sphere          half-b form of shape.hpp:78-103 (b = 2 b', disc = 4 disc': exact power-of-two scalings)
-// The shape loop is fully unrolled over DRT_PROG_MAX records whose kinds are either read from the scene (uniform
-// branches on a scalar mask, records by scalar loads the compiler hoists out of the bounce loop) or, for the
-// topology of the reference's own scene, fixed at compile time (template SG: no branches at all).
+// The kinds are either read from the scene (the kind-sorted program in LDS: one counted loop per kind) or fixed at compile
+// time (template SG, a KindSig: the shape loop fully unrolled, records in scalar registers, no branches at all) -- for
+// the reference's own scene in the library, for any other analytic scene by hiprtc at run time (drt_jit.h).
 #pragma once
 
 #include "drt_kernels.h"
@@ -370,7 +370,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
     if (SG::n > 0)
-        recs.load(sc);
+        recs.template load<SG>(sc);
     if (sizeof(R) == 4 && SG::n == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {
@@ -634,7 +634,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
     if (SG::n > 0)
-        recs.load(sc);
+        recs.template load<SG>(sc);
     if (sizeof(R) == 4 && SG::n == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {

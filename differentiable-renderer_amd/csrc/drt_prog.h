@@ -99,6 +99,16 @@ struct KindSig {
     {
         return (int)(((s < 16 ? W0 : s < 32 ? W1 : s < 48 ? W2 : W3) >> (3 * (s & 15))) & 7ull);
     }
+    // where shape s stands in the scene's kind-sorted record array (DevScene::sorted: kinds ascending, scene order kept
+    // inside a kind) -- a compile-time constant, so the compiled-in program and the kind-sorted one share ONE copy of the records
+    static __host__ __device__ constexpr int pos(int s)
+    {
+        int p = 0;
+        for (int i = 0; i < N; ++i)
+            if (kind(i) < kind(s) || (kind(i) == kind(s) && i < s))
+                ++p;
+        return p;
+    }
 };
 typedef KindSig<0ull, 0ull, 0ull, 0ull, 0> SigNone;
 
@@ -115,11 +125,12 @@ template <int NSIG, typename R = float>
 struct ProgRecs {
     typename Q4<R>::T r[NSIG > 0 ? NSIG : 1];
     const ProgLds* lds;
+    template <typename SG>
     __device__ inline void load(const DevScene<R>* __restrict__ sc)
     {
 #pragma unroll
         for (int s = 0; s < NSIG; ++s)
-            r[s] = *reinterpret_cast<const typename Q4<R>::T*>(sc->prog[s]);
+            r[s] = *reinterpret_cast<const typename Q4<R>::T*>(sc->sorted[SG::pos(s)]);
     }
 };
 

@@ -12,8 +12,9 @@
 // the whole range against libm in double (max abs error 1.2e-7).
 #pragma once
 
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
-#include <string.h>
+#endif
 
 #if defined(__HIPCC__)
 #define DRT_SC_HD __host__ __device__ inline
@@ -21,8 +22,8 @@
 #define DRT_SC_HD inline
 #endif
 
-DRT_SC_HD float drt_bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-DRT_SC_HD uint32_t drt_float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+DRT_SC_HD float drt_bits_to_float(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+DRT_SC_HD uint32_t drt_float_to_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
 DRT_SC_HD void sincos_2pi_u31(uint32_t r, float* s, float* c)
 {

@@ -43,14 +43,21 @@
 #ifndef DRT_HIP_H
 #define DRT_HIP_H
 
+#if defined(__HIPCC_RTC__)
+/* compiled by hiprtc at run time (the library specialises k_path for a scene: csrc/drt_jit.h): no system headers there */
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#else
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 5
+#define DRT_HIP_ABI_VERSION 6
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -206,7 +213,18 @@ typedef struct drt_hip_stats {
     uint64_t bvh_bytes;             /* mesh scenes: bytes of the BVH (nodes + triangle records) the walk reads from */
     uint64_t path_bytes;            /* k_path launches: the bytes they write (per-range pixel sums, per-block gradient
                                        partials, per-wave counters) -- everything that kernel moves through HBM */
+    uint32_t path_program;          /* k_path launches: which closest-hit program ran (DRT_PROGRAM_*; same results, different cost) */
+    uint32_t reserved;
+    double jit_ms;                  /* host time this context has spent compiling and loading specialised programs so far */
 } drt_hip_stats;
+
+/* k_path's closest-hit program (Pathtracer::raycast, pathtracer.hpp:72-89, over the analytic shapes) */
+enum {
+    DRT_PROGRAM_NONE = 0,        /* the render did not go through k_path */
+    DRT_PROGRAM_SORTED = 1,      /* shape kinds read at run time: records sorted by kind in LDS, one counted loop per kind */
+    DRT_PROGRAM_BUILTIN = 2,     /* kinds compiled in, the instantiation the library carries for the reference's own scene (render.cpp:39-47) */
+    DRT_PROGRAM_SPECIALISED = 3  /* kinds compiled in at run time for THIS scene (hiprtc; drt_hip_set_specialisation) */
+};
 
 typedef struct drt_hip_ctx drt_hip_ctx;
 
@@ -236,6 +254,19 @@ int drt_hip_comm_size(const drt_hip_ctx* ctx);    /* ranks of the context's comm
 int drt_hip_comm_destroy(drt_hip_ctx* ctx);
 int drt_hip_upload_scene(drt_hip_ctx* ctx, const drt_scene_desc* scene);
 int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3 */);
+/* When a scene of analytic shapes gets a path kernel compiled for ITS shape kinds (the reference dispatches
+ * Shape::intersect through a vtable per shape and ray, shape.hpp:11-35; the device wants the kinds as compile-time
+ * constants: ~25 % faster than reading them at run time).  The library carries that kernel for the reference's own scene;
+ * for any other it compiles one with hiprtc (~0.5 s of host time per kernel variant, cached per process), bit-identical
+ * in its results to the run-time program it replaces:
+ *   DRT_SPECIALISE_GENERIC the run-time program even for the reference's own scene (measurement: what specialisation buys)
+ *   DRT_SPECIALISE_NEVER   never compile at run time (the reference's own scene keeps the kernel the library carries for it)
+ *   DRT_SPECIALISE_AUTO    (default) once the scene has rendered 2^31 path-bounces through this context (~20 ms of
+ *                          frames): small test frames never pay for a compile, a render loop does within its first frames
+ *   DRT_SPECIALISE_NOW     at the next render that can use it (a caller that knows it will render many frames)
+ * The environment variable DRT_HIP_JIT (-1 | 0 | 1 | force) sets the default of new contexts.  Group contexts: every member. */
+enum { DRT_SPECIALISE_GENERIC = -1, DRT_SPECIALISE_NEVER = 0, DRT_SPECIALISE_AUTO = 1, DRT_SPECIALISE_NOW = 2 };
+int drt_hip_set_specialisation(drt_hip_ctx* ctx, int mode);
 /* out_rgb: width*height*3 floats, row-major, mean over spp; only the rows of this shard are
  *          written (others untouched). May be NULL.
  * adjoint_rgb: width*height*3 floats, the seed every sample of that pixel is back-propagated

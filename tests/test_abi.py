@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = C.CDLL(pkg.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(lib, s), f"libdrt_hip.so does not export {s}"
-    assert pkg.load_library().drt_hip_abi_version() == pkg.ABI_VERSION == 5   # v2 meshes, v3 queue statistics, v4 groups + communicators, v5 asynchronous host-buffer renders
+    assert pkg.load_library().drt_hip_abi_version() == pkg.ABI_VERSION == 6   # v2 meshes, v3 queue statistics, v4 groups + communicators, v5 asynchronous host-buffer renders, v6 scene-specialised path kernels
     assert sorted(pkg._ABI_SYMBOLS) == declared_symbols()
 
 
@@ -48,6 +48,19 @@ def test_ctypes_mirror_matches_the_c_layout(pkg, oracle):
     assert L(13) == pkg.RenderParamsDesc.absorb.offset
     assert L(14) == pkg.RenderParamsDesc.batch_paths.offset
     assert L(15) == pkg.HipStats.ms_kernel.offset
+
+
+def test_embedded_headers_compile_under_hiprtc(pkg):
+    """The library specialises k_path per scene at run time (csrc/drt_jit.h): the headers it embeds must compile under
+    hiprtc (no system headers there) -- checked here, where no GPU is needed, for one variant of each kernel template."""
+    lib = pkg.load_library()
+    f = lib.drt_hip_debug_jit_compile
+    f.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    for name in (b"k_path<float, true, 4, 3, KindSig<0x9249249ull, 0x0ull, 0x0ull, 0x0ull, 12>, true>",
+                 b"k_path_unbiased<float, false, 4, KindSig<0x9249249249ull, 0x1249ull, 0x0ull, 0x0ull, 20>>"):
+        ms, log = C.c_double(), C.create_string_buffer(8000)
+        size = f(b"gfx950", name, C.byref(ms), log, 8000)
+        assert size > 1000, log.value.decode()
 
 
 def test_no_device_means_an_error_not_a_fallback(pkg):
