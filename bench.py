@@ -177,6 +177,9 @@ def main():
     cam = pkg.cornell_camera(a.width, a.height)
     backward = not a.forward_only
     r = pkg.HipRenderer(local_rank)          # raises without libdrt_hip.so / a device: no fallback
+    # a render loop: the scene's own path kernel is compiled at the first frame (setup, before the warm-up; the library would
+    # do it by itself after 2^31 path-bounces -- DRT_SPECIALISE_AUTO --; `program` / `specialise_ms` in the line say what ran)
+    r.set_specialisation(pkg.SPECIALISE_NOW)
     r.upload_scene(scene)
     dev = torch.device("cuda", local_rank)
 
@@ -310,9 +313,14 @@ def main():
     # k_intersect_mesh: per CANDIDATE ray a 36-byte record (slot, origin, direction, analytic t, tie-break index) read and
     # at most one 8-byte hit written (the BVH itself is L2 / Infinity-Cache resident)
     seg = max(1, segments)
+    # mesh scenes, k_shade<TAIL> (no k_intersect launch: the shade launch intersects the ray it produces with the analytic shapes
+    # itself): the unfused 80 B + the next depth's hit lane (8 B written) + a 40-byte candidate record per ray that reaches the
+    # mesh bounds (the BVH walk's input: units["intersect_mesh"] of them per step)
+    shade_tail_bytes = 88.0 + 40.0 * units["intersect_mesh"] / seg
     bpu = {"intersect": 32.0, "intersect_mesh": 44.0,
            "shade": 80.0 if kernel_launches["intersect"] else
-                    (8.0 if kernel_launches["backward"] else 16.0 * paths / seg) + 32.0 * queue_rays / seg,
+                    (shade_tail_bytes if kernel_launches["intersect_mesh"] else
+                     (8.0 if kernel_launches["backward"] else 16.0 * paths / seg) + 32.0 * queue_rays / seg),
            "path": stats.get("path_bytes", 0) / seg,
            "backward": 8.0, "raygen": 32.0, "gradreduce": 0.0,
            # K5 reads 16 B of radiance per path; behind k_path it reads the per-range pixel sums that launch wrote
@@ -391,9 +399,17 @@ def main():
                 "traffic_note": "GB/s of PMC-counted HBM bytes per launch (profiles/traffic.json, rocprofv3 --pmc, FETCH_SIZE "
                                 "doubled per the gfx950 correction) over the live launch time" if traffic else None,
                 "avg_launch_ms": round(launch_ms, 4),
+                "mode": "one launch at a time: HIP events around every launch of frames rendered in stream order (as rocprofv3 "
+                        "sees them with DRT_HIP_OVERLAP_FRAMES=0, profiles/); `value` pipelines two frames, see `pipelined`",
                 "pmc_note": pmc_note,
                 "hbm": hbm_view, "valu": valu_view,
                 "kernels": per_kernel}
+    if dominant == "path" and valu_view and dk["launches_per_step"] > 0:
+        # the chip-level issue rate of the HEADLINE mode: the same instructions per step over the step time of the timed region
+        # (the grids of two consecutive frames overlap: a launch's own begin-to-end time is longer than a step there)
+        g2 = pmc["valu_insts_per_launch"] * dk["launches_per_step"] / (ms_per_step * 1e-3) * 1e-9
+        roofline["pipelined"] = {"achieved": round(g2, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                                 "frac": round(g2 / VALU_PEAK_GINST, 4), "ms_per_step": round(ms_per_step, 4)}
     if dominant == "intersect_mesh" and pmc.get("lane_stats"):
         roofline["walk_lanes"] = pmc["lane_stats"]      # tools/bvh_stats.py on the same scene (a -DDRT_BVH_STATS build)
 
@@ -447,6 +463,41 @@ def main():
         segs = one(timing=True)["segments"]
         fence()
         return {"value": round(segs / dt5 * 1e-6, 2), "unit": "Mray/s", "ms_per_step": round(dt5 * 1e3, 4)}
+
+    # ---- what the headline is made of.  `value` = frames that do not depend on each other, the path kernels of two consecutive
+    # ones overlapping (device-pointer renders without a wait).  `serial_frame`: the same frames with DRT_RENDER_SERIAL --
+    # everything of a frame on the context's stream, in order: what an optimisation loop gets, whose frame i + 1 needs frame
+    # i's gradients.  `generic_program`: serial frames on a context that reads the shape kinds at run time
+    # (DRT_SPECIALISE_GENERIC) instead of running the kernel compiled for the scene: what specialisation buys.
+    serial_view = generic_view = None
+    if rank == 0 and world == 1:
+        def frames(rr, params, n):
+            for _ in range(3):
+                rr.render_device(cam, params, out_rgb.data_ptr(), grads[0].data_ptr() if backward else 0, backward=backward, sync=False)
+            rr.synchronize()
+            torch.cuda.synchronize(dev)
+            t7 = time.perf_counter()
+            for _ in range(n):
+                rr.render_device(cam, params, out_rgb.data_ptr(), grads[0].data_ptr() if backward else 0, backward=backward, sync=False)
+            rr.synchronize()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t7) / n
+        rps = dataclasses.replace(rp, flags=rp.flags | pkg.RENDER_SERIAL)
+        dts = frames(r, rps, a.steps)
+        serial_view = {"value": round(total_segments / dts * 1e-6, 2), "unit": "Mray/s", "ms_per_step": round(dts * 1e3, 4),
+                       "note": "DRT_RENDER_SERIAL: frames in stream order, no overlap between consecutive frames' path kernels"}
+        if stats.get("path_program") in ("builtin", "specialised"):
+            try:
+                rg = pkg.HipRenderer(local_rank)
+                rg.set_specialisation(pkg.SPECIALISE_GENERIC)
+                rg.upload_scene(scene)
+                dtg = frames(rg, rps, a.steps)
+                generic_view = {"value": round(total_segments / dtg * 1e-6, 2), "unit": "Mray/s", "ms_per_step": round(dtg * 1e3, 4),
+                                "note": "serial frames with the shape kinds read at run time (the kind-sorted program in LDS; "
+                                        "DRT_SPECIALISE_GENERIC) -- bit-identical results"}
+                rg.close()
+            except Exception as exc:
+                generic_view = {"error": f"{type(exc).__name__}: {exc}"}
 
     f64_view = fwd_view = unb_view = None
     if extra and not a.unbiased and backward and world == 1:
@@ -557,6 +608,10 @@ def main():
                         np.abs(g_r - res["grads"]).max() / max(1e-300, np.abs(res["grads"]).max()))
             except Exception as exc:        # (the checker's binary is optional; the port above is the baseline)
                 cpu_baseline["reference"] = {"error": f"{type(exc).__name__}: {exc}"}
+                print(f"bench.py: cpu_baseline.reference failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+        elif a.ref_seconds > 0:
+            print("bench.py: oracle/_ref/ref_harness is not there (a clean checkout: it is built in the build container from "
+                  "/root/reference by oracle/Makefile and travels as a binary) -- no cpu_baseline.reference", file=sys.stderr)
         if a.cpu_all_cores:
             # the reference is single-threaded by construction (global rand()); this is N independent
             # processes, each rendering its interleaved row bands of the same sample
@@ -647,10 +702,19 @@ def main():
                                    f"{' + procedural mesh' if a.scene.startswith('mesh') else ''}) {a.width}x{a.height}, "
                                    f"{a.spp} spp per GPU, {depth_text} (-b {a.min_bounces} -p {a.absorb:g}), "
                                    f"{'fwd + radiative-backprop gradients of ' + str(scene.n_params) + ' parameters' if backward else 'fwd only'}",
+                       "mode": (("2 frames pipelined (the path kernels of consecutive frames overlap on two streams); "
+                                 if (stats.get("path_program", "none") != "none" and os.environ.get("DRT_HIP_OVERLAP_FRAMES", "1") != "0")
+                                 else "frames in stream order; ") +
+                                {"builtin": "k_path with the shape kinds of the reference's scene compiled in (the instantiation the library carries)",
+                                 "specialised": "k_path compiled for this scene's shape kinds at run time (hiprtc)",
+                                 "sorted": "k_path reading the shape kinds at run time (kind-sorted program)",
+                                 "none": "the queue wavefront (K1-K7)"}.get(stats.get("path_program", "none"), "?")),
+                       "program": stats.get("path_program"), "specialise_ms": round(stats.get("jit_ms", 0.0), 1),
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
                        "parallelism": par, "batches_per_step": stats["batches"],
                        "capped_paths_per_step": stats["capped_paths"]},
             "weak_scaling": weak_scaling,
+            "serial_frame": serial_view, "generic_program": generic_view,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
             "preheat_ms": a.preheat_ms, "preheat_frames": preheat_frames,
             "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view, "two_contexts": two_ctx_view,

@@ -103,6 +103,12 @@ struct drt_hip_ctx {
     // event -- what the caller sees (outputs written in stream order) does not change.
     hipStream_t path_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_begin[2] = {nullptr, nullptr}, ev_path[2] = {nullptr, nullptr};
+    // k_path's partial-sum buffers come in two sets ("lanes": fpart/gpart/counts and fpart2/gpart2/counts2).  Whoever used a
+    // lane last -- an overlapped frame or a plain render on the context's stream (lane 0) -- records ev_lane_free[lane] on the
+    // context's stream once its last reader (the finishing launch) is enqueued; an overlapped k_path launch, which runs on a
+    // stream of its own, waits for it before it writes the lane again.
+    hipEvent_t ev_lane_free[2] = {nullptr, nullptr};
+    bool lane_used[2] = {false, false};
     bool overlap_next = false;            // set around render_launch by the callers whose renders do not wait
     bool slot_used[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
     DevBuf fpart2, gpart2, counts2;       // k_path's partial sums of the odd frames
@@ -124,7 +130,6 @@ struct drt_hip_ctx {
     hipEvent_t ev_rendered[DRT_HIP_FRAMES_IN_FLIGHT] = {}, ev_copied[DRT_HIP_FRAMES_IN_FLIGHT] = {};
     RenderJob pending[DRT_HIP_FRAMES_IN_FLIGHT];
     bool in_flight[DRT_HIP_FRAMES_IN_FLIGHT] = {};
-    hipEvent_t overlap_wait = nullptr;    // what the frame's k_path waits for before it writes its set of partial-sum buffers
     uint64_t next_ticket = 1;
     bool zero_copy_next = false;          // set around the render_launch of an asynchronous host-buffer render
     uint64_t dev_frames = 0;              // renders made with DRT_RENDER_ALLREDUCE_ASYNC (their gradient set alternates)
@@ -852,8 +857,10 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
                         HIPCHK(ctx, hipEventRecord(ctx->ev_begin[lane2], ctx->stream));
                         HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_begin[lane2], 0));
                     }
-                    if (ctx->overlap_wait)
-                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->overlap_wait, 0));
+                    // (the lane's buffers: their last user -- this lane's previous frame, or a render that went through the
+                    //  context's stream -- has enqueued its last reader on the context's stream by the time its event is recorded)
+                    if (ctx->lane_used[lane2] && ctx->ev_lane_free[lane2])
+                        HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_lane_free[lane2], 0));
                 }
                 // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
                 const bool three = ctx->max_colour_param < 3;
@@ -1307,6 +1314,13 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, n_local_pixels)), dim3(DRT_BLOCK), 0, ctx->stream,
                            a, n_local_pixels, gfilm, d_out_gimg);
     }
+    {   // this render's lane of partial-sum buffers is free once the context's stream has come this far
+        const int lane = overlap_ok ? (ctx->slot & 1) : 0;
+        if (ctx->ev_lane_free[lane]) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_lane_free[lane], ctx->stream));
+            ctx->lane_used[lane] = true;
+        }
+    }
     HIPCHK(ctx, hipGetLastError());
     return DRT_OK;
 }
@@ -1366,6 +1380,9 @@ int drt_hip_create(int device_id, drt_hip_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess)
             ctx->copy_stream = nullptr;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&ctx->ev_lane_free[i], hipEventDisableTiming) != hipSuccess)
+                ctx->ev_lane_free[i] = nullptr;
     }
     {   // the BVH walk is a persistent kernel whose waves own strided streams of rays: its grid must be exactly what
         // is resident at once (more blocks would run as a second round behind the first, at half the occupancy)
@@ -1431,6 +1448,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         if (ctx->path_stream[i]) { (void)hipStreamSynchronize(ctx->path_stream[i]); (void)hipStreamDestroy(ctx->path_stream[i]); }
         if (ctx->ev_begin[i]) (void)hipEventDestroy(ctx->ev_begin[i]);
         if (ctx->ev_path[i]) (void)hipEventDestroy(ctx->ev_path[i]);
+        if (ctx->ev_lane_free[i]) (void)hipEventDestroy(ctx->ev_lane_free[i]);
     }
     release(ctx->probe);
     for (hipEvent_t e : ctx->event_pool)
@@ -1482,6 +1500,11 @@ static int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
         if (s->emitters[i].param < 0 || s->emitters[i].param >= s->n_params)
             return fail(ctx, DRT_ERR_INVALID, "scene: emitter parameter index out of range");
 
+    // (drt_hip_wait hands a frame over with the scene's parameter count and requires_grad flags: they must still be the ones
+    //  the frame was rendered with)
+    for (int i = 0; i < DRT_HIP_FRAMES_IN_FLIGHT; ++i)
+        if (ctx->in_flight[i])
+            return fail(ctx, DRT_ERR_INVALID, "upload_scene: asynchronous frames are in flight -- drt_hip_wait for them first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     // from here on the device state is being replaced: a failure below (BVH limits, out of memory) must leave the
@@ -2152,11 +2175,9 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         if (ar_async && ctx->slot_used[ctx->slot])
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[ctx->slot], 0));
     }
-    ctx->overlap_next = ar_async || dev_async;
-    ctx->overlap_wait = (ar_async || dev_async) && ctx->slot_used[ctx->slot] ? ctx->ev_copied[ctx->slot] : nullptr;
+    ctx->overlap_next = (ar_async || dev_async) && !(rp->flags & DRT_RENDER_SERIAL);
     rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
     ctx->overlap_next = false;
-    ctx->overlap_wait = nullptr;
     if (rc != DRT_OK) {
         abort_comm_after_failure(ctx, rp);
         ctx->slot = 0;
@@ -2252,15 +2273,10 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     ctx->zero_copy_next = !two_streams;
     // (the k_path grids of consecutive frames overlap -- render_impl: path_stream --: frame t shares its stream and its set of
     //  partial sums with frame t - 2, whose finishing launch, on the context's stream, must have read them)
-    ctx->overlap_next = two_streams;
-    {
-        const int before = (int)((t + DRT_HIP_FRAMES_IN_FLIGHT - 2) % DRT_HIP_FRAMES_IN_FLIGHT);
-        ctx->overlap_wait = two_streams && t > 2 && ctx->slot_used[before] ? ctx->ev_rendered[before] : nullptr;
-    }
+    ctx->overlap_next = two_streams && !(rp && (rp->flags & DRT_RENDER_SERIAL));
     int rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, &sink, -1, nullptr);
     ctx->zero_copy_next = false;
     ctx->overlap_next = false;
-    ctx->overlap_wait = nullptr;
     if (rc != DRT_OK)
         abort_comm_after_failure(ctx, rp);
     if (rc == DRT_OK) rc = render_reduce(ctx);

@@ -150,6 +150,9 @@ typedef struct drt_camera_desc {
                                        with DRT_RENDER_SYNC), NOT in the order of drt_hip_stream(ctx).  Alternate between two
                                        out_param_grad buffers if every frame's gradient is wanted.  Without DRT_RENDER_DEVICE_OUT
                                        the flag means DRT_RENDER_ALLREDUCE (drt_hip_render_async overlaps its all-reduce anyway). */
+#define DRT_RENDER_SERIAL     0x100u /* with DEVICE_OUT: this frame's path kernel does not overlap its neighbours' -- everything of the frame runs
+                                       on the context's stream, in order.  What an optimisation loop gets, whose frame i + 1 needs the
+                                       gradients of frame i (README.md:88-101); bench.py's `serial_frame`. */
 #define DRT_RENDER_UNBIASED   0x20u /* with BACKWARD: the reference's unbiased integration operator
                                        (integrate.hpp:39-52, README.md:104-136): backward draws a
                                        FRESH direction at every vertex and traces a new suffix path

@@ -18,7 +18,19 @@ bash tools/profile.sh ${T}_unbiased_mesh mesh160x160:512x512x64:d8:unbiased  --s
 python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_config4/traffic.json gpurun_out/prof_${T}_roulette/traffic.json gpurun_out/prof_${T}_unbiased/traffic.json gpurun_out/prof_${T}_unbiased_mesh/traffic.json gpurun_out/prof_${T}_fwd/traffic.json >> "$E/prof.log" 2>&1
 cp profiles/traffic.json "$E/traffic_merged.json"
 python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
-python3 bench.py > "$E/bench.json" 2> "$E/bench.err"
+# (--store-n1: profiles/n1_reference.json is re-stored at this binary, so the first N > 1 run compares against today's value)
+python3 bench.py --store-n1 > "$E/bench.json" 2> "$E/bench.err"
+cp profiles/n1_reference.json "$E/n1_reference.json"
+# a node with more than one GPU: the scaling lines (bench.py starts its own ranks, one per GPU; weak scaling)
+NGPU=$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 1)
+for n in 2 4 8; do
+  if [ "$NGPU" -ge "$n" ]; then
+    python3 bench.py --gpus $n --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{" > "$E/scale_config3_${n}gpus.json"
+    python3 bench.py --gpus $n --config 4 --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{" > "$E/scale_config4_${n}gpus.json"
+    python3 bench.py --gpus $n --config 5 --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{" > "$E/scale_config5_${n}gpus.json"
+  fi
+done
+(python3 tools/fit_albedo.py --quiet; python3 tools/fit_albedo.py --quiet --async) > "$E/fit_albedo.txt" 2>&1
 python3 bench.py --config 2 --no-cpu-baseline > "$E/bench_config2_fwd_only.json" 2>> "$E/bench.err"
 python3 bench.py --config 4 > "$E/bench_config4_per_gpu_share.json" 2>> "$E/bench.err"
 python3 bench.py --config 5 > "$E/bench_config5_per_gpu_share.json" 2>> "$E/bench.err"

@@ -9,6 +9,12 @@ WORKLOAD=${1:-cornell:512x512x64:d8:fwdbwd}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# Every pass with the frames in stream order: with overlapping frames (the default of device-pointer renders that do not wait)
+# the k_path grids of two consecutive frames run side by side and a launch's begin-to-end span in the kernel trace is no longer
+# its own duration (round 3's trace: avg 1387 us for a 790 us kernel).  bench.py's roofline describes one launch at a time,
+# measured live with HIP events; this trace must agree with it.  (Exported here, not through `env` on the profiler's
+# command line: the profiler's preloaded library has initialised the GPU by then and an exec hop is refused.)
+export DRT_HIP_OVERLAP_FRAMES=0
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-extra-views $*"
 cd "$PWD"
 # 1) per-kernel time
