@@ -470,7 +470,7 @@ def main():
     # i's gradients.  `generic_program`: serial frames on a context that reads the shape kinds at run time
     # (DRT_SPECIALISE_GENERIC) instead of running the kernel compiled for the scene: what specialisation buys.
     serial_view = generic_view = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_extra_views:      # (profiling runs keep their kernel statistics unmixed)
         def frames(rr, params, n):
             for _ in range(3):
                 rr.render_device(cam, params, out_rgb.data_ptr(), grads[0].data_ptr() if backward else 0, backward=backward, sync=False)

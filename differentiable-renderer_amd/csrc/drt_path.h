@@ -142,7 +142,13 @@ template <typename R, int NP, int NC>
 struct Tangents {
     uint32_t cnt[NC > 4 ? 2 : 1];   // n_p of the current path, 8 bits per colour parameter
     uint32_t zc;                    // zero factors met per channel, 8 bits each
-    V3<R> acc[NP > 0 ? NP : 1];     // gradient sums of this lane
+    // The lane's gradient sums, NP x 3 values, live in an LDS column of the block (acc[row][thread]: conflict-free), not
+    // in registers: they are touched once per SAMPLE (where the path meets a light), and twelve registers held across the
+    // bounce loop cost the kernel its sixth wave per SIMD (96 -> 80 VGPRs; as scratch spills, which is what the compiler
+    // makes of them when told to fit six waves, 0.728 -> 0.704 ms on config 3; as an LDS column: see DESIGN.md 3a).
+    R* acc;
+    __device__ inline V3<R> acc_get(int p) const { return mk<R>(acc[(p * 3) * DRT_BLOCK], acc[(p * 3 + 1) * DRT_BLOCK], acc[(p * 3 + 2) * DRT_BLOCK]); }
+    __device__ inline void acc_set(int p, V3<R> v) { acc[(p * 3) * DRT_BLOCK] = v.x; acc[(p * 3 + 1) * DRT_BLOCK] = v.y; acc[(p * 3 + 2) * DRT_BLOCK] = v.z; }
     __device__ inline void new_path() { cnt[0] = 0; if (NC > 4) cnt[NC > 4 ? 1 : 0] = 0; zc = 0; }
 };
 
@@ -165,7 +171,8 @@ __device__ inline void add_emission(const SceneLds<R>& lds, const TangentLds<R>&
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const bool own = eid == (uint32_t)p;
-            const V3<R> a0 = mk<R>(tg.acc[p].x + (own ? gT.x : R(0)), tg.acc[p].y + (own ? gT.y : R(0)), tg.acc[p].z + (own ? gT.z : R(0)));
+            const V3<R> ap = tg.acc_get(p);
+            const V3<R> a0 = mk<R>(ap.x + (own ? gT.x : R(0)), ap.y + (own ? gT.y : R(0)), ap.z + (own ? gT.z : R(0)));
             if (p < NC) {
                 const uint32_t n = (tg.cnt[p >> 2] >> (8 * (p & 3))) & 0xFFu;
                 const R nf = (R)(int)n;
@@ -179,9 +186,9 @@ __device__ inline void add_emission(const SceneLds<R>& lds, const TangentLds<R>&
                     if (zb & 2u) dT.y = (one && (tg.zc & 0xFF00u) == 0x100u) ? T.y : R(0);
                     if (zb & 4u) dT.z = (one && (tg.zc & 0xFF0000u) == 0x10000u) ? T.z : R(0);
                 }
-                tg.acc[p] = mk<R>(fma_r(dT.x, gE.x, a0.x), fma_r(dT.y, gE.y, a0.y), fma_r(dT.z, gE.z, a0.z));
+                tg.acc_set(p, mk<R>(fma_r(dT.x, gE.x, a0.x), fma_r(dT.y, gE.y, a0.y), fma_r(dT.z, gE.z, a0.z)));
             } else
-                tg.acc[p] = a0;
+                tg.acc_set(p, a0);
         }
     }
 }
@@ -317,8 +324,9 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // bookkeeping, the camera code runs whenever some lane starts over, the light's emission is added when the lane's
 // path ends.  ~35 % more instructions per bounce, but roulette-terminated renders (the reference's defaults, -b 1
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
+// (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
 template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false>
-__global__ void __launch_bounds__(DRT_BLOCK)
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && !SPEC && NP <= 4 && !REGEN) ? 6 : 1)
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)
@@ -344,9 +352,11 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     const uint32_t s_end = s_begin + a.spr < a.Sb ? s_begin + a.spr : a.Sb;
 
     Tangents<R, NP, NC> tg;
+    __shared__ R s_acc[NP > 0 ? NP * 3 : 1][DRT_BLOCK];
+    tg.acc = &s_acc[0][threadIdx.x];
 #pragma unroll
-    for (int p = 0; p < (NP > 0 ? NP : 1); ++p)
-        tg.acc[p] = mk<R>(R(0), R(0), R(0));
+    for (int p = 0; p < NP; ++p)
+        tg.acc_set(p, mk<R>(R(0), R(0), R(0)));
     double fx = 0, fy = 0, fz = 0;                        // radiance sum of this lane's pixel over the range
     uint32_t n_seg = 0, n_capped = 0;                     // wave-uniform counters
 
@@ -496,10 +506,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         if (NP > 0 && gimg_part && have) {
             // gradient image (README.md:142-145): a lane IS a pixel, its gradient sum of one parameter over the samples of
             // this range is that pixel's share -- same layout as the radiance partials, same finishing kernels
-            V3<R> v = tg.acc[0];
-#pragma unroll
-            for (int p = 1; p < NP; ++p)
-                v = mk<R>(a.gimg_param == p ? tg.acc[p].x : v.x, a.gimg_param == p ? tg.acc[p].y : v.y, a.gimg_param == p ? tg.acc[p].z : v.z);
+            const V3<R> v = tg.acc_get(a.gimg_param > 0 && a.gimg_param < NP ? a.gimg_param : 0);
             double* f = gimg_part + ((size_t)range * 3) * a.Pb + lp;
             f[0] = (double)v.x; f[(size_t)a.Pb] = (double)v.y; f[(size_t)a.Pb * 2] = (double)v.z;
         }
@@ -513,8 +520,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         const int wv = threadIdx.x / DRT_WAVE;
 #pragma unroll
         for (int r = 0; r < NP * 3; ++r) {
-            const V3<R> v3 = tg.acc[r / 3];
-            double v = (double)(r % 3 == 0 ? v3.x : (r % 3 == 1 ? v3.y : v3.z));
+            double v = (double)tg.acc[r * DRT_BLOCK];
 #pragma unroll
             for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)
                 v += __shfl_down(v, o2);

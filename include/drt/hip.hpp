@@ -281,6 +281,7 @@ public:
     // host buffers of the (at most DRT_HIP_FRAMES_IN_FLIGHT) frames in flight: kept, so that a frame costs no 3 MB allocation
     std::vector<float> frame_pool[DRT_HIP_FRAMES_IN_FLIGHT];
     std::vector<double> grad_pool[DRT_HIP_FRAMES_IN_FLIGHT];
+    bool slot_in_flight[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // the slot's buffers belong to a frame that has not been collected
     unsigned submitted = 0;
 private:
     bool m_has_scene = false;
@@ -408,9 +409,17 @@ class Pending {
 public:
     Pending() = default;
     Pending(Pending&& o) noexcept { *this = std::move(o); }
+    // A frame that is dropped without get() -- an exception between submit and get, a handle that is overwritten -- is still
+    // waited for and its results discarded: its slot of the (process-wide, pooled) context would otherwise stay in flight for
+    // ever and every later render on that device would be refused.
+    ~Pending() { discard(); }
     Pending& operator=(Pending&& o) noexcept
     {
+        if (this == &o)
+            return *this;
+        discard();
         m_ctx = o.m_ctx; o.m_ctx = nullptr;            // (the source no longer owns a frame)
+        m_slot = o.m_slot;
         m_ticket = o.m_ticket; m_img = o.m_img; m_backward = o.m_backward;
         m_frame = o.m_frame; m_grads = o.m_grads; m_npix = o.m_npix;
         m_requires_grad = std::move(o.m_requires_grad); m_handles = std::move(o.m_handles);
@@ -427,7 +436,10 @@ public:
         drt_hip_stats st{};
         Context* ctx = m_ctx;
         m_ctx = nullptr;
-        ctx->check(drt_hip_wait(ctx->get(), m_ticket, &st), "drt_hip_wait");
+        std::lock_guard<std::mutex> lock(ctx->mutex());
+        const int rc = drt_hip_wait(ctx->get(), m_ticket, &st);
+        ctx->slot_in_flight[m_slot] = false;
+        ctx->check(rc, "drt_hip_wait");
         const std::size_t npix = m_npix;
         for (std::size_t i = 0; i < npix; ++i)
             for (int c = 0; c < 3; ++c)
@@ -450,10 +462,21 @@ public:
     }
 
 private:
+    void discard() noexcept
+    {
+        if (!m_ctx)
+            return;
+        Context* ctx = m_ctx;
+        m_ctx = nullptr;
+        std::lock_guard<std::mutex> lock(ctx->mutex());
+        (void)drt_hip_wait(ctx->get(), m_ticket, nullptr);      // (into the pool's buffers; nothing is accumulated)
+        ctx->slot_in_flight[m_slot] = false;
+    }
     template <typename U>
     friend Pending<U> submit(const Scene<U>&, const Camera<U>&, const Pathtracer<U>&, std::size_t, Vector<U, 3>*, const Options&,
                              const Vector<U, 3>*);
     Context* m_ctx = nullptr;
+    unsigned m_slot = 0;
     uint64_t m_ticket = 0;
     Vector<T, 3>* m_img = nullptr;
     bool m_backward = false;
@@ -486,7 +509,11 @@ inline Pending<T> submit(const Scene<T>& scene, const Camera<T>& cam, const Path
     f.m_requires_grad = flat.requires_grad;
     f.m_handles = flat.handles;
     Context& ctx = pooled_context(opt.devices);
-    const unsigned slot = ctx.submitted % DRT_HIP_FRAMES_IN_FLIGHT;   // (the library refuses a fifth frame in flight: its buffers are free again)
+    std::lock_guard<std::mutex> lock(ctx.mutex());
+    const unsigned slot = ctx.submitted % DRT_HIP_FRAMES_IN_FLIGHT;
+    // (before the slot's buffers are touched: a frame still in flight is written into them at its get())
+    if (ctx.slot_in_flight[slot])
+        throw std::runtime_error("drt::hip::submit: four frames are in flight on this device -- get() the oldest one first");
     if (ctx.frame_pool[slot].size() < npix * 3) ctx.frame_pool[slot].resize(npix * 3);
     if (ctx.grad_pool[slot].size() < flat.requires_grad.size() * 3) ctx.grad_pool[slot].resize(flat.requires_grad.size() * 3);
     f.m_frame = ctx.frame_pool[slot].data();
@@ -509,6 +536,8 @@ inline Pending<T> submit(const Scene<T>& scene, const Camera<T>& cam, const Path
                                    opt.backward ? f.m_grads : nullptr, &f.m_ticket),
               "drt_hip_render_async");
     ++ctx.submitted;
+    ctx.slot_in_flight[slot] = true;
+    f.m_slot = slot;
     f.m_ctx = &ctx;
     return f;
 }

@@ -5,5 +5,5 @@ set -eu
 N=$1; shift
 mkdir -p build
 hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude "$@" \
-      -o build/$N.so differentiable-renderer_amd/csrc/drt_hip.hip -lrccl
+      -o build/$N.so differentiable-renderer_amd/csrc/drt_hip.hip -lrccl -lhiprtc
 echo "build/$N.so"
