@@ -35,6 +35,7 @@ RENDER_TIMING = 0x8
 RENDER_F64 = 0x10
 RENDER_UNBIASED = 0x20
 RENDER_SERIAL = 0x100
+RENDER_UNFUSED = 0x200
 RENDER_ALLREDUCE = 0x40
 RENDER_ALLREDUCE_ASYNC = 0x80
 FRAMES_IN_FLIGHT = 4          # drt_hip_render_async: DRT_HIP_FRAMES_IN_FLIGHT

@@ -325,25 +325,20 @@ __device__ inline uint32_t chunk_slot(const BatchArgs& a, const uint32_t* __rest
     return off < cnt ? (w << a.region_shift) + off : 0xFFFFFFFFu;
 }
 
-// Scenes with a mesh: the analytic pass also decides which rays the BVH walk has to see at all -- those that reach the
-// box around all triangles before their analytic hit.  In a room with one object that is a quarter of the rays; the
-// others would only drag the walk's lanes through refills (measured: 13 of 64 lanes busy per node visit, 3 per leaf).
-// Every wave of this kernel appends its candidates (wave ballot + prefix rank, no atomics) to ONE dense list of its
-// own -- span [list * cand_cap, ...) of `cand`, length in cand_count[list] -- and the walk's waves pull whole lists
-// from a device-wide counter: dense lanes from the first node on, and no wave is stuck with a stream of hard rays.
 // the walk's pull counters live behind the n_lists list lengths, on a 128-byte boundary
 __device__ inline uint32_t* pull_counters(uint32_t* cand_count, uint32_t n_lists)
 {
     return cand_count + ((n_lists + DRT_PULL_STRIDE - 1) / DRT_PULL_STRIDE) * DRT_PULL_STRIDE;
 }
 
+// K2 as a kernel of its own: the textbook wavefront (DRT_RENDER_UNFUSED; analytic scenes -- the fused routes fold it into
+// K3, and in scenes with a mesh every ray is intersected with the analytic shapes by the launch that PRODUCES it, which
+// also builds the BVH walk's candidate lists: tail_emit below).  Persistent grid, DRT_K2_RAYS rays per lane in flight.
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R>::T* __restrict__ ray_a,
             const typename Q2<R>::T* __restrict__ ray_b, HitRec<R>* __restrict__ hit,
-            const uint32_t* __restrict__ counts_k, DevBvh<R> bvh, uint32_t* __restrict__ cand,
-            typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b,
-            uint32_t* __restrict__ cand_count, uint32_t cand_cap, unsigned long long* __restrict__ total)
+            const uint32_t* __restrict__ counts_k, unsigned long long* __restrict__ total)
 {
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
@@ -353,10 +348,7 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
     const int n_shapes = sc->n_shapes;
     constexpr int NR = DRT_K2_RAYS;
     const uint32_t gw = grid_wave();
-    uint32_t n_cand = 0;                                        // length of this wave's candidate list
     uint32_t n_rays = 0;                                        // rays this wave intersected (statistics: total[4])
-    if (cand && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)   // the walk's list counters (it runs after this kernel)
-        pull_counters(cand_count, n_waves)[threadIdx.x * DRT_PULL_STRIDE] = 0;
     for (uint32_t c = gw; c < n_chunks; c += NR * n_waves) {
         uint32_t slot[NR];
         R4 ra[NR];
@@ -375,39 +367,7 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
         for (int r = 0; r < NR; ++r)
             if (slot[r] != 0xFFFFFFFFu)
                 hit[slot[r]] = h[r];
-        if (cand) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const uint32_t cr = c + (uint32_t)r * n_waves;
-                if (cr >= n_chunks)
-                    continue;                                   // (wave-uniform)
-                bool reach = false;
-                if (slot[r] != 0xFFFFFFFFu) {
-                    const V3<R> o = mk<R>(ra[r].x, ra[r].y, ra[r].z), d = mk<R>(ra[r].w, rb[r].x, rb[r].y);
-                    const V3<R> inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
-                    R tn;
-                    reach = box_hit(mk<R>(bvh.lo[0], bvh.lo[1], bvh.lo[2]), mk<R>(bvh.hi[0], bvh.hi[1], bvh.hi[2]), o, inv_d, h[r].t, tn);
-                }
-                uint32_t n_reach;
-                const uint32_t rank = wave_rank(reach, n_reach);
-                if (reach) {
-                    // the candidate's record: everything the walk needs, dense and in list order -- its refill is one
-                    // coalesced round trip instead of a chain of gathers (slot -> ray, hit -> tie-break index)
-                    const size_t at = (size_t)gw * cand_cap + n_cand + rank;
-                    const uint32_t flat = h[r].prim >= 0 ? (uint32_t)sc->flat[h[r].prim] : 0xFFFFFFFFu;
-                    R4 ca, cb;
-                    ca.x = ra[r].x; ca.y = ra[r].y; ca.z = ra[r].z; ca.w = h[r].t;
-                    cb.x = ra[r].w; cb.y = rb[r].x; cb.z = rb[r].y; cb.w = pid_pack(R(0), flat);
-                    cand[at] = slot[r];
-                    cand_a[at] = ca;
-                    cand_b[at] = cb;
-                }
-                n_cand += n_reach;
-            }
-        }
     }
-    if (cand && lane == 0)
-        cand_count[gw] = n_cand;
     if (total && lane == 0 && n_rays)
         atomicAdd(total + 4, (unsigned long long)n_rays);       // (integer: order-independent)
 }

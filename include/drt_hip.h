@@ -153,6 +153,9 @@ typedef struct drt_camera_desc {
 #define DRT_RENDER_SERIAL     0x100u /* with DEVICE_OUT: this frame's path kernel does not overlap its neighbours' -- everything of the frame runs
                                        on the context's stream, in order.  What an optimisation loop gets, whose frame i + 1 needs the
                                        gradients of frame i (README.md:88-101); bench.py's `serial_frame`. */
+#define DRT_RENDER_UNFUSED    0x200u /* scenes of analytic shapes: the textbook wavefront -- K1 raygen, then per bounce K2 (k_intersect) and K3
+                                       (k_shade) as launches of their own over the ray queues in HBM -- instead of the fused routes
+                                       (measurement / cross-check: the paths of bounces_per_launch >= 1, values equal to f32 rounding) */
 #define DRT_RENDER_UNBIASED   0x20u /* with BACKWARD: the reference's unbiased integration operator
                                        (integrate.hpp:39-52, README.md:104-136): backward draws a
                                        FRESH direction at every vertex and traces a new suffix path

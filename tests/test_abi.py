@@ -63,6 +63,25 @@ def test_embedded_headers_compile_under_hiprtc(pkg):
         assert size > 1000, log.value.decode()
 
 
+def test_environment_variables_are_read_in_one_place_and_documented():
+    """Every DRT_HIP_* variable the library reads is in csrc/drt_tuning.h (no getenv elsewhere) and in the table of
+    INTEGRATION.md section 2 -- and nothing documented there is stale."""
+    csrc = os.path.join(ROOT, "differentiable-renderer_amd", "csrc")
+    read = set()
+    for f in os.listdir(csrc):
+        if not f.endswith((".h", ".hip")):
+            continue
+        text = open(os.path.join(csrc, f), errors="ignore").read()
+        if f != "drt_tuning.h":
+            assert "getenv(" not in text, f"{f} reads the environment itself"
+        else:
+            read |= set(re.findall(r'"(DRT_HIP_[A-Z0-9_]+)"', text))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("### Environment variables"):doc.index("### What travels where")]
+    documented = set(re.findall(r"^\| `(DRT_HIP_[A-Z0-9_]+)` \|", table, flags=re.M))
+    assert read == documented, (sorted(read - documented), sorted(documented - read))
+
+
 def test_no_device_means_an_error_not_a_fallback(pkg):
     """On a box without a GPU the product path must refuse to run."""
     lib = pkg.load_library()

@@ -561,10 +561,28 @@ def test_results_do_not_depend_on_bounces_per_launch(pkg, hip, scene_name, b, p,
         assert got[2]["segments"] == ref[2]["segments"]
         np.testing.assert_array_equal(got[0], ref[0])
         np.testing.assert_array_equal(got[1], ref[1])
-        overridden = os.environ.get("DRT_HIP_SHADE_BOUNCES") or os.environ.get("DRT_HIP_FUSE") == "0"   # debug knobs win
+        overridden = os.environ.get("DRT_HIP_SHADE_BOUNCES")   # (the debug knob wins)
         if nb == 8 and not unbiased and not overridden:
             assert got[2]["kernels"]["shade"]["launches"] < ref[2]["kernels"]["shade"]["launches"]
             assert got[2]["queue_rays_read"] < ref[2]["queue_rays_read"]
+
+
+@pytest.mark.parametrize("scene_name,unbiased", [("cornell", False), ("cornell_specular", False), ("cornell", True)])
+def test_the_textbook_wavefront_agrees_with_the_fused_one(pkg, hip, scene_name, unbiased):
+    """DRT_RENDER_UNFUSED: K1, then per bounce K2 (k_intersect) and K3 (k_shade) as launches of their own -- the
+    pipeline as SURVEY section 8 lists it -- against the fused one-launch-per-bounce route: the same paths (segment
+    count), values equal to f32 rounding (K2's closest-hit loop and the fused launch's packed test differ in the last bit)."""
+    import dataclasses
+    hip.upload_scene(pkg.scene_by_name(scene_name))
+    cam = pkg.cornell_camera(96, 80)
+    rp = pkg.RenderParams(spp=5, min_bounces=6, absorb=1.0, seed=21, bounces_per_launch=1)
+    ref = hip.render(cam, rp, backward=True, unbiased=unbiased)
+    got = hip.render(cam, dataclasses.replace(rp, flags=rp.flags | pkg.RENDER_UNFUSED), backward=True, unbiased=unbiased)
+    assert ref[2]["kernels"]["intersect"]["launches"] == 0 and got[2]["kernels"]["intersect"]["launches"] >= 6
+    assert got[2]["kernels"]["raygen"]["launches"] == 1
+    assert got[2]["segments"] == ref[2]["segments"]
+    np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=1e-6 * np.abs(ref[1]).max())
 
 
 @pytest.mark.parametrize("f64", [False, True])

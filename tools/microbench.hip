@@ -84,7 +84,7 @@ int main(int argc, char** argv)
             std::vector<uint32_t> hc(ba.n_regions, ba.region_size);
             uint32_t* dc; CK(hipMalloc(&dc, hc.size() * 4)); CK(hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
             for (int grid : {1024, 2048, 4096}) {
-                float t = time_ms([&] { hipLaunchKernelGGL(k_intersect<float>, dim3(grid), dim3(256), 0, 0, ba, ds, a, b, (HitRec<float>*)h, dc, DevBvh<float>{}, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u); }, 20);
+                float t = time_ms([&] { hipLaunchKernelGGL(k_intersect<float>, dim3(grid), dim3(256), 0, 0, ba, ds, a, b, (HitRec<float>*)h, dc, (unsigned long long*)nullptr); }, 20);
                 printf("k_intersect shapes %d region %4u grid %5d: %8.3f ms  %7.1f GB/s  %6.1f Gray/s\n", ns, ba.region_size, grid, t, N * 32 / t * 1e-6, N / t * 1e-6);
             }
             CK(hipFree(dc));
