@@ -581,7 +581,12 @@ def test_the_textbook_wavefront_agrees_with_the_fused_one(pkg, hip, scene_name, 
     assert ref[2]["kernels"]["intersect"]["launches"] == 0 and got[2]["kernels"]["intersect"]["launches"] >= 6
     assert got[2]["kernels"]["raygen"]["launches"] == 1
     assert got[2]["segments"] == ref[2]["segments"]
-    np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-7)
+    if "specular" in scene_name:
+        # (glossy bounces amplify the last-bit differences of the two closest-hit routines: the stated f32 pixel bound)
+        bad = np.abs(got[0].astype(np.float64) - ref[0]).max(-1) > PIXEL_TOL * float(np.abs(ref[0]).max())
+        assert bad.sum() <= flip_budget(96 * 80 * 5)
+    else:
+        np.testing.assert_allclose(got[0], ref[0], rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=1e-6 * np.abs(ref[1]).max())
 
 
