@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6200.0        # measured float4 copy on the pool's boxes (profiles/r01_microbench_stream_roofs.txt; guide: 6.29)
 # vector-instruction issue: a wave64 VALU op takes 2 cycles of its SIMD; 256 CUs x 4 SIMDs at 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0     # 1228.8 G wave-instructions / s
+VALU_MEASURED_GINST = 900.0               # what v_fma_f32 alone sustains on the pool's boxes (profiles/r04_microbench_valu_issue.txt)
 
 # BASELINE.json configs -> workload per GPU (configs 4, 5: the 1/8 share of one of the 8 GPUs they are quoted on)
 CONFIGS = {
@@ -379,6 +380,7 @@ def main():
         ginst = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3) * 1e-9
         valu_view = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
                      "frac": round(ginst / VALU_PEAK_GINST, 4),
+                     "frac_of_measured_issue_roof": round(ginst / VALU_MEASURED_GINST, 4),
                      "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
                      "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
                      "note": "SQ_INSTS_VALU per launch (profiles/traffic.json, rocprofv3 --pmc on this workload) / live launch "
@@ -409,7 +411,8 @@ def main():
         # (the grids of two consecutive frames overlap: a launch's own begin-to-end time is longer than a step there)
         g2 = pmc["valu_insts_per_launch"] * dk["launches_per_step"] / (ms_per_step * 1e-3) * 1e-9
         roofline["pipelined"] = {"achieved": round(g2, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
-                                 "frac": round(g2 / VALU_PEAK_GINST, 4), "ms_per_step": round(ms_per_step, 4)}
+                                 "frac": round(g2 / VALU_PEAK_GINST, 4),
+                                 "frac_of_measured_issue_roof": round(g2 / VALU_MEASURED_GINST, 4), "ms_per_step": round(ms_per_step, 4)}
     if dominant == "intersect_mesh" and pmc.get("lane_stats"):
         roofline["walk_lanes"] = pmc["lane_stats"]      # tools/bvh_stats.py on the same scene (a -DDRT_BVH_STATS build)
 

@@ -60,14 +60,15 @@ def check_f32(img, grads, segments, g_img, g_grads, g_segments, heavy_tailed=Fal
         assert grad_rel_err(grads, g_grads) <= (GRAD_TOL_HEAVY if heavy_tailed else GRAD_TOL)
 
 
-def check_f32_heavy_tailed(hip, cam, rp, adjoint, n_params, ref_img, ref_grads, ref_segments):
+def check_f32_heavy_tailed(hip, cam, rp, adjoint, n_params, ref_img, ref_grads, ref_segments, ref_grad_image):
     """The f32 mode on the RANDOM scenes, where a single path can weigh 1e5 times the average (exponent-80 lobes, roulette
     boosts): a path whose discrete hit decision flips under f32 rounding then moves the frame's mean or a gradient by far
     more than any rounding bound (measured: one silhouette-edge path of a 15,360-path frame, 8.3e-4 of the largest gradient
     component; one of a 61,440-path frame, 14 % of a channel's mean).  So the check is flip-aware: pixels outside the f32
     pixel bound are counted (at most 0.5 % of the frame) and SET ASIDE -- the mean is taken over the others, and the
-    gradient is compared after removing what the set-aside pixels contribute, which the device's per-pixel gradient images
-    give for both precisions (the f64 mode of the same call is checked against the oracle to 1e-9 by the caller)."""
+    gradient is compared after removing what the set-aside pixels contribute: in f32 as the device's per-pixel gradient
+    image of each parameter gives it, on the reference side as the CHECKER's per-pixel gradient image gives it
+    (ref_grad_image(p): nothing the device produced excuses the device)."""
     img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint)
     scale = float(np.abs(ref_img).max())
     bad = np.abs(img.astype(np.float64) - ref_img).max(-1) > PIXEL_TOL * scale
@@ -80,8 +81,7 @@ def check_f32_heavy_tailed(hip, cam, rp, adjoint, n_params, ref_img, ref_grads, 
     if bad.any():
         for p in range(n_params):
             _, gi32, _ = hip.render_gradient_image(cam, rp, p, adjoint=adjoint)
-            _, gi64, _ = hip.render_gradient_image(cam, rp, p, adjoint=adjoint, f64=True)
-            corr[p] = (gi32.astype(np.float64) - gi64)[bad].sum(0) * rp.spp
+            corr[p] = (gi32.astype(np.float64) - ref_grad_image(p))[bad].sum(0) * rp.spp
     assert grad_rel_err(grads - corr, ref_grads) <= GRAD_TOL_HEAVY, (int(bad.sum()), grad_rel_err(grads, ref_grads))
     return int(bad.sum())
 
@@ -211,7 +211,8 @@ def test_matches_oracle_on_random_scenes(pkg, hip, oracle):
         assert stats["segments"] == ref["stats"]["segments"]
         assert grad_rel_err(grads, ref["grads"]) < 1e-9
         np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
-        check_f32_heavy_tailed(hip, cam, rp, adj, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"])
+        check_f32_heavy_tailed(hip, cam, rp, adj, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"],
+                               lambda p: oracle.render(scene, cam, rp, backward=True, adjoint=adj, grad_image_param=p)["grad_image"])
 
 
 def test_matches_the_reference_binary_live(pkg, hip, oracle):
@@ -234,7 +235,8 @@ def test_matches_the_reference_binary_live(pkg, hip, oracle):
         assert grad_rel_err(grads, ref["grads"]) < 1e-9
         np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
         if not unbiased:
-            check_f32_heavy_tailed(hip, cam, rp, adj, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"])
+            check_f32_heavy_tailed(hip, cam, rp, adj, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"],
+                                   lambda p: oracle.render(scene, cam, rp, backward=True, adjoint=adj, grad_image_param=p)["grad_image"])
 
 
 def test_edge_cases(pkg, hip, oracle):
@@ -678,7 +680,8 @@ def test_path_kernel_corner_cases(pkg, hip, oracle):
     assert bst["kernels"]["path"]["launches"] == 1 and bst["kernels"]["backward"]["launches"] == 0
     assert grad_rel_err(g, rref["grads"]) < 1e-9
     np.testing.assert_array_equal(both, fwd)
-    check_f32_heavy_tailed(hip, rcam, rrp, None, rscene.n_params, rref["image"], rref["grads"], rref["stats"]["segments"])
+    check_f32_heavy_tailed(hip, rcam, rrp, None, rscene.n_params, rref["image"], rref["grads"], rref["stats"]["segments"],
+                           lambda p: oracle.render(rscene, rcam, rrp, backward=True, grad_image_param=p)["grad_image"])
     # more than 8 parameters: forward-only still goes through k_path (no tangents), backward through the tape
     bscene = pkg.random_scene(3, specular=False, n_lights=6)
     assert bscene.n_params > 8
@@ -706,7 +709,8 @@ def test_path_kernel_scene_with_many_shapes(pkg, hip, oracle):
         np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
         img32, g32, st32 = hip.render(cam, rp, backward=True)
         assert st32["kernels"]["path"]["launches"] == 1
-        check_f32_heavy_tailed(hip, cam, rp, None, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"])
+        check_f32_heavy_tailed(hip, cam, rp, None, scene.n_params, ref["image"], ref["grads"], ref["stats"]["segments"],
+                               lambda p: oracle.render(scene, cam, rp, backward=True, grad_image_param=p)["grad_image"])
 
 
 def test_eight_parameters_every_walls_albedo(pkg, hip, oracle):
