@@ -36,6 +36,7 @@ RENDER_F64 = 0x10
 RENDER_UNBIASED = 0x20
 RENDER_SERIAL = 0x100
 RENDER_UNFUSED = 0x200
+RENDER_LOSS_L2 = 0x400
 RENDER_ALLREDUCE = 0x40
 RENDER_ALLREDUCE_ASYNC = 0x80
 FRAMES_IN_FLIGHT = 4          # drt_hip_render_async: DRT_HIP_FRAMES_IN_FLIGHT
@@ -572,8 +573,10 @@ class HipRenderer:
 
     def render(self, cam: Camera, rp: RenderParams, backward: bool = False,
                adjoint: Optional[np.ndarray] = None, timing: bool = False, f64: bool = False,
-               unbiased: bool = False):
-        """Host-buffer render. -> (image float32 [H,W,3], grads float64 [P,3] or None, stats dict)."""
+               unbiased: bool = False, loss_l2: bool = False):
+        """Host-buffer render. -> (image float32 [H,W,3], grads float64 [P,3] or None, stats dict).
+        loss_l2: `adjoint` is a TARGET image and every sample is back-propagated through its own squared-error loss
+        (DRT_RENDER_LOSS_L2; README.md:93-98 of the reference)."""
         assert self.scene is not None
         flags = rp.flags & ~(RENDER_DEVICE_OUT | RENDER_SYNC)
         if backward:
@@ -584,6 +587,8 @@ class HipRenderer:
             flags |= RENDER_F64
         if unbiased:
             flags |= RENDER_UNBIASED
+        if loss_l2:
+            flags |= RENDER_LOSS_L2
         d = rp.to_desc()
         d.flags = flags
         img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)

@@ -1065,13 +1065,22 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
     return Ln;          // L_0: the radiance of the path
 }
 
+// the seed a path is back-propagated with: (1, 1, 1) (render.cpp:80), the caller's per-pixel adjoint, or -- DRT_RENDER_LOSS_L2,
+// `radiance` given -- the derivative of the per-sample squared error against the target image, 2 (L_path - target_pixel)
+// (README.md:93-98: loss = loss_func(radiance); loss.backward())
 template <typename R>
-__device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ adjoint, uint32_t i)
+__device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ adjoint, uint32_t i,
+                                  const typename Q4<R>::T* __restrict__ radiance = nullptr)
 {
     if (!adjoint)
         return mk<R>(R(1), R(1), R(1));                       // render.cpp:80
     const uint32_t gp = global_pixel(a, a.p0 + i % a.Pb);
-    return mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1], (R)adjoint[(size_t)gp * 3 + 2]);
+    const V3<R> t = mk<R>((R)adjoint[(size_t)gp * 3], (R)adjoint[(size_t)gp * 3 + 1], (R)adjoint[(size_t)gp * 3 + 2]);
+    if (radiance) {
+        const typename Q4<R>::T L = radiance[i];
+        return mk<R>(R(2) * (L.x - t.x), R(2) * (L.y - t.y), R(2) * (L.z - t.z));
+    }
+    return t;
 }
 
 // next region >= w this wave shades; CAM: depth 0, region w holds its share of the batch's paths
@@ -1505,8 +1514,10 @@ __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : 1
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
            const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad,
-           typename Q4<R>::T* __restrict__ lacc, int n_rows, int row_stride)
+           typename Q4<R>::T* __restrict__ lacc, int n_rows, int row_stride,
+           const typename Q4<R>::T* radiance_in = nullptr)
 {
+    // (radiance_in: DRT_RENDER_LOSS_L2 -- the radiance of every path, written by k_radiance before this launch; may alias lacc)
     typedef typename Q4<R>::T R4;
     constexpr bool SMALL = NP > 0;
     __shared__ SceneLds<R> lds;
@@ -1533,7 +1544,7 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                 first[j] = tape[(size_t)j * N + i];
         V3<R> L0 = mk<R>(R(0), R(0), R(0));
         if (K > 0)
-            L0 = backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i), inv_p_rr, ga, acc, grad, first);
+            L0 = backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i, radiance_in), inv_p_rr, ga, acc, grad, first);
         if (lacc) {
             R4 o;
             o.x = L0.x; o.y = L0.y; o.z = L0.z; o.w = R(0);

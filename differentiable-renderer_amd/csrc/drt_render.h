@@ -55,6 +55,9 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     const bool f64 = (rp->flags & DRT_RENDER_F64) != 0;
     if (j.backward && !out_param_grad && gimg_param < 0 && !ctx->is_member)
         return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_BACKWARD needs out_param_grad");
+    if ((rp->flags & DRT_RENDER_LOSS_L2) && j.backward &&
+        (!adjoint_rgb || (rp->flags & DRT_RENDER_UNBIASED) || gimg_param >= 0))
+        return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_LOSS_L2 needs a target image in adjoint_rgb, the biased operator and summed gradients");
     if ((rp->flags & (DRT_RENDER_ALLREDUCE | DRT_RENDER_ALLREDUCE_ASYNC)) && j.backward && !ctx->comm && !ctx->is_member)
         return fail(ctx, DRT_ERR_INVALID, "render: DRT_RENDER_ALLREDUCE on a context without a communicator (drt_hip_comm_init_rank)");
 

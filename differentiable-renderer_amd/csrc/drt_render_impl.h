@@ -149,6 +149,7 @@ struct Shard {
     int spp;
     uint64_t total_paths;
     bool unbiased;                  // the reference's unbiased integration operator (integrate.hpp:39-52)
+    bool loss_l2;                   // DRT_RENDER_LOSS_L2: every sample seeded with 2 (L_s - target_pixel), d_adjoint is the target
     bool can_fuse;                  // K2 folded into K3: analytic scenes, unless DRT_RENDER_UNFUSED asks for the textbook pipeline
     bool use_path, path_regen;      // the whole path in one launch (k_path); its regenerating form
     bool shade_tail;                // mesh scenes: the launch that produces a ray also intersects it with the analytic shapes and
@@ -212,6 +213,7 @@ void shard_plan(Shard<R>& s)
     s.spp = rp->spp;
     s.total_paths = (uint64_t)s.n_local_pixels * (uint64_t)s.spp;
     s.unbiased = s.backward && (rp->flags & DRT_RENDER_UNBIASED) != 0 && s.gimg_param < 0;
+    s.loss_l2 = s.backward && (rp->flags & DRT_RENDER_LOSS_L2) != 0;
     // K2 folded into K3 wherever nothing else consumes the hit records: never with a mesh (the BVH walk is its own kernel)
     s.can_fuse = !(rp->flags & DRT_RENDER_UNFUSED) && !ctx->has_mesh;
     // ---- k_path (drt_path.h): the whole path in one launch, in registers.  Taken when the scene is analytic and at most 8
@@ -221,7 +223,8 @@ void shard_plan(Shard<R>& s)
     // its next sample at once) otherwise: roulette-terminated paths under the default cap of 64, the reference's own
     // defaults (-b 1 -p 0.5).
     s.use_path = s.can_fuse && ctx->prog_ok && D > 0 && (!(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) &&
-                 rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path < 0;
+                 rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path < 0 &&
+                 !s.loss_l2;       // (the per-sample seed needs the path's radiance before its gradients: the tape route, two walks)
     s.path_regen = tuning().path_regen > 0;
     if (s.unbiased)
         s.path_regen = false;                  // (k_path_unbiased walks its samples in lockstep)
@@ -830,9 +833,14 @@ int queue_batch(Shard<R>& s)
     } else if (s.unbiased && D > 0) {
         if ((rc = adjoint_rounds<R>(s)) != DRT_OK) return rc;
     } else if (s.backward && D > 0) {
+        // DRT_RENDER_LOSS_L2: the seed of a path is 2 (L_path - target): the radiance walk first, then the gradient walk
+        if (s.loss_l2)
+            DRT_TIMED(s, DRT_K_BACKWARD,
+                      hipLaunchKernelGGL(k_radiance<R>, dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, s.d_scene, s.d_params, s.tape, s.nv, s.lacc));
 #define DRT_LAUNCH_BWD(NP)                                                                                       \
     hipLaunchKernelGGL((k_backward<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, s.d_scene, s.d_params, \
-                       s.tape, s.nv, s.d_adjoint, s.gpart, s.grad, s.film ? s.lacc : (R4*)nullptr, s.g_rows, s.g_stride)
+                       s.tape, s.nv, s.d_adjoint, s.gpart, s.grad, (s.film && !s.loss_l2) ? s.lacc : (R4*)nullptr, s.g_rows, \
+                       s.g_stride, s.loss_l2 ? (const R4*)s.lacc : (const R4*)nullptr)
         if (ctx->n_params <= 4) DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_BWD(4));
         else if (ctx->n_params <= 8) DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_BWD(8));
         else DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_BWD(0));

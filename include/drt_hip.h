@@ -153,6 +153,13 @@ typedef struct drt_camera_desc {
 #define DRT_RENDER_SERIAL     0x100u /* with DEVICE_OUT: this frame's path kernel does not overlap its neighbours' -- everything of the frame runs
                                        on the context's stream, in order.  What an optimisation loop gets, whose frame i + 1 needs the
                                        gradients of frame i (README.md:88-101); bench.py's `serial_frame`. */
+#define DRT_RENDER_LOSS_L2    0x400u /* with BACKWARD: a loss that is NOT linear in the radiance, per SAMPLE -- the reference's loop
+                                       `loss = loss_func(radiance); loss.backward()` (README.md:93-98) with loss_func = squared error:
+                                       adjoint_rgb is read as a TARGET image (required), and every camera sample s of pixel p is
+                                       back-propagated with the seed d|L_s - target_p|^2 / dL_s = 2 (L_s - target_p) instead of a
+                                       per-pixel constant.  out_param_grad = d/d params of the sum over all samples of |L_s - target|^2.
+                                       (The per-pixel adjoint_rgb of the default mode is exact for losses on the pixel MEAN.)
+                                       Biased operator, summed gradients (not with DRT_RENDER_UNBIASED or the gradient image). */
 #define DRT_RENDER_UNFUSED    0x200u /* scenes of analytic shapes: the textbook wavefront -- K1 raygen, then per bounce K2 (k_intersect) and K3
                                        (k_shade) as launches of their own over the ray queues in HBM -- instead of the fused routes
                                        (measurement / cross-check: the paths of bounces_per_launch >= 1, values equal to f32 rounding) */

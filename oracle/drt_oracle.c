@@ -512,10 +512,13 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                 v3 L0;
                 int nv = walk(&w, eye, dir, 0, vtx, &L0);
                 pixel = v3_add(pixel, v3_div(L0, 1.0)); /* render.cpp:78, pdf = 1 */
-                if (want_grad) {
+                const int loss_l2 = (oracle_flags & DRT_ORACLE_LOSS_L2) != 0 && adjoint_rgb && !unbiased;
+                for (int rep = 0; want_grad && rep < (loss_l2 ? 2 : 1); ++rep) {
                     v3 g = v3_make(1, 1, 1); /* render.cpp:80 */
                     if (adjoint_rgb)
                         g = v3_make(adjoint_rgb[pix * 3], adjoint_rgb[pix * 3 + 1], adjoint_rgb[pix * 3 + 2]);
+                    if (loss_l2)      /* diff = radiance - target (SubOp), handed to radiance once per operand of diff * diff */
+                        g = v3_mul(v3_sub(L0, g), v3_make(1, 1, 1));
                     if (!unbiased) {
                         /* biased: the forward samples are reused; vector.hpp:420-484 from the root */
                         for (int k = 0; k < nv; ++k) {

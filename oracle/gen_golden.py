@@ -40,7 +40,10 @@ def run(case):
     if case.get("adjoint_seed") is not None:
         adjoint = np.random.RandomState(case["adjoint_seed"]).uniform(
             -1, 2, (case["height"], case["width"], 3)).astype(np.float32)
-    r = O.render_reference(scene, cam, rp, backward=True, adjoint=adjoint,
+    if case.get("target_seed") is not None:        # per-sample squared-error loss against this target image (loss_l2)
+        adjoint = np.random.RandomState(case["target_seed"]).uniform(
+            0, 0.6, (case["height"], case["width"], 3)).astype(np.float32)
+    r = O.render_reference(scene, cam, rp, backward=True, adjoint=adjoint, loss_l2=bool(case.get("loss_l2")),
                            rng_mode=case.get("rng_mode", O.RNG_KEYED),
                            dump_paths=case.get("dump_paths", 0),
                            grad_image_param=case.get("grad_image_param", -1),
@@ -123,6 +126,16 @@ SMALL = [
          absorb=0.4, seed=19, unbiased=True),
     dict(name="g11_mesh40x40_48x48x4_d5", scene="mesh40x40", width=48, height=48, spp=4, min_bounces=5,
          absorb=1.0, seed=9),
+    # a per-SAMPLE loss that is not linear in the radiance (README.md:93-98: loss = loss_func(radiance); loss.backward()):
+    # squared error against a target image, through the reference's own autograd (`loss l2` of the harness)
+    dict(name="l1_loss_l2_cornell_48x32x6_d5", scene="cornell", width=48, height=32, spp=6, min_bounces=5,
+         absorb=1.0, seed=14, loss_l2=True, target_seed=3),
+    dict(name="l2_loss_l2_emissive_wall_40x30x5_rr", scene="cornell_emissive_wall", width=40, height=30, spp=5,
+         min_bounces=2, absorb=0.3, seed=15, loss_l2=True, target_seed=4),
+    dict(name="l3_loss_l2_random3_36x28x5", scene="random3", width=36, height=28, spp=5, min_bounces=2,
+         absorb=0.25, seed=16, loss_l2=True, target_seed=5, eye=(0.2, -0.3, 0.0), at=(0.0, 0.1, 1.0)),
+    dict(name="l4_loss_l2_mesh10x12_28x24x4", scene="mesh10x12", width=28, height=24, spp=4, min_bounces=3,
+         absorb=0.3, seed=17, loss_l2=True, target_seed=6),
 ]
 BIG = [
     dict(name="c1_cornell_256x256x8_d4", scene="cornell", width=256, height=256, spp=8,

@@ -25,6 +25,7 @@ RNG_KEYED, RNG_LIBC = 0, 1
 FAITHFUL_CONTINUATION = 0x1
 UNBIASED = 0x2          # integrate(..., unbiased=true): backward re-samples at every vertex
 ZERO_DIR_MISS = 0x4     # zero-length rays never hit (see ref_harness.cpp)
+LOSS_L2 = 0x8           # per-sample squared-error loss against a target image (README.md:93-98)
 
 
 def load_pkg():
@@ -77,7 +78,7 @@ def lib() -> C.CDLL:
 
 def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray] = None,
            rng_mode: int = RNG_KEYED, faithful: bool = False, dump_paths: int = 0,
-           grad_image_param: int = -1, unbiased: bool = False, zero_dir_miss: bool = False):
+           grad_image_param: int = -1, unbiased: bool = False, zero_dir_miss: bool = False, loss_l2: bool = False):
     """-> dict(image f64 [H,W,3], grads f64 [P,3] | None, stats dict, vertices f64 [n,16] | None,
     grad_image f64 [H,W,3] | None)"""
     sd, keep = scene.to_desc()
@@ -103,7 +104,7 @@ def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray]
         lib().drt_oracle_set_gradient_image(grad_image_param, gimg.ctypes.data_as(C.c_void_p))
     rc = lib().drt_oracle_render(C.byref(sd), C.byref(cd), C.byref(rd), rng_mode,
                                  (FAITHFUL_CONTINUATION if faithful else 0) | (UNBIASED if unbiased else 0)
-                                 | (ZERO_DIR_MISS if zero_dir_miss else 0), adj_ptr,
+                                 | (ZERO_DIR_MISS if zero_dir_miss else 0) | (LOSS_L2 if loss_l2 else 0), adj_ptr,
                                  img.ctypes.data_as(C.c_void_p),
                                  grads.ctypes.data_as(C.c_void_p) if backward else None,
                                  C.byref(st),
@@ -130,7 +131,7 @@ def have_reference() -> bool:
 
 def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, dump_paths: int,
                      adjoint_file: str = "none", grad_image_param: int = -1, tracer_mode: int = 0,
-                     zero_dir_miss: bool = False):
+                     zero_dir_miss: bool = False, loss: str = "none"):
     with open(path, "w") as f:
         f.write(f"params {len(scene.params)}\n")
         for rgb, rg in zip(scene.params, scene.requires_grad):
@@ -158,11 +159,12 @@ def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, d
         f.write(f"adjoint {adjoint_file}\n")
         f.write(f"gradimage {grad_image_param}\n")
         f.write(f"mode {tracer_mode} {int(zero_dir_miss)}\n")
+        f.write(f"loss {loss}\n")
 
 
 def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray] = None,
                      rng_mode: int = RNG_KEYED, dump_paths: int = 0, grad_image_param: int = -1,
-                     tracer_mode: int = 0, zero_dir_miss: bool = False):
+                     tracer_mode: int = 0, zero_dir_miss: bool = False, loss_l2: bool = False):
     """tracer_mode 0 = drt::Pathtracer, 1 = the harness tracer (biased), 2 = the harness tracer with the
     reference's unbiased integration operator.
     Run the UNMODIFIED reference headers through oracle/_ref/ref_harness. Same return shape as
@@ -177,7 +179,7 @@ def render_reference(scene, cam, rp, backward: bool = False, adjoint: Optional[n
             np.ascontiguousarray(adjoint, dtype=np.float32).tofile(adj_file)
         sf = os.path.join(td, "scene.txt")
         write_scene_file(sf, scene, cam, rp, rng_mode, backward, dump_paths, adj_file, grad_image_param,
-                         tracer_mode, zero_dir_miss)
+                         tracer_mode, zero_dir_miss, "l2" if loss_l2 else "none")
         prefix = os.path.join(td, "out")
         subprocess.run([REF_HARNESS, sf, prefix], check=True, stderr=subprocess.DEVNULL)
         meta = json.load(open(prefix + ".json"))

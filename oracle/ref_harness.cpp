@@ -25,6 +25,9 @@
 //   gradimage <param|-1>  per-pixel gradient image of one parameter -> <prefix>.gimg.f64
 //   mode <tracer 0|1|2> <zero_dir_miss 0|1>   tracer 0 = drt::Pathtracer, 1 = HarnessTracer biased,
 //                         2 = HarnessTracer unbiased (integrate(..., true), integrate.hpp:39-52)
+//   loss <none|l2>        l2: the adjoint file is a TARGET image and every sample is back-propagated through a loss of its own,
+//                         the loop of the reference's README.md:93-98 with loss_func = squared error:
+//                         `auto diff = radiance - target; auto loss = diff * diff; loss.backward(Vec3(1));`
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -295,6 +298,7 @@ int main(int argc, char** argv)
     V3 eye(0.), fwd(0.), right(0.), up(0.);
     std::string adjoint_file = "none";
     int gimg_param = -1, tracer_mode = 0, zero_dir_miss = 0;
+    std::string loss_kind = "none";
 
     while (in >> tok) {
         if (tok == "params") {
@@ -380,6 +384,8 @@ int main(int argc, char** argv)
             in >> gimg_param;
         } else if (tok == "mode") {
             in >> tracer_mode >> zero_dir_miss;
+        } else if (tok == "loss") {
+            in >> loss_kind;
         } else {
             die("unknown token in scene file");
         }
@@ -435,7 +441,14 @@ int main(int argc, char** argv)
                 P3 radiance = tracer_mode == 0 ? tracer.trace(scene, cam.eye(), dir)
                                                : htracer.trace(scene, cam.eye(), dir);
                 pixel += radiance.detach() / pdf;
-                if (backward) {
+                if (backward && loss_kind == "l2") {
+                    if (adjoint.empty())
+                        die("loss l2 needs a target image (adjoint file)");
+                    P3 target(V3{adjoint[pix*3], adjoint[pix*3+1], adjoint[pix*3+2]}, false);
+                    P3 diff = radiance - target;
+                    P3 loss = diff * diff;
+                    loss.backward(V3(1.));
+                } else if (backward) {
                     V3 g(1.);
                     if (!adjoint.empty())
                         g = V3{adjoint[pix*3], adjoint[pix*3+1], adjoint[pix*3+2]};

@@ -48,7 +48,14 @@ def case_inputs(pkg, case):
     if case.get("adjoint_seed") is not None:
         adjoint = np.random.RandomState(case["adjoint_seed"]).uniform(
             -1, 2, (case["height"], case["width"], 3)).astype(np.float32)
+    if case.get("target_seed") is not None:        # the target image of a per-sample squared-error loss (loss_l2)
+        adjoint = np.random.RandomState(case["target_seed"]).uniform(
+            0, 0.6, (case["height"], case["width"], 3)).astype(np.float32)
     return scene, cam, rp, adjoint
+
+
+LOSS_GOLDENS = ["l1_loss_l2_cornell_48x32x6_d5", "l2_loss_l2_emissive_wall_40x30x5_rr", "l3_loss_l2_random3_36x28x5",
+                "l4_loss_l2_mesh10x12_28x24x4"]
 
 
 SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_64x64x8_rr",

@@ -297,6 +297,64 @@ def test_device_frames_overlap_and_stay_in_order(pkg):
         hip.close()
 
 
+def test_every_user_of_the_partial_sum_buffers_is_ordered(pkg):
+    """k_path's partial sums come in two sets ("lanes"); overlapped frames write theirs from streams of their own.  Sequences
+    the C ABI allows and round 3 left unordered (the advisor's findings): (1) a gradient image rendered with device pointers
+    and no wait -- lane 0 on the context's stream -- followed at once by frames that do not wait; (2) drt_hip_render_async
+    straight after such frames; (3) DRT_RENDER_SERIAL frames between overlapping ones.  Frames large enough to still be
+    running when the next call is made; every result must equal the synchronous call's bit for bit."""
+    import ctypes as C
+    import dataclasses
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(384, 256)
+    r = pkg.HipRenderer(0)
+    hip = pkg.HipRenderer(0)
+    try:
+        r.upload_scene(scene)
+        hip.upload_scene(scene)
+        rps = [pkg.RenderParams(spp=24, min_bounces=6, absorb=1.0, seed=s) for s in range(11, 17)]
+        ref = [hip.render(cam, rp, backward=True) for rp in rps]
+        ref_gi = hip.render_gradient_image(cam, rps[0], 2)
+        outs = [torch.zeros((256, 384, 3), dtype=torch.float32, device=dev) for _ in rps]
+        grads = [torch.zeros((scene.n_params, 3), dtype=torch.float64, device=dev) for _ in rps]
+        gi_out = torch.zeros((256, 384, 3), dtype=torch.float32, device=dev)
+        gi_img = torch.zeros((256, 384, 3), dtype=torch.float32, device=dev)
+        for round_ in range(3):
+            for t in outs + grads + [gi_out, gi_img]:
+                t.zero_()
+            torch.cuda.synchronize()
+            # (1) frames in flight, then the gradient image (lane 0, context's stream, no wait), then frames again
+            r.render_device(cam, rps[0], outs[0].data_ptr(), grads[0].data_ptr())
+            r.render_device(cam, rps[1], outs[1].data_ptr(), grads[1].data_ptr())
+            d = rps[0].to_desc()
+            d.flags = pkg.RENDER_DEVICE_OUT
+            cd = cam.to_desc()
+            rc = r.lib.drt_hip_render_gradient_image(r.ctx, C.byref(cd), C.byref(d), 2, None, C.c_void_p(gi_out.data_ptr()),
+                                                     C.c_void_p(gi_img.data_ptr()), None)
+            assert rc == 0
+            r.render_device(cam, rps[2], outs[2].data_ptr(), grads[2].data_ptr())
+            # (3) a serial frame between overlapping ones
+            r.render_device(cam, dataclasses.replace(rps[3], flags=rps[3].flags | pkg.RENDER_SERIAL), outs[3].data_ptr(), grads[3].data_ptr())
+            r.render_device(cam, rps[4], outs[4].data_ptr(), grads[4].data_ptr())
+            # (2) an asynchronous host-buffer frame straight after them
+            h = r.render_async(cam, rps[5], backward=True)
+            img5, g5, _ = r.wait(h)
+            r.synchronize()
+            for i in range(5):
+                np.testing.assert_array_equal(outs[i].cpu().numpy(), ref[i][0], err_msg=f"frame {i}, round {round_}")
+                np.testing.assert_array_equal(grads[i].cpu().numpy(), ref[i][1], err_msg=f"frame {i}, round {round_}")
+            np.testing.assert_array_equal(img5, ref[5][0])
+            np.testing.assert_array_equal(g5, ref[5][1])
+            np.testing.assert_array_equal(gi_out.cpu().numpy(), ref_gi[0])
+            np.testing.assert_array_equal(gi_img.cpu().numpy(), ref_gi[1])
+    finally:
+        r.close()
+        hip.close()
+
+
 def test_allreduce_on_the_second_stream_gives_the_same_gradients(pkg):
     """DRT_RENDER_ALLREDUCE_ASYNC (device buffers, a communicator): all-reduce and gradient copy run on the context's second
     stream, the steps alternate between two gradient sets; after drt_hip_synchronize every step's gradient equals the

@@ -24,7 +24,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SMALL_GOLDENS, case_inputs, load_golden
+from conftest import LOSS_GOLDENS, SMALL_GOLDENS, case_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +105,32 @@ def test_f64_mode_matches_reference_golden(pkg, hip, name):
     assert grad_rel_err(grads, g["grads"]) < 1e-9
     # the image comes back as float32: compare at float32 resolution
     np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", LOSS_GOLDENS)
+def test_per_sample_squared_error_loss_matches_the_references_autograd(pkg, hip, name):
+    """DRT_RENDER_LOSS_L2: every camera sample back-propagated through a loss of its own, |L_s - target_pixel|^2 -- the loop of
+    the reference's README.md:93-98 with loss_func = squared error.  Fixtures from the reference's own autograd
+    (`diff = radiance - target; loss = diff * diff; loss.backward(1)`): f64 mode to 1e-9 with identical segment counts, f32 to
+    the stated gradient bound; group contexts and batches change nothing; and the flag is refused where it means nothing."""
+    import dataclasses
+    g = load_golden(name)
+    scene, cam, rp, target = case_inputs(pkg, g["case"])
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True, adjoint=target, f64=True, loss_l2=True)
+    assert st["segments"] == int(g["segments"])
+    assert grad_rel_err(grads, g["grads"]) < 1e-9
+    np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    img32, g32, st32 = hip.render(cam, rp, backward=True, adjoint=target, loss_l2=True)
+    assert grad_rel_err(g32, g["grads"]) <= (GRAD_TOL_HEAVY if "random" in name else GRAD_TOL)
+    # several batches, several bounces per launch: the same paths, sums equal to rounding
+    _, gb, _ = hip.render(cam, dataclasses.replace(rp, batch_paths=1000, bounces_per_launch=2), backward=True, adjoint=target,
+                          f64=True, loss_l2=True)
+    assert grad_rel_err(gb, g["grads"]) < 1e-9
+    with pytest.raises(pkg.DrtHipError, match="DRT_RENDER_LOSS_L2"):
+        hip.render(cam, rp, backward=True, loss_l2=True)                              # no target image
+    with pytest.raises(pkg.DrtHipError, match="DRT_RENDER_LOSS_L2"):
+        hip.render(cam, rp, backward=True, adjoint=target, loss_l2=True, unbiased=True)
 
 
 def test_config1_256x256x8_depth4(pkg, hip):

@@ -268,3 +268,62 @@ def test_frames_in_flight_through_the_glue_give_the_same_image_and_gradients(app
     assert "pipelined (up to 3 frames in flight)" in rep.stdout
     np.testing.assert_array_equal(parse_grads(one.stdout), parse_grads(rep.stdout))
     np.testing.assert_array_equal(read_exr_half_rgba(str(tmp_path / "one.exr")), read_exr_half_rgba(str(tmp_path / "rep.exr")))
+
+
+@pytest.mark.gpu
+def test_a_dropped_frame_does_not_block_the_pooled_context(tmp_path):
+    """drt::hip::Pending without get() (an exception between submit and get, a handle overwritten): the frame is waited for
+    and discarded by the destructor / the move-assignment, so the process-wide context keeps rendering -- five dropped
+    frames (more than may be in flight), then a synchronous render and a submitted one, both equal to a fresh render."""
+    src = tmp_path / "drop.cpp"
+    src.write_text(r'''
+#include "drt/hip.hpp"
+#include <cstdio>
+#include <vector>
+using namespace drt;
+int main()
+{
+    using T = double;
+    Vector<T, 3, true> white(Vector<T, 3>{0.5, 0.5, 0.5}, true), emission(Vector<T, 3>(1), true);
+    auto mat = std::make_shared<DiffuseBxDF<T>>(white);
+    auto em = std::make_shared<AreaEmitter<T>>(emission);
+    Sphere<T> ball(Vector<T, 3>{0., 0., 3.}, 1., mat);
+    Plane<T> floor_(Vector<T, 3>{0., 1., 0.}, -3., mat);
+    Sphere<T> light(Vector<T, 3>{0., 3., 3.}, 1., nullptr, em);
+    Scene<T> scene{&ball, &floor_, &light};
+    Camera<T> cam(48, 32);
+    cam.look_at(Vector<T, 3>{0, 0, 0}, Vector<T, 3>{0, 0, 1});
+    Pathtracer<T> tracer(1.0, 4);
+    hip::Options opt;
+    opt.backward = true;
+    std::vector<Vector<double, 3>> a(48 * 32), b(48 * 32), c(48 * 32);
+    hip::render(scene, cam, tracer, 4, a.data(), opt);
+    const Vector<T, 3> g1 = white.grad();
+    for (int i = 0; i < 5; ++i) {
+        hip::Pending<T> p = hip::submit(scene, cam, tracer, 4, b.data(), opt);     // dropped at the end of the iteration
+    }
+    {
+        hip::Pending<T> p = hip::submit(scene, cam, tracer, 4, b.data(), opt);
+        p = hip::submit(scene, cam, tracer, 4, b.data(), opt);                     // the first frame is discarded here
+        p.get();
+    }
+    white.grad() = Vector<T, 3>(0.);
+    hip::render(scene, cam, tracer, 4, c.data(), opt);
+    const Vector<T, 3> g2 = white.grad();
+    int bad = 0;
+    for (int i = 0; i < 48 * 32; ++i)
+        for (int ch = 0; ch < 3; ++ch)
+            bad += (a[i][ch] != b[i][ch]) + (a[i][ch] != c[i][ch]);
+    for (int ch = 0; ch < 3; ++ch)
+        bad += g1[ch] != g2[ch];
+    std::printf("bad %d\n", bad);
+    hip::release_contexts();
+    return bad ? 1 : 0;
+}
+''')
+    exe = str(tmp_path / "drop")
+    lib_dir = os.path.join(ROOT, "differentiable-renderer_amd")
+    sh(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, "-L" + lib_dir, "-ldrt_hip",
+        "-Wl,-rpath," + lib_dir, "-lpthread"])
+    out = sh([exe])
+    assert "bad 0" in out.stdout
