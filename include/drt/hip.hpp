@@ -32,6 +32,8 @@ namespace drt { namespace hip {
 struct Options {
     bool backward = false;          // also back-propagate (render.cpp:80, commented out there)
     bool unbiased = false;          // backward with the unbiased integration operator (integrate.hpp:39-52)
+    bool sample_loss_l2 = false;    // `adjoint` is a TARGET image: every sample is back-propagated through a loss of its own,
+                                    // |radiance - target|^2 (README.md:93-98 with loss_func = squared error; DRT_RENDER_LOSS_L2)
     uint32_t seed = 1;
     int max_depth = 0;              // 0 = library default (64)
     std::vector<int> devices = {0}; // pixel-row bands are dealt round-robin to these devices (several: one group
@@ -365,7 +367,8 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
         rp.n_shards = 1;                // a group context deals the bands to its devices itself
         rp.band_rows = opt.band_rows;
         rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
-                   (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
+                   (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u) |
+                   (opt.backward && opt.sample_loss_l2 ? DRT_RENDER_LOSS_L2 : 0u);
         rp.batch_paths = opt.batch_paths;
         rp.bounces_per_launch = opt.bounces_per_launch;
         // n_dev > 1: out_param_grad comes back ALREADY summed over the devices (one ncclAllReduce in the library)
@@ -529,7 +532,8 @@ inline Pending<T> submit(const Scene<T>& scene, const Camera<T>& cam, const Path
     rp.n_shards = 1;
     rp.band_rows = opt.band_rows;
     rp.flags = (opt.backward ? DRT_RENDER_BACKWARD : 0u) | (opt.f64 ? DRT_RENDER_F64 : 0u) |
-               (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u);
+               (opt.backward && opt.unbiased ? DRT_RENDER_UNBIASED : 0u) |
+               (opt.backward && opt.sample_loss_l2 ? DRT_RENDER_LOSS_L2 : 0u);
     rp.batch_paths = opt.batch_paths;
     rp.bounces_per_launch = opt.bounces_per_launch;
     ctx.check(drt_hip_render_async(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, f.m_frame,
