@@ -10,6 +10,12 @@
 // is executed: 24 instead of 38 VALU on gfx950.  2^31 stands for RAND_MAX = 2^31 - 1: an angle error of 3e-9 rad, 20x
 // below f32 resolution.  Cephes' minimax polynomials for |x| <= pi/4.  Host + device: tests/cpp/sincos_kat.cpp sweeps
 // the whole range against libm in double (max abs error 1.2e-7).
+// (Round 4 measured the hardware's v_sin_f32 / v_cos_f32 on u = r / 2^31 in its place -- arguments in revolutions, the range
+// reduction done by the instruction: 8 instead of 24 issue slots, k_path 0.705 -> 0.670 ms on config 3 -- and did not keep it:
+// max abs error 2.7e-7 (mean 7e-8) against 1.2e-7 (2.6e-8), tools/microbench_sincos.hip, and with it two of the small
+// fixed-seed fixtures each gained a path whose hit decision flips under f32 rounding -- g4b's gradient went to 1.36e-4 of
+// its largest component, over the stated 1e-4.  At full size nothing moves (config 3: 4.5e-6), but the small fixtures are
+// what pins the f32 mode path for path.)
 #pragma once
 
 #if !defined(__HIPCC_RTC__)

@@ -1,0 +1,45 @@
+// microbench_sincos.hip -- accuracy of the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions) for phi = 2 pi r / RAND_MAX,
+// against the integer-reduced polynomials of csrc/drt_sincos.h (not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Idifferentiable-renderer_amd/csrc tools/microbench_sincos.hip -o build/microbench_sincos
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include "drt_sincos.h"
+
+__global__ void k(const uint32_t* r, float* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = r[i];
+    const float u = (float)x * 4.656612875245797e-10f;          // r / 2^31 (f32: 24 of the draw's 31 bits)
+    out[i * 4 + 0] = __builtin_amdgcn_sinf(u);
+    out[i * 4 + 1] = __builtin_amdgcn_cosf(u);
+    float s, c;
+    sincos_2pi_u31(x, &s, &c);
+    out[i * 4 + 2] = s;
+    out[i * 4 + 3] = c;
+}
+
+int main()
+{
+    const int n = 1 << 24;
+    uint32_t* h = (uint32_t*)malloc(n * 4);
+    uint64_t st = 88172645463325252ull;
+    for (int i = 0; i < n; ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; h[i] = (uint32_t)(st >> 33); }
+    uint32_t* d; float* o;
+    hipMalloc(&d, n * 4); hipMalloc(&o, (size_t)n * 16);
+    hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, d, o, n);
+    float* r = (float*)malloc((size_t)n * 16);
+    hipMemcpy(r, o, (size_t)n * 16, hipMemcpyDeviceToHost);
+    double e_hw = 0, e_poly = 0, a_hw = 0, a_poly = 0;
+    for (int i = 0; i < n; ++i) {
+        const double phi = 2.0 * M_PI * (double)h[i] / 2147483647.0, s = sin(phi), c = cos(phi);
+        const double ehw = fmax(fabs(r[i * 4] - s), fabs(r[i * 4 + 1] - c)), ep = fmax(fabs(r[i * 4 + 2] - s), fabs(r[i * 4 + 3] - c));
+        e_hw = fmax(e_hw, ehw); e_poly = fmax(e_poly, ep); a_hw += ehw; a_poly += ep;
+    }
+    printf("max abs error over %d draws: v_sin/v_cos(f32 u) %.3g (mean %.3g)   integer-reduced polynomials %.3g (mean %.3g)\n", n, e_hw,
+           a_hw / n, e_poly, a_poly / n);
+    return 0;
+}
