@@ -15,7 +15,9 @@
 // max abs error 2.7e-7 (mean 7e-8) against 1.2e-7 (2.6e-8), tools/microbench_sincos.hip, and with it two of the small
 // fixed-seed fixtures each gained a path whose hit decision flips under f32 rounding -- g4b's gradient went to 1.36e-4 of
 // its largest component, over the stated 1e-4.  At full size nothing moves (config 3: 4.5e-6), but the small fixtures are
-// what pins the f32 mode path for path.)
+// what pins the f32 mode path for path.  The hybrid -- this integer quadrant reduction, then the two hardware instructions on
+// the remainder in place of the two polynomials -- is as accurate as the polynomials (1.29e-7 / mean 4.2e-8) and passes every
+// test, but buys 0.4 %: 0.700 -> 0.697 ms.  The quarter-rate pipe is the busier one.)
 #pragma once
 
 #if !defined(__HIPCC_RTC__)
