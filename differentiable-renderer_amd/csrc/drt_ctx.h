@@ -53,6 +53,7 @@ struct drt_hip_ctx {
 
     bool has_scene = false;
     bool has_specular = false;
+    bool emissive_bxdf = false;           // some analytic shape carries a BxDF AND an emitter (several emission terms per path)
     int max_colour_param = -1;            // largest parameter index that is some material's colour (device numbering)
     bool prog_ok = false;                 // k_path's intersection program covers the scene (drt_path.h)
     bool prog_sorted = false;             // the kind-sorted program covers the scene's analytic shapes (k_shade's tail)

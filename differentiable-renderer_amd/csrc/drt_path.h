@@ -155,7 +155,10 @@ struct Tangents {
 // an emissive vertex reached with prefix throughput T: radiance and gradients
 //   L     += T E / p_k                                   (pathtracer.hpp:113-114, 133)
 //   d/dc_p += g dT_p E / p_k      d/dE += g T / p_k       (vector.hpp:418-484 in closed form)
-template <typename R, int NP, int NC>
+// LOSS (DRT_RENDER_LOSS_L2, the end of a path only): `g` holds the lane's TARGET pixel and the seed is the derivative of the
+// sample's own squared error, 2 (L - target), with L the path's radiance INCLUDING this emission -- final where the path ends
+// on a light without BxDF, which is the only emissive vertex of a path in the scenes this form is used for.
+template <typename R, int NP, int NC, bool LOSS = false>
 __device__ inline void add_emission(const SceneLds<R>& lds, const TangentLds<R>& tl, const R* __restrict__ params, uint32_t eid, R inv_pk,
                                     V3<R> T, V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
 {
@@ -167,6 +170,8 @@ __device__ inline void add_emission(const SceneLds<R>& lds, const TangentLds<R>&
     if (NP > 0) {
         if (NC > 0)
             asm volatile("" ::: "memory");    // (keeps the reads of `tl` below where they are: see there)
+        if (LOSS)
+            g = mk<R>(R(2) * (L.x - g.x), R(2) * (L.y - g.y), R(2) * (L.z - g.z));
         const V3<R> gE = g * E, gT = g * Tr * inv_pk;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -325,7 +330,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // path ends.  ~35 % more instructions per bounce, but roulette-terminated renders (the reference's defaults, -b 1
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
 // (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
-template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false>
+template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false, bool LOSS = false>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? 5 : 1))
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
@@ -429,7 +434,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         }
         if (wave_any(end_ids != DRT_ID_NONE)) {
             if (end_ids != DRT_ID_NONE)
-                add_emission<R, NP, NC>(lds, tl, params, end_ids, end_inv_pk, T, g, L, tg);
+                add_emission<R, NP, NC, LOSS>(lds, tl, params, end_ids, end_inv_pk, T, g, L, tg);
         }
         fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
     }
@@ -489,7 +494,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             if (wave_any(ended)) {
                 if (ended) {
                     if (on_light)
-                        add_emission<R, NP, NC>(lds, tl, params, light, inv_pk, T, g, L, tg);
+                        add_emission<R, NP, NC, LOSS>(lds, tl, params, light, inv_pk, T, g, L, tg);
                     fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
                 }
             }

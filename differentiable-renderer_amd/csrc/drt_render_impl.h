@@ -150,6 +150,7 @@ struct Shard {
     uint64_t total_paths;
     bool unbiased;                  // the reference's unbiased integration operator (integrate.hpp:39-52)
     bool loss_l2;                   // DRT_RENDER_LOSS_L2: every sample seeded with 2 (L_s - target_pixel), d_adjoint is the target
+    hipFunction_t loss_kernel = nullptr;   // ... on k_path: the LOSS instantiation, made at run time only (drt_jit.h)
     bool can_fuse;                  // K2 folded into K3: analytic scenes, unless DRT_RENDER_UNFUSED asks for the textbook pipeline
     bool use_path, path_regen;      // the whole path in one launch (k_path); its regenerating form
     bool shade_tail;                // mesh scenes: the launch that produces a ray also intersects it with the analytic shapes and
@@ -203,6 +204,24 @@ struct Shard {
     }
 };
 
+// "k_path<float, SPEC, NP, NC, KindSig<...>, REGEN[, LOSS]>" / "k_path_unbiased<float, SPEC, NP, KindSig<...>>": the name expression
+// of the f32 instantiation a render would launch, for the scene's own signature
+inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss)
+{
+    const std::string sg = drt_jit::sig_type(ctx->prog_sig, ctx->n_shapes);
+    const char* sp = ctx->has_specular ? "true" : "false";
+    const bool three = ctx->max_colour_param < 3;      // tangent state only for parameters that ARE some BxDF's colour
+    char name[400];
+    if (unbiased)
+        snprintf(name, sizeof name, "k_path_unbiased<float, %s, %d, %s>", sp, ctx->n_params > 4 ? 8 : 4, sg.c_str());
+    else {
+        const int np = tangents ? (ctx->n_params > 4 ? 8 : 4) : 0;
+        const int nc = tangents ? (ctx->n_params > 4 ? 8 : (three ? 3 : 4)) : 0;
+        snprintf(name, sizeof name, "k_path<float, %s, %d, %d, %s, %s%s>", sp, np, nc, sg.c_str(), regen ? "true" : "false", loss ? ", true" : "");
+    }
+    return name;
+}
+
 // ---- which route, how large a batch, which grids ---------------------------------------------------------------------
 template <typename R>
 void shard_plan(Shard<R>& s)
@@ -223,8 +242,7 @@ void shard_plan(Shard<R>& s)
     // its next sample at once) otherwise: roulette-terminated paths under the default cap of 64, the reference's own
     // defaults (-b 1 -p 0.5).
     s.use_path = s.can_fuse && ctx->prog_ok && D > 0 && (!(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) &&
-                 rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path < 0 &&
-                 !s.loss_l2;       // (the per-sample seed needs the path's radiance before its gradients: the tape route, two walks)
+                 rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path < 0;
     s.path_regen = tuning().path_regen > 0;
     if (s.unbiased)
         s.path_regen = false;                  // (k_path_unbiased walks its samples in lockstep)
@@ -245,6 +263,17 @@ void shard_plan(Shard<R>& s)
                 longest = k + 1;
         }
         s.path_regen = 1.7 * mean_len + 0.5 < (double)longest;
+    }
+    if (s.use_path && s.loss_l2) {
+        // The per-sample seed 2 (L_s - target) needs the path's radiance before its gradients.  k_path has it where the path
+        // ends on a light -- the only emissive vertex of a path unless some shape carries a BxDF AND an emitter -- in the LOSS
+        // instantiation, which the library does not carry: it is compiled at run time (f32, unless the context may not
+        // compile).  Everything else takes the tape route: two walks of the tape, k_radiance then k_backward.
+        s.use_path = false;
+        if (sizeof(R) == 4 && !ctx->emissive_bxdf && ctx->jit_mode >= DRT_SPECIALISE_AUTO) {
+            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true));
+            s.use_path = s.loss_kernel != nullptr;
+        }
     }
     // Batch = the paths that are in flight at once on the queue route.  The BVH walk wants it LARGE: its launches end in a
     // tail of ~0.1 ms whatever their size (the list counters run dry, every wave finishes what it holds), so config 4 at full
@@ -485,7 +514,7 @@ int path_batch(Shard<R>& s)
     // other analytic scene reads its kinds at run time (the kind-sorted program) until it has rendered enough for a kernel
     // of its own to pay (drt_jit.h; f32 only: the f64 mode keeps the reference's literal shape loop for such scenes).
     const bool builtin = tuning().builtin_program && ctx->jit_mode >= 0 && ctx->n_shapes == DRT_NSIG_CORNELL &&
-                         ctx->prog_sig[0] == DRT_SIG_CORNELL;
+                         ctx->prog_sig[0] == DRT_SIG_CORNELL && !s.loss_kernel;
     unsigned long long* ptotal = s.path_finish ? s.totals : (unsigned long long*)nullptr;
     // (frames that overlap: this frame's grid goes to the lane's own stream, behind whoever still uses the lane's buffers, and
     //  the finishing launch on the context's stream waits for it.  Scene and parameter uploads block until they are done, so
@@ -505,24 +534,12 @@ int path_batch(Shard<R>& s)
         if (ctx->lane_used[lane2] && ctx->ev_lane_free[lane2])
             HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_lane_free[lane2], 0));
     }
-    // tangents are carried for the parameters that ARE some BxDF's colour: 3 when the 4th is emission-only
     const bool three = ctx->max_colour_param < 3;
     const bool tangents = backward || s.gimg_param >= 0;
-    hipFunction_t jit = nullptr;
+    hipFunction_t jit = s.loss_kernel;
     ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(s.D > 0 ? s.D : 1);
-    if (!builtin && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK)) {
-        const std::string sg = drt_jit::sig_type(ctx->prog_sig, ctx->n_shapes);
-        const char* sp = ctx->has_specular ? "true" : "false";
-        char name[384];
-        if (unbiased)
-            snprintf(name, sizeof name, "k_path_unbiased<float, %s, %d, %s>", sp, ctx->n_params > 4 ? 8 : 4, sg.c_str());
-        else {
-            const int np = tangents ? (ctx->n_params > 4 ? 8 : 4) : 0;
-            const int nc = tangents ? (ctx->n_params > 4 ? 8 : (three ? 3 : 4)) : 0;
-            snprintf(name, sizeof name, "k_path<float, %s, %d, %d, %s, %s>", sp, np, nc, sg.c_str(), path_regen ? "true" : "false");
-        }
-        jit = jit_function(ctx, name);
-    }
+    if (!jit && !builtin && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
+        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false));
     st->path_program = builtin ? DRT_PROGRAM_BUILTIN : (jit ? DRT_PROGRAM_SPECIALISED : DRT_PROGRAM_SORTED);
     int rc;
     if ((rc = timing_begin(ctx, s.timing, DRT_K_PATH)) != DRT_OK) return rc;

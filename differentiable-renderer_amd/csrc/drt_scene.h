@@ -356,6 +356,10 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
             ctx->requires_grad[i] = s->requires_grad[i] ? 1 : 0;
     // only materials that a shape or a mesh face actually uses decide the K3 instantiation
     // (render.cpp:35 creates a specular material its scene never uses)
+    ctx->emissive_bxdf = false;
+    for (int i = 0; i < s->n_shapes; ++i)
+        if (s->shapes[i].type != DRT_SHAPE_MESH && s->shapes[i].material >= 0 && s->shapes[i].emitter >= 0)
+            ctx->emissive_bxdf = true;
     ctx->has_specular = false;
     // (mirrors live in the specular instantiation too)
     auto uses = [&](int m) { if (m >= 0 && s->materials[m].type != DRT_BXDF_DIFFUSE) ctx->has_specular = true; };

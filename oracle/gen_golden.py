@@ -136,6 +136,8 @@ SMALL = [
          absorb=0.25, seed=16, loss_l2=True, target_seed=5, eye=(0.2, -0.3, 0.0), at=(0.0, 0.1, 1.0)),
     dict(name="l4_loss_l2_mesh10x12_28x24x4", scene="mesh10x12", width=28, height=24, spp=4, min_bounces=3,
          absorb=0.3, seed=17, loss_l2=True, target_seed=6),
+    dict(name="l5_loss_l2_specular_40x32x6_rr", scene="cornell_specular", width=40, height=32, spp=6, min_bounces=1,
+         absorb=0.5, seed=18, loss_l2=True, target_seed=7),
 ]
 BIG = [
     dict(name="c1_cornell_256x256x8_d4", scene="cornell", width=256, height=256, spp=8,

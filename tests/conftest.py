@@ -55,7 +55,7 @@ def case_inputs(pkg, case):
 
 
 LOSS_GOLDENS = ["l1_loss_l2_cornell_48x32x6_d5", "l2_loss_l2_emissive_wall_40x30x5_rr", "l3_loss_l2_random3_36x28x5",
-                "l4_loss_l2_mesh10x12_28x24x4"]
+                "l4_loss_l2_mesh10x12_28x24x4", "l5_loss_l2_specular_40x32x6_rr"]
 
 
 SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_64x64x8_rr",

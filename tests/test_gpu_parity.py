@@ -123,6 +123,14 @@ def test_per_sample_squared_error_loss_matches_the_references_autograd(pkg, hip,
     np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
     img32, g32, st32 = hip.render(cam, rp, backward=True, adjoint=target, loss_l2=True)
     assert grad_rel_err(g32, g["grads"]) <= (GRAD_TOL_HEAVY if "random" in name else GRAD_TOL)
+    # f32, analytic scene, no shape with both a BxDF and an emitter: ONE k_path launch, its LOSS instantiation compiled at run
+    # time (the path's radiance is final where it meets the light); otherwise the tape route -- and the two agree
+    on_path = not scene.meshes and not any(m >= 0 and e >= 0 for _, m, e, _ in scene.shapes)
+    assert (st32["kernels"]["path"]["launches"] == 1) == on_path, st32["kernels"]
+    assert st32["path_program"] == ("specialised" if on_path else "none")
+    _, gq, stq = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, adjoint=target, loss_l2=True)
+    assert stq["kernels"]["path"]["launches"] == 0
+    np.testing.assert_allclose(g32, gq, rtol=1e-4 if "random" in name else 2e-5, atol=1e-5 * np.abs(gq).max())
     # several batches, several bounces per launch: the same paths, sums equal to rounding
     _, gb, _ = hip.render(cam, dataclasses.replace(rp, batch_paths=1000, bounces_per_launch=2), backward=True, adjoint=target,
                           f64=True, loss_l2=True)
