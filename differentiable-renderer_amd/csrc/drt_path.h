@@ -223,8 +223,14 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
                                    const R* __restrict__ params, const ProgRecs<SG::n, R>& recs, uint32_t key,
                                    R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
                                    typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
-                                   bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr)
+                                   bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr,
+                                   bool last = false)
 {
+    // `last` (wave-uniform; the lockstep kernel at the deepest vertex a path can have): no lane's path goes on from here, so
+    // nothing is sampled -- the reference does sample a direction there, and the trace() it hands it to is absorbed before it
+    // casts a ray (pathtracer.hpp:128): a factor of exactly 0.  What is left of the bounce is the hit, the light it may have
+    // ended on, and the count of paths a user cap (not the roulette) cut short.  Same results bit for bit, ~110 of the
+    // bounce's ~280 vector instructions less: 5 % of a depth-8 frame.
     const HitRec<R> h = path_closest_hit<SG>(sc, recs, ra, rb);
     const bool hit = live && h.prim >= 0;
     const int prim = h.prim >= 0 ? h.prim : 0;                        // (a miss reads record 0, uses nothing of it)
@@ -232,18 +238,31 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     const V3<R> d = mk<R>(ra.w, rb.x, rb.y);
     const V3<R> P = o + d * h.t;                                      // pathtracer.hpp:83
     const DevShape<R>& sh = lds.sc.shapes[prim];
-    const V3<R> ctr = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
-    // (f32: (P - c) / r with 1 / r from a table would save the rsq and the select -- and moves sphere normals by a few ulp,
-    //  which flips one grazing path of the 64 x 48 x 8 smoke frame: measured, not kept; the literal form stays)
-    const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
-    const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
-    const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
     const uint32_t ids = (uint32_t)sh.pad;                            // colour | emission << 16 parameter ids
     const uint32_t cid = ids & 0xFFFFu, eid = ids >> 16;
     const bool has_bxdf = cid != DRT_ID_NONE, emits = hit && eid != DRT_ID_NONE;
     // emission, pathtracer.hpp:113-114: a shape with BxDF AND emitter (rare) adds it here, a pure light is the caller's
     on_light = emits && !has_bxdf;
     light = eid;
+    if (last && !vo) {
+        if (wave_any(emits && has_bxdf)) {
+            if (emits && has_bxdf)
+                add_emission<R, NP, NC>(lds, tl, params, eid, inv_pk, T, g, L, tg);
+        }
+        alive = false;
+        capped = false;
+        if (!a.cap_is_roulette) {                                      // (a user max_depth: had the roulette let the path live?)
+            const bool rr_kills = next_rr && rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold;
+            capped = hit && has_bxdf && !rr_kills;
+        }
+        return;
+    }
+    const V3<R> ctr = mk<R>(sh.p[0], sh.p[1], sh.p[2]);
+    // (f32: (P - c) / r with 1 / r from a table would save the rsq and the select -- and moves sphere normals by a few ulp,
+    //  which flips one grazing path of the 64 x 48 x 8 smoke frame: measured, not kept; the literal form stays)
+    const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
+    const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
+    const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
     if (vo) {
         vo->P = P; vo->nrm = nrm; vo->d = d;
         vo->ids = ids;
@@ -422,7 +441,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             bool alive, capped, on_light;
             uint32_t light;
             path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
-                                                    ra, rb, T, L, tg, alive, capped, on_light, light);
+                                                    ra, rb, T, L, tg, alive, capped, on_light, light, nullptr, next_cap);
             // A light without a BxDF ends the path: T and dT stay as they are in this lane, so its emission is added
             // ONCE PER SAMPLE, after the bounce loop, for all lanes together -- not here, where every bounce a few lanes
             // of the wave would drag the other sixty through it.
