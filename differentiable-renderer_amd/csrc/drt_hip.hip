@@ -471,12 +471,12 @@ int drt_hip_synchronize(drt_hip_ctx* ctx)
 
 #ifdef DRT_BVH_STATS
 // debug build only: read and clear the traversal counters of k_intersect_mesh (drt_kernels.h)
-extern "C" int drt_hip_debug_bvh_stats(unsigned long long* out8)
+extern "C" int drt_hip_debug_bvh_stats(unsigned long long* out16)
 {
     (void)hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bvh_stats), 8 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bvh_stats), 16 * sizeof(unsigned long long)) != hipSuccess)
         return -1;
-    unsigned long long zero[8] = {0};
+    unsigned long long zero[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), zero, sizeof zero);
     return 0;
 }

@@ -387,7 +387,7 @@ k_intersect(BatchArgs a, const DevScene<R>* __restrict__ sc, const typename Q4<R
 // linear scan (pathtracer.hpp:80): (t, flat index) is compared lexicographically.
 #ifdef DRT_BVH_STATS
 // debug build only (tools/): [0] rays, [1] node visits served from LDS, [2] from memory, [3] leaf visits, [4] triangle tests
-__device__ unsigned long long g_bvh_stats[8];
+__device__ unsigned long long g_bvh_stats[16];   // [8] node visits / [9] leaf visits whose entry distance lies beyond the hit found meanwhile; [10..15] rays by deepest stack (<=4, 8, 12, 16, 24, more)
 // [0..7]: rays by their number of node visits (1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, more); [8..15]: those of them that ended
 // on a triangle; [16..23]: node visits summed per bin
 __device__ unsigned long long g_bvh_hist[24];
@@ -444,6 +444,8 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
 #endif
 #ifdef DRT_BVH_STATS
     uint32_t stat_visits = 0;
+    float stat_t[DRT_BVH_STACK], stat_cur_t = 0.f;
+    int stat_max_sp = 0;
 #endif
     bool active = false;
     uint32_t n_walked = 0;                                      // candidate rays this wave took (statistics: total[5])
@@ -532,6 +534,8 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                     DRT_STAT(0, 1);
 #ifdef DRT_BVH_STATS
                     stat_visits = 0;
+                    stat_cur_t = 0.f;
+                    stat_max_sp = 0;
 #endif
                 }
                 cur_off += n_want < avail ? n_want : avail;
@@ -558,6 +562,7 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             DRT_STAT(cur < n_lds ? 1 : 2, 1);
 #ifdef DRT_BVH_STATS
             ++stat_visits;
+            if (stat_cur_t > (float)tmin) DRT_STAT(8, 1);
 #endif
             if (cur < n_lds) {
                 w0 = s_node[cur][0]; w1 = s_node[cur][1]; w2 = s_node[cur][2]; w3 = s_node[cur][3];
@@ -597,9 +602,19 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             DRT_CSWAP(0, 1) DRT_CSWAP(2, 3) DRT_CSWAP(0, 2) DRT_CSWAP(1, 3) DRT_CSWAP(1, 2)
 #undef DRT_CSWAP
             // farthest first onto the stack, nearest becomes current
+#ifdef DRT_BVH_STATS
+            if (tc[3] < (R)INFINITY) stat_t[sp] = (float)tc[3];
+            if (tc[2] < (R)INFINITY) stat_t[sp + (tc[3] < (R)INFINITY)] = (float)tc[2];
+            if (tc[1] < (R)INFINITY) stat_t[sp + (tc[3] < (R)INFINITY) + (tc[2] < (R)INFINITY)] = (float)tc[1];
+#endif
             if (tc[3] < (R)INFINITY) s_stack[sp++][tid] = lc[3];
             if (tc[2] < (R)INFINITY) s_stack[sp++][tid] = lc[2];
             if (tc[1] < (R)INFINITY) s_stack[sp++][tid] = lc[1];
+#ifdef DRT_BVH_STATS
+            stat_max_sp = sp > stat_max_sp ? sp : stat_max_sp;
+            if (tc[0] < (R)INFINITY) stat_cur_t = (float)tc[0];
+            else if (sp > 0) stat_cur_t = stat_t[sp - 1];
+#endif
             if (tc[0] < (R)INFINITY)
                 cur = lc[0];
             else
@@ -611,6 +626,9 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, count = cur & 7u;
             DRT_STAT(3, 1);
             DRT_STAT(4, count);
+#ifdef DRT_BVH_STATS
+            if (stat_cur_t > (float)tmin) DRT_STAT(9, 1);
+#endif
             // all triangles of the leaf (<= kMaxLeaf = 4) are requested before the first is tested:
             // one round trip to L2 per leaf instead of one per triangle
             R4 ta[4], tb[4], tcc[4];
@@ -636,11 +654,15 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
                         }
                     }
                 }
+#ifdef DRT_BVH_STATS
+            if (sp > 0) stat_cur_t = stat_t[sp - 1];
+#endif
             cur = sp > 0 ? s_stack[--sp][tid] : DRT_BVH_NONE;
         }
         if (active && cur == DRT_BVH_NONE) {
 #ifdef DRT_BVH_STATS
             {
+                DRT_STAT(10 + (stat_max_sp <= 4 ? 0 : (stat_max_sp <= 8 ? 1 : (stat_max_sp <= 12 ? 2 : (stat_max_sp <= 16 ? 3 : (stat_max_sp <= 24 ? 4 : 5))))), 1);
                 const uint32_t v = stat_visits;
                 const int bin = v <= 1 ? 0 : (v <= 2 ? 1 : (v <= 4 ? 2 : (v <= 8 ? 3 : (v <= 16 ? 4 : (v <= 32 ? 5 : (v <= 64 ? 6 : 7))))));
                 atomicAdd(&g_bvh_hist[bin], 1ull);

@@ -63,7 +63,7 @@ lib_stats = os.path.abspath(sys.argv[4]) if len(sys.argv) > 4 else None
 if lib_stats:
     r = pkg.HipRenderer(0, lib_path=lib_stats)
     r.upload_scene(scene)
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     prev = np.zeros(8)
     print("depth      rays  nodes/ray(LDS+mem)  leaves/ray  tris/ray  lanes/interior-iter  leaf-lanes/outer-iter  iters per 64 rays (interior, outer)")
     for d in range(1, 9):
