@@ -131,6 +131,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     release_mesh(ctx);
     for (hipModule_t m : ctx->jit_modules)
         (void)hipModuleUnload(m);
+    drt_jit::wait_idle();                   // (a compile this context started in the background is allowed to finish)
     if (ctx->d_scene_f) (void)hipFree(ctx->d_scene_f);
     if (ctx->d_scene_d) (void)hipFree(ctx->d_scene_d);
     if (ctx->d_params_f) (void)hipFree(ctx->d_params_f);

@@ -7,17 +7,20 @@
 // built from (embedded as strings: embed_sources.py) -- `k_path<float, false, 4, 3, KindSig<the scene's words>, false>` as
 // a name expression, ~0.3-0.7 s per variant on the box's host, cached per process by that name.  The result is
 // bit-identical to the kind-sorted program it replaces (same record arithmetic: prog_t; tests/test_gpu_jit.py), so WHEN a
-// scene gets its own program is a matter of cost only: once it has rendered enough for the compile to pay
-// (drt_hip.hip: jit_wanted), at once with DRT_HIP_JIT=force, never with DRT_HIP_JIT=0.
+// scene gets its own program is a matter of cost only: once it has rendered enough for the compile to pay -- then on a
+// thread of its own, no frame waits for the compiler (poll) --, at once and waited for with DRT_SPECIALISE_NOW /
+// DRT_HIP_JIT=force (compile), never with DRT_HIP_JIT=0.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace drt_jit {
@@ -32,26 +35,16 @@ struct Code {
     double ms = 0;              // compile time
 };
 
-inline std::mutex& mutex() { static std::mutex m; return m; }
-inline std::map<std::string, Code>& cache() { static std::map<std::string, Code> c; return c; }
-
-// compile the instantiation `name_expr` of a kernel template of drt_path.h for `arch` (process-wide cache; thread-safe:
-// the members of a group context launch from threads of their own)
-inline const Code& compile(const std::string& arch, const std::string& name_expr)
+// the hiprtc work itself (no lock held; ~0.3-0.7 s of one host core)
+inline void build(const std::string& arch, const std::string& name_expr, Code& c)
 {
-    std::lock_guard<std::mutex> lock(mutex());
-    const std::string key = arch + "|" + name_expr;
-    auto it = cache().find(key);
-    if (it != cache().end())
-        return it->second;
-    Code& c = cache()[key];
     const auto t0 = std::chrono::steady_clock::now();
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, "#include \"drt_path.h\"\n", "drt_jit.hip", drt_jit_n_headers, drt_jit_header_srcs,
                                          drt_jit_header_names);
     if (r != HIPRTC_SUCCESS) {
         c.log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
-        return c;
+        return;
     }
     r = hiprtcAddNameExpression(prog, name_expr.c_str());
     const std::string arch_opt = "--offload-arch=" + arch;
@@ -69,7 +62,7 @@ inline const Code& compile(const std::string& arch, const std::string& name_expr
     if (r != HIPRTC_SUCCESS) {
         c.log = std::string("hiprtc (") + name_expr + "): " + hiprtcGetErrorString(r) + "\n" + c.log;
         (void)hiprtcDestroyProgram(&prog);
-        return c;
+        return;
     }
     const char* lowered = nullptr;
     size_t size = 0;
@@ -83,7 +76,86 @@ inline const Code& compile(const std::string& arch, const std::string& name_expr
         c.log = std::string("hiprtc (") + name_expr + "): no code object";
     (void)hiprtcDestroyProgram(&prog);
     c.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return c;
+}
+
+// The process-wide cache, by architecture and name expression.  An entry exists from the moment somebody asked for it;
+// `done` says whether its compile has finished (entries of a std::map do not move: the compiling thread keeps a reference).
+struct Entry {
+    Code code;
+    bool done = false;
+};
+struct State {
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<std::string, Entry> cache;
+    std::vector<std::thread> workers;       // background compiles (poll); joined when the library is unloaded
+    ~State()
+    {
+        for (std::thread& t : workers)
+            if (t.joinable())
+                t.join();
+    }
+};
+inline State& state() { static State s; return s; }
+
+// compile the instantiation `name_expr` of a kernel template of drt_path.h for `arch` and WAIT for it (thread-safe: the
+// members of a group context launch from threads of their own; a compile already running in the background is joined)
+inline const Code& compile(const std::string& arch, const std::string& name_expr)
+{
+    State& st = state();
+    const std::string key = arch + "|" + name_expr;
+    std::unique_lock<std::mutex> lock(st.m);
+    auto it = st.cache.find(key);
+    if (it != st.cache.end()) {
+        Entry& e = it->second;
+        st.cv.wait(lock, [&e] { return e.done; });
+        return e.code;
+    }
+    Entry& e = st.cache[key];
+    lock.unlock();
+    build(arch, name_expr, e.code);
+    lock.lock();
+    e.done = true;
+    st.cv.notify_all();
+    return e.code;
+}
+
+// the same WITHOUT waiting: nullptr while the compile runs -- started on a thread of its own by the first call -- and the
+// code once it is there.  What DRT_SPECIALISE_AUTO uses: the frames of a render loop never wait for the compiler, they
+// run the kind-sorted program (same results, bit for bit) until the specialised one has arrived.
+inline const Code* poll(const std::string& arch, const std::string& name_expr)
+{
+    State& st = state();
+    const std::string key = arch + "|" + name_expr;
+    std::lock_guard<std::mutex> lock(st.m);
+    auto it = st.cache.find(key);
+    if (it != st.cache.end())
+        return it->second.done ? &it->second.code : nullptr;
+    Entry& e = st.cache[key];
+    st.workers.emplace_back([arch, name_expr, &e, &st] {
+        build(arch, name_expr, e.code);
+        {
+            std::lock_guard<std::mutex> l(st.m);
+            e.done = true;
+        }
+        st.cv.notify_all();
+    });
+    return nullptr;
+}
+
+// wait for the background compiles that are still running (a context is being destroyed: the process may be about to exit,
+// and the compiler's own state should not be torn down under a running compile)
+inline void wait_idle()
+{
+    State& st = state();
+    std::vector<std::thread> done;
+    {
+        std::lock_guard<std::mutex> lock(st.m);
+        done.swap(st.workers);
+    }
+    for (std::thread& t : done)
+        if (t.joinable())
+            t.join();
 }
 
 // "KindSig<0x...ull, 0x...ull, 0x...ull, 0x...ull, n>"

@@ -74,15 +74,19 @@ int queue_length(drt_hip_ctx* ctx, const uint32_t* counts_row, uint32_t n_region
 }
 // The instantiation `name_expr` of a kernel template of drt_path.h, compiled for this scene's KindSig by hiprtc and loaded
 // on this context's device (drt_jit.h).  nullptr: it could not be made (ctx->jit_error says why; the caller renders with
-// the kind-sorted program, same results).
-hipFunction_t jit_function(drt_hip_ctx* ctx, const std::string& name_expr)
+// the kind-sorted program, same results).  wait = false: also nullptr while the compiler is still at it on its own thread --
+// nothing is recorded then, the next frame asks again.
+hipFunction_t jit_function(drt_hip_ctx* ctx, const std::string& name_expr, bool wait = true)
 {
     auto it = ctx->jit_fn.find(name_expr);
     if (it != ctx->jit_fn.end())
         return it->second;
     const auto t0 = std::chrono::steady_clock::now();
     hipFunction_t fn = nullptr;
-    const drt_jit::Code& c = drt_jit::compile(ctx->arch, name_expr);
+    const drt_jit::Code* pc = wait ? &drt_jit::compile(ctx->arch, name_expr) : drt_jit::poll(ctx->arch, name_expr);
+    if (!pc)
+        return nullptr;
+    const drt_jit::Code& c = *pc;
     if (!c.ok) {
         ctx->jit_error = c.log;
     } else {
@@ -101,7 +105,8 @@ hipFunction_t jit_function(drt_hip_ctx* ctx, const std::string& name_expr)
     if (!fn && tuning().jit_verbose)
         fprintf(stderr, "[drt_hip] specialisation failed: %s\n", ctx->jit_error.c_str());
     ctx->jit_fn[name_expr] = fn;
-    ctx->jit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // (what the kernel cost: the compile, on whichever thread it ran, and this context's load)
+    ctx->jit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() + (wait ? 0. : c.ms);
     return fn;
 }
 // A compile costs ~0.5 s of host time and buys ~25 % of the kind-sorted program's time: it pays once the scene has rendered
@@ -539,7 +544,7 @@ int path_batch(Shard<R>& s)
     hipFunction_t jit = s.loss_kernel;
     ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(s.D > 0 ? s.D : 1);
     if (!jit && !builtin && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
-        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false));
+        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false), ctx->jit_mode > 1);
     st->path_program = builtin ? DRT_PROGRAM_BUILTIN : (jit ? DRT_PROGRAM_SPECIALISED : DRT_PROGRAM_SORTED);
     int rc;
     if ((rc = timing_begin(ctx, s.timing, DRT_K_PATH)) != DRT_OK) return rc;

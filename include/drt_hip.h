@@ -276,7 +276,10 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3
  *   DRT_SPECIALISE_NEVER   never compile at run time (the reference's own scene keeps the kernel the library carries for it)
  *   DRT_SPECIALISE_AUTO    (default) once the scene has rendered 2^31 path-bounces through this context (~20 ms of
  *                          frames): small test frames never pay for a compile, a render loop does within its first frames
- *   DRT_SPECIALISE_NOW     at the next render that can use it (a caller that knows it will render many frames)
+ *                          -- on a thread of the library's own: no frame waits for the compiler, the frames rendered
+ *                          meanwhile use the run-time program (drt_hip_stats.path_program says which one ran)
+ *   DRT_SPECIALISE_NOW     at the next render that can use it, which waits for the compile (a caller that knows it
+ *                          will render many frames and wants every one of them on the fast kernel)
  * The environment variable DRT_HIP_JIT (-1 | 0 | 1 | force) sets the default of new contexts.  Group contexts: every member. */
 enum { DRT_SPECIALISE_GENERIC = -1, DRT_SPECIALISE_NEVER = 0, DRT_SPECIALISE_AUTO = 1, DRT_SPECIALISE_NOW = 2 };
 int drt_hip_set_specialisation(drt_hip_ctx* ctx, int mode);
