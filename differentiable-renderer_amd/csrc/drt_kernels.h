@@ -54,6 +54,9 @@ struct BatchArgs {
     int32_t min_bounces, depth_cap;
     int32_t cap_is_roulette;   // the cap is the depth where absorb == 1 kills every path: the reference
                                // still draws its roulette number there (a user max_depth draws nothing)
+    int32_t cap_draws;         // the roulette number of the cap's depth counts as drawn (the unbiased operator's draw
+                               // bookkeeping): cap_is_roulette, or the cap is the library's own DRT_MAX_DEPTH -- the reference,
+                               // which has no cap, draws there, and where that draw ends the path the two stay in step
     double absorb;
     uint32_t seed;
     uint32_t rng_stream;     // drt_rng_stream(seed, 0): the h-seed of every path of the frame (at most 2^32 camera samples)
@@ -1722,7 +1725,7 @@ k_adj_init(BatchArgs a, const TapeRec<R>* __restrict__ tape, const uint32_t* __r
         // every depth in [min_bounces, K] the walk reached (absorbed, missed, or -- zero-length rays
         // never hit -- the continuation after a BxDF-less vertex), none at the depth cap
         const bool last_null = (tape[(size_t)(K - 1) * N + i].ids & 0xFFFFu) == DRT_ID_NONE;
-        const int top = (K < a.depth_cap || a.cap_is_roulette) ? K : a.depth_cap - 1;
+        const int top = (K < a.depth_cap || a.cap_draws) ? K : a.depth_cap - 1;
         const int rr = top - a.min_bounces + 1;
         cs.ndraw[i] = 2u + 2u * (uint32_t)(K - (last_null ? 1 : 0)) + (uint32_t)(rr > 0 ? rr : 0);
     }
@@ -1894,7 +1897,7 @@ k_adj_accumulate(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R
                 //  of depth s; the launcher lets cv and nx change places instead of 32 bytes per path being copied here)
                 // draws the suffix consumed after its base (see k_adj_init)
                 const bool last_null = (tape[(size_t)(K - 1) * N + i].ids & 0xFFFFu) == DRT_ID_NONE;
-                const int top = (K < a.depth_cap || a.cap_is_roulette) ? K : a.depth_cap - 1;
+                const int top = (K < a.depth_cap || a.cap_draws) ? K : a.depth_cap - 1;
                 const int first_rr = a.min_bounces > s + 1 ? a.min_bounces : s + 1;
                 const int rr = top - first_rr + 1;
                 cs.ndraw[i] = cs.dbase[i] + 2u * (uint32_t)(K - s - (last_null ? 1 : 0)) + (uint32_t)(rr > 0 ? rr : 0);

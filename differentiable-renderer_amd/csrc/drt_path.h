@@ -43,7 +43,7 @@ struct PathArgs {
     // batch: pixels [p0, p0 + Pb) of the shard, samples [s0, s0 + Sb), cut into ranges of spr samples
     uint32_t Pb, p0, Sb, s0, spr, n_ranges, n_groups;
     // integrator
-    int32_t min_bounces, depth_cap, cap_is_roulette;
+    int32_t min_bounces, depth_cap, cap_is_roulette, cap_draws;   // (cap_draws: BatchArgs)
     uint32_t rr_threshold, seed, rng_stream;   // rng_stream: drt_rng_stream(seed, 0)
     uint32_t regen_min;             // regenerating form: idle lanes it takes to run the camera code (see k_path)
     int32_t gimg_param;             // >= 0: the lanes' gradient sums of this parameter also leave per pixel (gradient image)
@@ -599,7 +599,7 @@ __device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, 
         path_bounce<R, SPEC, 0, 0, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, nd, next_rr, next_cap, live, g1, ra, rb, T, L,
                                               none, alive, capped, on_light, light, &v);
         // the roulette of the next depth is drawn unless a user cap ends the path first (pathtracer.hpp:128 behind the cap test)
-        const uint32_t rr_drawn = (next_rr && (!next_cap || a.cap_is_roulette)) ? 1u : 0u;
+        const uint32_t rr_drawn = (next_rr && (!next_cap || a.cap_draws)) ? 1u : 0u;
         if (live) {
             if (!any_vertex && v.hit) {
                 first = v;
@@ -676,7 +676,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
         __syncthreads();
     }
     // is the roulette of depth d drawn at all?  (not behind a user cap: the reference tests the cap first)
-    auto rr_drawn = [&](int d) { return d >= a.min_bounces && (d < a.depth_cap || a.cap_is_roulette != 0); };
+    auto rr_drawn = [&](int d) { return d >= a.min_bounces && (d < a.depth_cap || a.cap_draws != 0); };
 
     if (range < a.n_ranges) {
         for (uint32_t sl = s_begin; sl < s_end; ++sl) {

@@ -454,6 +454,7 @@ void shard_args(Shard<R>& s)
     a.min_bounces = rp->min_bounces;
     a.depth_cap = s.D;
     a.cap_is_roulette = (rp->absorb >= 1.0 && rp->min_bounces == s.D) ? 1 : 0;
+    a.cap_draws = (a.cap_is_roulette || rp->max_depth <= 0) ? 1 : 0;
     a.absorb = rp->absorb;
     a.seed = rp->seed;
     a.rng_stream = drt_rng_stream(rp->seed, 0u);
@@ -494,7 +495,7 @@ int path_batch(Shard<R>& s)
     pa.spr = s.path_spr < a.Sb ? s.path_spr : a.Sb;
     pa.n_ranges = (a.Sb + pa.spr - 1) / pa.spr;
     pa.n_groups = (a.Pb + DRT_WAVE - 1) / DRT_WAVE;
-    pa.min_bounces = a.min_bounces; pa.depth_cap = a.depth_cap; pa.cap_is_roulette = a.cap_is_roulette;
+    pa.min_bounces = a.min_bounces; pa.depth_cap = a.depth_cap; pa.cap_is_roulette = a.cap_is_roulette; pa.cap_draws = a.cap_draws;
     pa.rr_threshold = a.rr_threshold; pa.seed = a.seed; pa.rng_stream = a.rng_stream;
     pa.regen_min = (uint32_t)tuning().path_regen_min;
     pa.p_rr = 1.0 - rp->absorb;
@@ -785,9 +786,12 @@ int adjoint_rounds(Shard<R>& s)
         if (!chains_done)
             if ((rc = bounce_loop<R>(s, sd, sd & 1, false, s.cs.nx_a, s.cs.nx_b, s.cs.nx_hit, sd, (const uint32_t*)s.cs.dbase, sd,
                                      &sfx_read, &sfx_written)) != DRT_OK) return rc;
+        // (rows sd .. D - 1: the suffix's segments; row D: the suffixes a user cap cut short -- capped_paths counts every walk
+        //  the cap ended, the camera paths' and the suffixes', like the one-launch kernel does)
         if (sd < D)
             hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, s.counts + (size_t)sd * s.max_regions,
-                               (uint32_t)((size_t)(D - sd) * s.max_regions), s.totals, (uint32_t)s.max_regions, sfx_read, sfx_written, 0xFFFFFFFFu);
+                               (uint32_t)((size_t)(D + 1 - sd) * s.max_regions), s.totals, (uint32_t)s.max_regions, sfx_read, sfx_written,
+                               (uint32_t)(D - sd));
 #define DRT_LAUNCH_ADJ_ACC(NP)                                                                                           \
     hipLaunchKernelGGL((k_adj_accumulate<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r, s.d_scene, s.d_params, \
                        s.tape, s.nv, s.cs, s.gpart, s.grad, s.g_rows, s.g_stride)
@@ -795,6 +799,21 @@ int adjoint_rounds(Shard<R>& s)
         else if (ctx->n_params <= 8) DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_ACC(8));
         else DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_ACC(0));
 #undef DRT_LAUNCH_ADJ_ACC
+        if (tuning().dump_path >= 0 && (size_t)tuning().dump_path < a.n_paths) {      // debugging aid (DRT_HIP_DUMP_PATH)
+            const size_t i = (size_t)tuning().dump_path;
+            (void)hipStreamSynchronize(ctx->stream);
+            uint32_t k_nv = 0, nd = 0, db = 0;
+            HitRec<R> hn, hc;
+            R4 gg;
+            (void)hipMemcpy(&k_nv, s.nv + i, sizeof k_nv, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&nd, s.cs.ndraw + i, sizeof nd, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&db, s.cs.dbase + i, sizeof db, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&hn, s.cs.nx_hit + i, sizeof hn, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&hc, s.cs.cv_hit + i, sizeof hc, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&gg, s.cs.g + i, sizeof gg, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[drt_hip] path %zu round %d: chain prim %d, suffix base %u, nv %u (= %d suffix vertices), draws after %u, next prim %d t %.9g, g' = %.9g %.9g %.9g\n",
+                    i, r, hc.prim, db, k_nv, (int)k_nv - (r + 1), nd, hn.prim, (double)hn.t, (double)gg.x, (double)gg.y, (double)gg.z);
+        }
         std::swap(s.cs.cv_a, s.cs.nx_a);                // the suffix's first vertex is the chain's next one
         std::swap(s.cs.cv_b, s.cs.nx_b);
         std::swap(s.cs.cv_hit, s.cs.nx_hit);

@@ -222,7 +222,11 @@ typedef struct drt_hip_stats {
     uint64_t queue_rays_read;       /* rays the shade launches read from the queue (a fused launch keeps a ray */
     uint64_t queue_rays_written;    /* in registers over several bounces) / survivors they wrote back: 32 B each */
     uint64_t capped_paths;          /* paths still alive when they reached max_depth (cut short: 0 when the cap is
-                                       the roulette's own certain kill, absorb == 1 at min_bounces) */
+                                       the roulette's own certain kill, absorb == 1 at min_bounces); under
+                                       DRT_RENDER_UNBIASED every walk counts, the camera paths' and the suffixes'.
+                                       Without a user max_depth the limit is DRT_MAX_DEPTH and a path whose roulette
+                                       ends it AT that depth is not cut short: its draw is consumed as the reference
+                                       consumes it, and with capped_paths == 0 the render is the reference's */
     uint64_t bvh_bytes;             /* mesh scenes: bytes of the BVH (nodes + triangle records) the walk reads from */
     uint64_t path_bytes;            /* k_path launches: the bytes they write (per-range pixel sums, per-block gradient
                                        partials, per-wave counters) -- everything that kernel moves through HBM */

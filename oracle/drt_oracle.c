@@ -11,6 +11,7 @@
 #include "drt_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -382,6 +383,7 @@ static int walk(walk_ctx* w, v3 orig, v3 dir, int depth, vertex_t* vtx, v3* L)
         }
         const int shape = hit.shape;
         if (zero_dir) w->st.zero_dir_segments++; else w->st.segments++;
+        if (!zero_dir && (uint64_t)depth + 1 > w->st.deepest) w->st.deepest = (uint64_t)depth + 1;
         if (w->logging && w->nvlog < w->max_vertices) {
             drt_oracle_vertex* Lg = &w->vertices[w->nvlog++];
             memset(Lg, 0, sizeof *Lg);
@@ -558,7 +560,11 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                             v3 dir_out = bxdf_sample(m, cur.normal, cur.dir_in, &w.rng, &q);
                             vertex_eval(scene, &cur, dir_out);
                             v3 Ls;
+                            const uint32_t draw_before = (uint32_t)w.rng.draw;
                             int nv2 = walk(&w, v3_add(cur.point, v3_scale(dir_out, 1e-3)), dir_out, depth + 1, vtx2, &Ls);
+                            if (getenv("DRT_ORACLE_TRACE_PATH") && (uint64_t)atoll(getenv("DRT_ORACLE_TRACE_PATH")) == path)
+                                fprintf(stderr, "[oracle] path %llu round %d: theta draw %u, suffix base %u, %d suffix vertices, draws after %u, g = %.9g %.9g %.9g, L' = %.9g %.9g %.9g\n",
+                                        (unsigned long long)path, depth, draw_before - 2, draw_before, nv2, (unsigned)w.rng.draw, g.v[0], g.v[1], g.v[2], Ls.v[0], Ls.v[1], Ls.v[2]);
                             v3 seed = v3_div(g1, q);                   /* grad / pdf, integrate.hpp:17 */
                             v3 g3 = v3_scale(seed, cur.c);             /* ScalarMulBackward */
                             if (wants_grad(scene, cur.color_param)) {

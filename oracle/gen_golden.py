@@ -138,6 +138,15 @@ SMALL = [
          absorb=0.3, seed=17, loss_l2=True, target_seed=6),
     dict(name="l5_loss_l2_specular_40x32x6_rr", scene="cornell_specular", width=40, height=32, spp=6, min_bounces=1,
          absorb=0.5, seed=18, loss_l2=True, target_seed=7),
+    # unbiased operator, long roulette chains: renders in which the deepest trace() stands exactly at depth 64 -- the library's
+    # limit on path vertices (DRT_MAX_DEPTH) -- and the reference's roulette ends the path THERE: the device consumes that draw
+    # like the reference does and every later suffix stays in step (found by the long fuzz of round 4: before, 20 rays differed)
+    dict(name="u7_unbiased_cornell_12x10x4_depth64", scene="cornell", width=12, height=10, spp=4, min_bounces=0,
+         absorb=0.17, seed=253, unbiased=True),
+    dict(name="u8_unbiased_specular_12x10x4_depth64", scene="cornell_specular", width=12, height=10, spp=4, min_bounces=0,
+         absorb=0.17, seed=289, unbiased=True),
+    dict(name="u9_unbiased_mesh10x12f5_29x28x3_depth64", scene="mesh10x12f5", width=29, height=28, spp=3, min_bounces=4,
+         absorb=0.2, seed=66973654, unbiased=True),
 ]
 BIG = [
     dict(name="c1_cornell_256x256x8_d4", scene="cornell", width=256, height=256, spp=8,

@@ -436,6 +436,31 @@ def test_unbiased_backward_matches_reference(pkg, hip, name):
     np.testing.assert_array_equal(grads, grads2)
 
 
+from conftest import DEPTH_LIMIT_GOLDENS  # noqa: E402
+
+
+@pytest.mark.parametrize("name", DEPTH_LIMIT_GOLDENS)
+def test_unbiased_chains_that_end_at_the_depth_limit_stay_in_step_with_the_reference(pkg, hip, name):
+    """The library ends paths at 64 vertices (DRT_MAX_DEPTH); the reference has no limit.  Where the reference's own roulette
+    ends a path exactly THERE -- depth 64: its trace() draws, and the draw kills -- nothing is cut short (capped_paths == 0)
+    and the device must consume that draw too, or every later suffix of the chain draws other numbers (found by the long
+    fuzz of round 4: 20 rays of one path in 92,667).  Fixtures from the reference's own integrate(..., unbiased=true)."""
+    import dataclasses
+    g = load_golden(name)
+    scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
+    hip.upload_scene(scene)
+    for nb in (0, 1):                                      # the one-launch kernel (analytic scenes) and the adjoint-round wavefront
+        _, grads, st = hip.render(cam, dataclasses.replace(rp, bounces_per_launch=nb), backward=True, adjoint=adjoint, f64=True, unbiased=True)
+        assert st["capped_paths"] == 0
+        assert st["segments"] == int(g["segments"])
+        assert grad_rel_err(grads, g["grads"]) < 1e-9
+        assert st["kernels"]["path"]["launches"] == (1 if nb == 0 and "mesh" not in name else 0)
+    # f32: chains this long are chaotic (a rounding difference grows with every bounce off a sphere): finite, and close
+    _, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, unbiased=True)
+    assert np.isfinite(grads).all() and abs(st["segments"] - int(g["segments"])) <= 0.02 * int(g["segments"])
+    assert grad_rel_err(grads, g["grads"]) <= 1e-3
+
+
 def test_unbiased_and_biased_gradients_agree_statistically(pkg, hip):
     """Two estimators of the same derivative: at 256x256x16 they agree within Monte-Carlo noise."""
     scene = pkg.cornell_box()
