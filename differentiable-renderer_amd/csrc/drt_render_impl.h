@@ -247,7 +247,7 @@ void shard_plan(Shard<R>& s)
     // its next sample at once) otherwise: roulette-terminated paths under the default cap of 64, the reference's own
     // defaults (-b 1 -p 0.5).
     s.use_path = s.can_fuse && ctx->prog_ok && D > 0 && (!(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) &&
-                 rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path < 0;
+                 rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path == -1;
     s.path_regen = tuning().path_regen > 0;
     if (s.unbiased)
         s.path_regen = false;                  // (k_path_unbiased walks its samples in lockstep)
@@ -799,20 +799,27 @@ int adjoint_rounds(Shard<R>& s)
         else if (ctx->n_params <= 8) DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_ACC(8));
         else DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_ACC(0));
 #undef DRT_LAUNCH_ADJ_ACC
-        if (tuning().dump_path >= 0 && (size_t)tuning().dump_path < a.n_paths) {      // debugging aid (DRT_HIP_DUMP_PATH)
-            const size_t i = (size_t)tuning().dump_path;
+        if (tuning().dump_path >= -2 && tuning().dump_path != -1) {       // debugging aid (DRT_HIP_DUMP_PATH = <path of the batch> | -2: every path)
             (void)hipStreamSynchronize(ctx->stream);
-            uint32_t k_nv = 0, nd = 0, db = 0;
-            HitRec<R> hn, hc;
-            R4 gg;
-            (void)hipMemcpy(&k_nv, s.nv + i, sizeof k_nv, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&nd, s.cs.ndraw + i, sizeof nd, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&db, s.cs.dbase + i, sizeof db, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&hn, s.cs.nx_hit + i, sizeof hn, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&hc, s.cs.cv_hit + i, sizeof hc, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&gg, s.cs.g + i, sizeof gg, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[drt_hip] path %zu round %d: chain prim %d, suffix base %u, nv %u (= %d suffix vertices), draws after %u, next prim %d t %.9g, g' = %.9g %.9g %.9g\n",
-                    i, r, hc.prim, db, k_nv, (int)k_nv - (r + 1), nd, hn.prim, (double)hn.t, (double)gg.x, (double)gg.y, (double)gg.z);
+            const size_t first = tuning().dump_path >= 0 ? (size_t)tuning().dump_path : 0;
+            const size_t last = tuning().dump_path >= 0 ? first + 1 : (a.n_paths <= 8192 ? (size_t)a.n_paths : 0);
+            for (size_t i = first; i < last && i < a.n_paths; ++i) {
+                uint32_t k_nv = 0, nd = 0, db = 0;
+                HitRec<R> hn, hc;
+                R4 gg;
+                (void)hipMemcpy(&hc, s.cs.cv_hit + i, sizeof hc, hipMemcpyDeviceToHost);
+                if (hc.prim < 0)
+                    continue;                                   // (the chain of this path has ended)
+                (void)hipMemcpy(&k_nv, s.nv + i, sizeof k_nv, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&nd, s.cs.ndraw + i, sizeof nd, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&db, s.cs.dbase + i, sizeof db, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&hn, s.cs.nx_hit + i, sizeof hn, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&gg, s.cs.g + i, sizeof gg, hipMemcpyDeviceToHost);
+                const uint32_t ids_ = 0;
+                (void)ids_;
+                fprintf(stderr, "[drt_hip] path %zu (pixel %u sample %u) round %d: chain prim %d, suffix base %u, %d suffix vertices, draws after %u, next prim %d\n",
+                        i, (unsigned)(i % a.Pb), (unsigned)(i / a.Pb), r, hc.prim, db, (int)k_nv - (r + 1), nd, hn.prim);
+            }
         }
         std::swap(s.cs.cv_a, s.cs.nx_a);                // the suffix's first vertex is the chain's next one
         std::swap(s.cs.cv_b, s.cs.nx_b);

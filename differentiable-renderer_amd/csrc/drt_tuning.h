@@ -33,7 +33,7 @@ struct Tuning {
     bool async_copy_inline = false;// DRT_HIP_ASYNC_COPY       inline: asynchronous frames on ONE stream, the finishing kernels store into the pinned block
     bool group_threads = true;     // DRT_HIP_GROUP_THREADS    0: a group context's members enqueue in turn, not from a thread each
     // ---- debugging
-    long long dump_path = -1;      // DRT_HIP_DUMP_PATH        print the tape of this path of the last batch (queue route)
+    long long dump_path = -1;      // DRT_HIP_DUMP_PATH        print the tape of this path of the last batch (queue route) and, under the unbiased operator, its chain round by round; -2: every path's chain
 };
 
 inline const Tuning& tuning()

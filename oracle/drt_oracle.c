@@ -562,7 +562,7 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
                             v3 Ls;
                             const uint32_t draw_before = (uint32_t)w.rng.draw;
                             int nv2 = walk(&w, v3_add(cur.point, v3_scale(dir_out, 1e-3)), dir_out, depth + 1, vtx2, &Ls);
-                            if (getenv("DRT_ORACLE_TRACE_PATH") && (uint64_t)atoll(getenv("DRT_ORACLE_TRACE_PATH")) == path)
+                            if (getenv("DRT_ORACLE_TRACE_PATH") && (atoll(getenv("DRT_ORACLE_TRACE_PATH")) == -2 || (uint64_t)atoll(getenv("DRT_ORACLE_TRACE_PATH")) == path))
                                 fprintf(stderr, "[oracle] path %llu round %d: theta draw %u, suffix base %u, %d suffix vertices, draws after %u, g = %.9g %.9g %.9g, L' = %.9g %.9g %.9g\n",
                                         (unsigned long long)path, depth, draw_before - 2, draw_before, nv2, (unsigned)w.rng.draw, g.v[0], g.v[1], g.v[2], Ls.v[0], Ls.v[1], Ls.v[2]);
                             v3 seed = v3_div(g1, q);                   /* grad / pdf, integrate.hpp:17 */
