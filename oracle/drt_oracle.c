@@ -366,8 +366,11 @@ static int walk(walk_ctx* w, v3 orig, v3 dir, int depth, vertex_t* vtx, v3* L)
     const drt_render_params* rp = w->rp;
     int nv = 0;
     for (;;) {
-        if (w->max_depth && depth >= w->max_depth)
-            break; /* extension, not in the reference */
+        /* extension, not in the reference: a user cap is tested BEFORE the roulette (no draw at the cap) -- unless the roulette
+         * of this depth ends the path with certainty anyway (absorb == 1 at or beyond min_bounces): then the cap cuts nothing,
+         * the draw is consumed as the reference consumes it, and the render is the reference's (drt_hip.h: max_depth) */
+        if (w->max_depth && depth >= w->max_depth && !(rp->absorb >= 1.0 && depth >= rp->min_bounces))
+            break;
         if (depth >= rp->min_bounces && rng_uniform(&w->rng) < rp->absorb)
             break;
         double p = depth >= rp->min_bounces ? (1 - rp->absorb) : 1;

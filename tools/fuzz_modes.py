@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random render configurations through every route of the library (run on the GPU box): each must finish, be finite,
 and the one-launch kernels (k_path, its regenerating, 8-parameter, gradient-image and unbiased forms) must agree with
-the queue wavefront (bounces_per_launch = 1) in the f64 mode to 1e-9 with identical segment counts.
+the queue wavefront (bounces_per_launch = 1) in the f64 mode to 1e-9 with identical segment counts -- and both with the CPU
+restatement of the reference (oracle/), which knows the library's extensions (max_depth, shards); a third of the biased cases
+also run the per-sample squared-error loss and a gradient image against it.
 Usage: tools/fuzz_modes.py [n_cases] [seed]"""
 import dataclasses
 import sys
@@ -13,6 +15,7 @@ sys.path.insert(0, '.')
 import __graft_entry__ as e
 
 pkg = e.load_package()
+oracle = e.load_oracle()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = pkg.HipRenderer(0)
@@ -65,7 +68,35 @@ for case in range(n_cases):
     assert err < (1e-9 if a[2]["segments"] == q[2]["segments"] else 1e-6), (case, name, kw, unbiased, err)
     np.testing.assert_allclose(a[0], q[0], rtol=1e-6, atol=1e-9)
     assert a[2]["capped_paths"] == q[2]["capped_paths"] or a[2]["segments"] != q[2]["segments"], (case, name, kw, a[2]["capped_paths"], q[2]["capped_paths"])
+    # ... and both against the CPU restatement of the reference (which knows the extensions: max_depth, shards): ray counts
+    # and gradients, wherever no path was cut short by the library's own depth limit and no chain is chaotic
+    o = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, unbiased=unbiased, zero_dir_miss=unbiased)
+    oscale = max(1e-300, float(np.abs(o["grads"]).max()))
+    limit_hit = md == 0 and o["stats"]["deepest"] > 64
+    if not limit_hit and not (unbiased and o["stats"]["deepest"] >= 40):
+        assert q[2]["segments"] == o["stats"]["segments"], (case, name, kw, unbiased, q[2]["segments"], o["stats"]["segments"])
+        assert float(np.abs(q[1] - o["grads"]).max() / oscale) < 1e-9, (case, name, kw, unbiased)
+        np.testing.assert_allclose(q[0], o["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    # a per-sample squared-error loss and the gradient image, where the render allows them (biased operator)
+    extra = ""
+    if not unbiased and rs.rand() < 0.3:
+        target = rs.uniform(0.0, 0.8, (h, w, 3)).astype(np.float32)
+        gl = r.render(cam, rp, backward=True, f64=True, adjoint=target, loss_l2=True)
+        ol = oracle.render(scene, cam, rp, backward=True, adjoint=target, loss_l2=True)
+        if not limit_hit:
+            el = float(np.abs(gl[1] - ol["grads"]).max() / max(1e-300, float(np.abs(ol["grads"]).max())))
+            assert el < 1e-9, (case, name, kw, "loss_l2", el)
+        assert np.isfinite(r.render(cam, rp, backward=True, adjoint=target, loss_l2=True)[1]).all()
+        extra += " l2"
+    if not unbiased and n_sh == 1 and rs.rand() < 0.3:
+        gp = int(rs.randint(scene.n_params))
+        gi = r.render_gradient_image(cam, rp, gp, adjoint=adjoint, f64=True)
+        og = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, grad_image_param=gp)
+        if not limit_hit:
+            gs = max(1e-300, float(np.abs(og["grad_image"]).max()))
+            assert float(np.abs(gi[1] - og["grad_image"]).max() / gs) < 1e-6, (case, name, kw, "gradient image", gp)
+        extra += f" gimg{gp}"
     route = "path" if a[2]["kernels"]["path"]["launches"] else "queue"
     print(f"{case:3d} {name:22s} {w:3d}x{h:<3d} spp {kw['spp']:2d} b{b} p{p:g} md{md:<2d} shards {n_sh} {'unb' if unbiased else 'bia'} "
-          f"{'adj' if adjoint is not None else '   '} {route:5s} seg {a[2]['segments']:8d} err {err:.1e}  {dt * 1e3:6.0f} ms", flush=True)
+          f"{'adj' if adjoint is not None else '   '}{extra} {route:5s} seg {a[2]['segments']:8d} err {err:.1e}  {dt * 1e3:6.0f} ms", flush=True)
 print(f"FUZZ OK: {n_cases} cases in {time.time() - t0:.0f} s, worst one-launch vs wavefront gradient difference (f64) {worst:.2e}")
