@@ -19,6 +19,12 @@ oracle = e.load_oracle()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 r = pkg.HipRenderer(0)
+# f32: the run-time (kind-sorted) hit program against the compiled-in one -- the library's own for the reference's topology,
+# hiprtc's for every other analytic scene -- must agree in every bit (tests/test_gpu_jit.py on fixed cases; here on random ones)
+rg, rj = pkg.HipRenderer(0), pkg.HipRenderer(0)
+rg.set_specialisation(pkg.SPECIALISE_GENERIC)
+rj.set_specialisation(pkg.SPECIALISE_NOW)
+n_bitwise = 0
 scenes = ["cornell", "cornell_specular", "cornell_walls", "cornell_emissive_wall", "cornell_mirror_wall", "random3", "random7",
           "mesh6x8", "mesh10x12f5"]
 worst = 0.0
@@ -96,7 +102,17 @@ for case in range(n_cases):
             gs = max(1e-300, float(np.abs(og["grad_image"]).max()))
             assert float(np.abs(gi[1] - og["grad_image"]).max() / gs) < 1e-6, (case, name, kw, "gradient image", gp)
         extra += f" gimg{gp}"
+    if not name.startswith("mesh") and "bounces_per_launch" not in kw:
+        rg.upload_scene(scene); rj.upload_scene(scene)
+        fg = rg.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
+        fj = rj.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
+        if fg[2]["kernels"]["path"]["launches"]:
+            assert fg[2]["path_program"] == "sorted" and fj[2]["path_program"] in ("specialised", "builtin"), (case, name, fg[2]["path_program"], fj[2]["path_program"])
+            assert np.array_equal(fg[0], fj[0]) and np.array_equal(fg[1], fj[1]) and fg[2]["segments"] == fj[2]["segments"], (case, name, kw, unbiased, "sorted vs compiled-in program")
+            n_bitwise += 1
+            extra += " =" + fj[2]["path_program"][:4]
     route = "path" if a[2]["kernels"]["path"]["launches"] else "queue"
     print(f"{case:3d} {name:22s} {w:3d}x{h:<3d} spp {kw['spp']:2d} b{b} p{p:g} md{md:<2d} shards {n_sh} {'unb' if unbiased else 'bia'} "
           f"{'adj' if adjoint is not None else '   '}{extra} {route:5s} seg {a[2]['segments']:8d} err {err:.1e}  {dt * 1e3:6.0f} ms", flush=True)
-print(f"FUZZ OK: {n_cases} cases in {time.time() - t0:.0f} s, worst one-launch vs wavefront gradient difference (f64) {worst:.2e}")
+print(f"FUZZ OK: {n_cases} cases in {time.time() - t0:.0f} s, worst one-launch vs wavefront gradient difference (f64) {worst:.2e}; "
+      f"{n_bitwise} f32 renders bit-identical between the run-time and the compiled-in hit program")
