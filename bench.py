@@ -170,6 +170,14 @@ def main():
         torch.cuda.set_device(local_rank)
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # The process group runs its first collective NOW, before this rank's render context makes its streams.  Measured
+            # (tools/allreduce_overlap.py, one rank): with the context created between init_process_group and the group's
+            # first collective, the path kernels of consecutive frames never ran side by side -- 0.716 ms per frame instead
+            # of 0.658, in-library all-reduce or not; with one collective first, 0.658 in every mode.  (HIP deals streams to
+            # hardware queues as they come; RCCL's own arrive with the first collective.)  INTEGRATION.md section 4 says so.
+            first = torch.ones(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(first)
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(a.dist_backend)
 
@@ -231,10 +239,13 @@ def main():
         return st
 
     def fence():
+        """device work of this rank done, then every rank here -> the time at which THIS rank's work was done"""
         r.synchronize()
         torch.cuda.synchronize(dev)
+        t_done = time.perf_counter()
         if use_dist:
             dist.barrier()
+        return t_done
 
     # Setup, before the W warm-up steps: the device comes out of idle at low clocks and takes some tens of milliseconds of
     # load to reach its operating point (measured on config 3, ms per frame over 5 / 10 / 20 frames from a cold start: 0.865 /
@@ -266,8 +277,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # The K steps stand between a barrier + device synchronisation on either side; a rank's time runs from the opening
+    # barrier to the moment ITS device work is done, and the MAX over the ranks is the job's time -- the closing barrier's own
+    # latency (a host round trip through the process group: ~1 ms here, 8 % of twenty 0.66-ms steps) is not rendering time.
+    elapsed = fence() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -722,7 +735,6 @@ def main():
             "preheat_ms": a.preheat_ms, "preheat_frames": preheat_frames,
             "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view, "two_contexts": two_ctx_view,
         }
-        print(json.dumps(line), flush=True)
     # teardown in the same order on every rank: the library's communicator first (all ranks are still here), then the
     # launcher's process group, then the context
     r.synchronize()
@@ -732,6 +744,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     r.close()
+    if rank == 0:
+        # the ONE line, and the LAST one of this rank's stdout: RCCL writes its version banner through C stdio, which keeps it
+        # in a buffer until the process ends when stdout is a pipe -- flushed here, before the line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
