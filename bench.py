@@ -173,8 +173,8 @@ def main():
             # The process group runs its first collective NOW, before this rank's render context makes its streams.  Measured
             # (tools/allreduce_overlap.py, one rank): with the context created between init_process_group and the group's
             # first collective, the path kernels of consecutive frames never ran side by side -- 0.716 ms per frame instead
-            # of 0.658, in-library all-reduce or not; with one collective first, 0.658 in every mode.  (HIP deals streams to
-            # hardware queues as they come; RCCL's own arrive with the first collective.)  INTEGRATION.md section 4 says so.
+            # of 0.658, in-library all-reduce or not; with one collective first, 0.658 in every mode.  (Why is not known:
+            # making the context's streams anew after the collective changes nothing.)  INTEGRATION.md section 3 says so.
             first = torch.ones(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(first)
             torch.cuda.synchronize()
