@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Frames per second of device-pointer renders with and without the in-library all-reduce (a 1-rank communicator on a
-single-GPU box): does the collective of frame i keep frame i + 1's path kernel from overlapping?"""
+single-GPU box): does the collective of frame i keep frame i + 1's path kernel from overlapping?  (No.)  And the launch-order
+effect of a torch.distributed process group in the same process:
+    tools/allreduce_overlap.py                                          no process group
+    tools/allreduce_overlap.py --torch-dist-eager                       group and its first collective, then the context: fast
+    tools/allreduce_overlap.py --torch-dist-eager --context-first       context, then the group: fast
+    tools/allreduce_overlap.py --torch-dist-eager --context-between     group, context, THEN the group's first collective: frames no longer overlap"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -20,8 +25,11 @@ if len(sys.argv) > 1:                  # --torch-dist: with torch.distributed's 
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("nccl")
+    BETWEEN = len(sys.argv) > 2 and sys.argv[2] == "--context-between"   # the slow order: group made, context made, THEN the group's first collective
+    if BETWEEN:
+        r0 = pkg.HipRenderer(0); r0.upload_scene(pkg.cornell_box()); LATE = True
     t = torch.ones(4, device="cuda"); dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
-    print("torch.distributed initialised:", sys.argv[1])
+    print("torch.distributed initialised:", sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", flush=True)
 r = r0 if LATE else pkg.HipRenderer(0)
 r.upload_scene(pkg.cornell_box())
 r.comm_init(pkg.comm_unique_id(), 0, 1)

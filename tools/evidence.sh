@@ -47,6 +47,10 @@ python3 tools/fuzz_reference.py 150 11 > "$E/fuzz_vs_reference.txt" 2>&1
 python3 tools/fuzz_overlap.py 300 1 2>&1 | grep -v amdgpu > "$E/fuzz_overlap.txt"
 (echo "## frames overlapping (default)"; python3 tools/one_ctx_frames.py 2>&1 | grep -v amdgpu; echo "## DRT_HIP_OVERLAP_FRAMES=0"; DRT_HIP_OVERLAP_FRAMES=0 python3 tools/one_ctx_frames.py 2>&1 | grep -v amdgpu) > "$E/one_ctx_frames.txt"
 python3 tools/two_frames.py cornell 2>&1 | grep -v amdgpu > "$E/two_frames.txt"
+(python3 tools/jit_background.py random11; python3 tools/jit_background.py random5) 2>&1 | grep -v amdgpu > "$E/jit_background.txt"
+python3 tools/small_frames.py 2>&1 | grep -v amdgpu > "$E/small_frames.txt"
+(timeout 300 python3 tools/allreduce_overlap.py; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager --context-between) 2>&1 | grep "ms per frame\|initialised" > "$E/launch_order.txt"
+(timeout 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{") > "$E/bench_1rank_under_torchrun.json"
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
 [ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
 for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh ${T}_fwd; do

@@ -63,7 +63,9 @@ for case in range(n_cases):
     # (a path the depth limit cut short is reported -- capped_paths -- and its share of the gradient is missing or, under the
     #  unbiased operator, drawn from other numbers from there on: one path of a heavy-tailed scene can be 1e-4 of a gradient)
     assert e64 < (1e-9 if capped == 0 else 1e-3), (case, name, rp, unbiased, e64, capped)
-    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    # (per pixel: with a weak roulette some paths run to forty vertices and more, where host and device no longer stand on
+    #  the same point to better than 1e-5 -- see `chaotic` above -- and what such a vertex adds to its pixel carries that)
+    np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12 if p > 0.35 else 1e-6 * float(ref["image"].max()))
     assert np.isfinite(img32).all() and np.isfinite(g32).all()
     worst64, worst32 = max(worst64, e64), max(worst32, e32)
     print(f"{case:3d} {name:22s} {w:3d}x{h:<3d} spp {rp.spp:2d} b{b} p{p:g} {'unb' if unbiased else 'bia'} "
