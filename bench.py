@@ -31,6 +31,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The path kernels of consecutive frames overlap on two streams of the render context, and HIP shares its hardware queues
+# among ALL streams of the process: four by default.  A torch.distributed RCCL process group brings streams of its own, and
+# with the context made between the group's creation and its first collective two of the context's streams ended up on one
+# queue -- frames in stream order, 0.716 instead of 0.658 ms (tools/allreduce_overlap.py --torch-dist-eager --context-between:
+# 0.716 with 2 or 4 queues, 0.657 with 8 or 16; every other workload of this file measures the same with 4 and 8).  Read by
+# the HIP runtime when it starts, so it is set before torch is imported; a value from the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6200.0        # measured float4 copy on the pool's boxes (profiles/r01_microbench_stream_roofs.txt; guide: 6.29)
 # vector-instruction issue: a wave64 VALU op takes 2 cycles of its SIMD; 256 CUs x 4 SIMDs at 2.4 GHz
@@ -173,8 +181,9 @@ def main():
             # The process group runs its first collective NOW, before this rank's render context makes its streams.  Measured
             # (tools/allreduce_overlap.py, one rank): with the context created between init_process_group and the group's
             # first collective, the path kernels of consecutive frames never ran side by side -- 0.716 ms per frame instead
-            # of 0.658, in-library all-reduce or not; with one collective first, 0.658 in every mode.  (Why is not known:
-            # making the context's streams anew after the collective changes nothing.)  INTEGRATION.md section 3 says so.
+            # of 0.658, in-library all-reduce or not; with one collective first, 0.658 in every mode.  (Two of the context's
+            # streams then share one of HIP's four hardware queues; GPU_MAX_HW_QUEUES=8, set at the top of this file, removes
+            # the effect by itself -- both are kept.)  INTEGRATION.md section 3 says so.
             first = torch.ones(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(first)
             torch.cuda.synchronize()
