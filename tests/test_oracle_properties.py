@@ -143,3 +143,22 @@ def test_max_depth_cap_equals_absorb_one(pkg, oracle):
     b = oracle.render(scene, cam, pkg.RenderParams(spp=4, min_bounces=99, absorb=0.5, max_depth=5, seed=4), backward=True)
     np.testing.assert_array_equal(a["image"], b["image"])
     np.testing.assert_array_equal(a["grads"], b["grads"])
+
+
+def test_a_cap_where_the_roulette_ends_every_path_anyway_is_transparent(pkg, oracle):
+    """A user max_depth at or beyond min_bounces with absorb == 1 cuts nothing: the roulette of that depth ends the path with
+    certainty and consumes its draw, as in the reference, which has no cap -- under the unbiased operator, where every later
+    suffix of a chain depends on how many numbers were drawn before, the capped render is the uncapped one (round 4's route
+    fuzz found the restatement skipping that draw; the device never did)."""
+    scene = pkg.scene_by_name("cornell_mirror_wall")
+    cam = pkg.cornell_camera(24, 18)
+    free = oracle.render(scene, cam, pkg.RenderParams(spp=3, min_bounces=3, absorb=1.0, seed=294368374), backward=True, unbiased=True,
+                         zero_dir_miss=True)
+    for cap in (3, 4, 9):
+        capped = oracle.render(scene, cam, pkg.RenderParams(spp=3, min_bounces=3, absorb=1.0, seed=294368374, max_depth=cap),
+                               backward=True, unbiased=True, zero_dir_miss=True)
+        assert capped["stats"]["segments"] == free["stats"]["segments"]
+        np.testing.assert_array_equal(capped["grads"], free["grads"])
+    cut = oracle.render(scene, cam, pkg.RenderParams(spp=3, min_bounces=3, absorb=1.0, seed=294368374, max_depth=2), backward=True,
+                        unbiased=True, zero_dir_miss=True)
+    assert cut["stats"]["segments"] < free["stats"]["segments"] and cut["stats"]["deepest"] == 2 and free["stats"]["deepest"] == 3
