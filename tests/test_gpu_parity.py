@@ -461,6 +461,22 @@ def test_unbiased_chains_that_end_at_the_depth_limit_stay_in_step_with_the_refer
     assert grad_rel_err(grads, g["grads"]) <= 1e-3
 
 
+def test_a_cap_where_the_roulette_ends_every_path_anyway_changes_nothing(pkg, hip):
+    """max_depth at or beyond min_bounces with absorb == 1: the roulette ends every path there and its draw is consumed, as in
+    the reference (no cap) -- the unbiased operator's later suffixes draw the same numbers, capped or not, in both routes."""
+    import dataclasses
+    scene = pkg.scene_by_name("cornell_mirror_wall")
+    cam = pkg.cornell_camera(24, 18)
+    hip.upload_scene(scene)
+    for nb in (0, 1):
+        rp = pkg.RenderParams(spp=3, min_bounces=3, absorb=1.0, seed=294368374, bounces_per_launch=nb)
+        _, g0, s0 = hip.render(cam, rp, backward=True, f64=True, unbiased=True)
+        for cap in (3, 5):
+            _, g1, s1 = hip.render(cam, dataclasses.replace(rp, max_depth=cap), backward=True, f64=True, unbiased=True)
+            assert s1["segments"] == s0["segments"] and s1["capped_paths"] == 0
+            np.testing.assert_array_equal(g1, g0)
+
+
 def test_unbiased_and_biased_gradients_agree_statistically(pkg, hip):
     """Two estimators of the same derivative: at 256x256x16 they agree within Monte-Carlo noise."""
     scene = pkg.cornell_box()
