@@ -477,6 +477,24 @@ def test_a_cap_where_the_roulette_ends_every_path_anyway_changes_nothing(pkg, hi
             np.testing.assert_array_equal(g1, g0)
 
 
+def test_absorb_one_ends_every_path_even_where_the_references_draw_is_exactly_one(pkg, hip, oracle):
+    """The one deliberate deviation in a result: rand() == RAND_MAX makes the reference's uniform() 1.0, `1.0 < absorb` fails for
+    absorb == 1, the path goes on with survival probability 0 and is divided by it -- NaN in the reference's image and
+    gradients (tests/test_oracle_properties.py pins that).  The device ends the path: finite, one ray fewer, and every other
+    pixel the reference's."""
+    scene = pkg.scene_by_name("cornell_mirror_wall")
+    cam = pkg.cornell_camera(15, 36)
+    rp = pkg.RenderParams(spp=10, min_bounces=5, absorb=1.0, seed=83368279)
+    o = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    for kw in (dict(f64=True), dict()):
+        img, g, st = hip.render(cam, rp, backward=True, **kw)
+        assert np.isfinite(img).all() and np.isfinite(g).all() and st["capped_paths"] == 0
+        assert st["segments"] == o["stats"]["segments"] - 1
+        ok = np.ones((36, 15), bool); ok[14, 3] = False
+        np.testing.assert_allclose(img[ok], o["image"][ok].astype(np.float32), rtol=2e-7 if kw else 2e-4, atol=1e-12 if kw else 1e-6)
+
+
 def test_unbiased_and_biased_gradients_agree_statistically(pkg, hip):
     """Two estimators of the same derivative: at 256x256x16 they agree within Monte-Carlo noise."""
     scene = pkg.cornell_box()

@@ -162,3 +162,18 @@ def test_a_cap_where_the_roulette_ends_every_path_anyway_is_transparent(pkg, ora
     cut = oracle.render(scene, cam, pkg.RenderParams(spp=3, min_bounces=3, absorb=1.0, seed=294368374, max_depth=2), backward=True,
                         unbiased=True, zero_dir_miss=True)
     assert cut["stats"]["segments"] < free["stats"]["segments"] and cut["stats"]["deepest"] == 2 and free["stats"]["deepest"] == 3
+
+
+def test_a_roulette_draw_of_exactly_one_survives_absorb_one_and_divides_by_zero(pkg, oracle):
+    """random::uniform() is rand() / RAND_MAX: 1.0 when rand() returns RAND_MAX, once in 2^31 draws.  With absorb == 1 such a
+    path passes `uniform() < absorb` at min_bounces, goes on with survival probability p = 1 - absorb = 0 and its radiance is
+    divided by it (pathtracer.hpp:128-133): inf or NaN in the reference -- and in the restatement, which follows it.  The
+    device ends every path at min_bounces when absorb == 1 (finite; tests/test_gpu_parity.py).  Found by round 4's route fuzz:
+    path 2133 of this render draws RAND_MAX at its depth-5 roulette (one frame in 128 of BASELINE config 3 has such a path)."""
+    scene = pkg.scene_by_name("cornell_mirror_wall")
+    cam = pkg.cornell_camera(15, 36)
+    rp = pkg.RenderParams(spp=10, min_bounces=5, absorb=1.0, seed=83368279)
+    assert oracle.rng_u31(rp.seed, 2133, 12) == 2147483647
+    o = oracle.render(scene, cam, rp, backward=True)
+    assert o["stats"]["deepest"] == 6 and not np.isfinite(o["grads"]).all() and not np.isfinite(o["image"][14, 3]).any()
+    assert np.isfinite(np.delete(o["image"].reshape(-1, 3), 14 * 15 + 3, axis=0)).all()

@@ -77,6 +77,11 @@ for case in range(n_cases):
     # ... and both against the CPU restatement of the reference (which knows the extensions: max_depth, shards): ray counts
     # and gradients, wherever no path was cut short by the library's own depth limit and no chain is chaotic
     o = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, unbiased=unbiased, zero_dir_miss=unbiased)
+    if not (np.isfinite(o["grads"]).all() and np.isfinite(o["image"]).all()):
+        # rand() == RAND_MAX at the roulette of an absorb == 1 render: the reference divides by a survival probability of 0
+        # (tests/test_oracle_properties.py); the device ends the path.  Once in 2^31 draws: it happens in a long fuzz.
+        print(f"{case:3d} {name:22s} the reference's result is not finite (a roulette draw of exactly 1 at absorb == 1): skipped", flush=True)
+        continue
     oscale = max(1e-300, float(np.abs(o["grads"]).max()))
     limit_hit = md == 0 and o["stats"]["deepest"] > 64
     if not limit_hit and not (unbiased and o["stats"]["deepest"] >= 40):
