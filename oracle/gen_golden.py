@@ -147,6 +147,11 @@ SMALL = [
          absorb=0.17, seed=289, unbiased=True),
     dict(name="u9_unbiased_mesh10x12f5_29x28x3_depth64", scene="mesh10x12f5", width=29, height=28, spp=3, min_bounces=4,
          absorb=0.2, seed=66973654, unbiased=True),
+    # the reference's uniform() returns exactly 1.0 for path 2133's roulette draw at depth 5 (rand() == RAND_MAX): with absorb == 1
+    # the path survives, p = 1 - absorb = 0, and the reference divides by it -- a NaN pixel and NaN gradients IN THE FIXTURE.
+    # The restatement reproduces that; the device ends the path (the one deliberate deviation)
+    dict(name="q1_nan_mirror_wall_15x36x10_d5", scene="cornell_mirror_wall", width=15, height=36, spp=10, min_bounces=5,
+         absorb=1.0, seed=83368279),
 ]
 BIG = [
     dict(name="c1_cornell_256x256x8_d4", scene="cornell", width=256, height=256, spp=8,

@@ -67,6 +67,8 @@ SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_
 UNBIASED_GOLDENS = ["u1_unbiased_cornell_40x30x4_rr", "u2_unbiased_cornell_48x48x4_d4",
                     "u3_unbiased_specular_32x32x4_adj", "u4_unbiased_emissive_wall_32x24x4",
                     "u5_unbiased_mesh10x12_24x24x3", "u6_unbiased_mirror_32x24x4_rr"]
+# the reference's own NaN: a roulette draw of exactly 1.0 at absorb == 1
+QUIRK_GOLDENS = ["q1_nan_mirror_wall_15x36x10_d5"]
 # long roulette chains under the unbiased operator: the deepest trace() stands exactly at depth 64, the library's limit
 DEPTH_LIMIT_GOLDENS = ["u7_unbiased_cornell_12x10x4_depth64", "u8_unbiased_specular_12x10x4_depth64",
                        "u9_unbiased_mesh10x12f5_29x28x3_depth64"]

@@ -477,22 +477,24 @@ def test_a_cap_where_the_roulette_ends_every_path_anyway_changes_nothing(pkg, hi
             np.testing.assert_array_equal(g1, g0)
 
 
-def test_absorb_one_ends_every_path_even_where_the_references_draw_is_exactly_one(pkg, hip, oracle):
+def test_absorb_one_ends_every_path_even_where_the_references_draw_is_exactly_one(pkg, hip):
     """The one deliberate deviation in a result: rand() == RAND_MAX makes the reference's uniform() 1.0, `1.0 < absorb` fails for
     absorb == 1, the path goes on with survival probability 0 and is divided by it -- NaN in the reference's image and
     gradients (tests/test_oracle_properties.py pins that).  The device ends the path: finite, one ray fewer, and every other
     pixel the reference's."""
-    scene = pkg.scene_by_name("cornell_mirror_wall")
-    cam = pkg.cornell_camera(15, 36)
-    rp = pkg.RenderParams(spp=10, min_bounces=5, absorb=1.0, seed=83368279)
-    o = oracle.render(scene, cam, rp, backward=True)
+    g = load_golden("q1_nan_mirror_wall_15x36x10_d5")       # from the reference itself: NaN at pixel (3, 14), NaN gradients
+    scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
+    assert not np.isfinite(g["image"][14, 3]).any() and not np.isfinite(g["grads"]).all()
     hip.upload_scene(scene)
     for kw in (dict(f64=True), dict()):
-        img, g, st = hip.render(cam, rp, backward=True, **kw)
-        assert np.isfinite(img).all() and np.isfinite(g).all() and st["capped_paths"] == 0
-        assert st["segments"] == o["stats"]["segments"] - 1
+        img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, **kw)
+        assert np.isfinite(img).all() and np.isfinite(grads).all() and st["capped_paths"] == 0
+        assert st["segments"] == int(g["segments"]) - 1
         ok = np.ones((36, 15), bool); ok[14, 3] = False
-        np.testing.assert_allclose(img[ok], o["image"][ok].astype(np.float32), rtol=2e-7 if kw else 2e-4, atol=1e-12 if kw else 1e-6)
+        np.testing.assert_allclose(img[ok], g["image"][ok].astype(np.float32), rtol=2e-7 if kw else 2e-4, atol=1e-12 if kw else 1e-6)
+        # the parameters the path does not touch keep the reference's gradients
+        fin = np.isfinite(g["grads"]).all(1)
+        assert fin.any() and grad_rel_err(grads[fin], g["grads"][fin]) < (1e-9 if kw else 1e-4)
 
 
 def test_unbiased_and_biased_gradients_agree_statistically(pkg, hip):

@@ -4,7 +4,7 @@ keeps the reference's operation order and shares its libm."""
 import numpy as np
 import pytest
 
-from conftest import DEPTH_LIMIT_GOLDENS, LOSS_GOLDENS, SMALL_GOLDENS, UNBIASED_GOLDENS, case_inputs, load_golden
+from conftest import DEPTH_LIMIT_GOLDENS, LOSS_GOLDENS, QUIRK_GOLDENS, SMALL_GOLDENS, UNBIASED_GOLDENS, case_inputs, load_golden
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS + ["g6_libc_64x64x8_d4", "m3_mirror_libc_32x32x4_d4"])
@@ -150,3 +150,18 @@ def test_per_sample_squared_error_loss_bit_exact(pkg, oracle, name):
     # and it is a different thing from the per-pixel seed of the default mode
     lin = oracle.render(scene, cam, rp, backward=True, adjoint=target)
     assert not np.allclose(lin["grads"], r["grads"], rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", QUIRK_GOLDENS)
+def test_the_references_own_nan_is_reproduced(pkg, oracle, name):
+    """A fixture in which THE REFERENCE produced NaN: rand() == RAND_MAX makes uniform() 1.0, the roulette of an absorb == 1
+    render lets the path pass, and the path is divided by its survival probability of 0 (pathtracer.hpp:128-133).  The
+    restatement reproduces the fixture NaN for NaN and bit for bit elsewhere; the device deviates on purpose (it ends the path:
+    tests/test_gpu_parity.py::test_absorb_one_ends_every_path_even_where_the_references_draw_is_exactly_one)."""
+    g = load_golden(name)
+    assert not np.isfinite(g["grads"]).all() and not np.isfinite(g["image"]).all()
+    scene, cam, rp, adjoint = case_inputs(pkg, g["case"])
+    r = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint)
+    np.testing.assert_array_equal(r["image"], g["image"])          # (NaN == NaN for assert_array_equal)
+    np.testing.assert_array_equal(r["grads"], g["grads"])
+    assert r["stats"]["segments"] == int(g["segments"])
