@@ -61,13 +61,19 @@ typedef struct {
     int mode;
     drt_rng_key path_key;
     uint32_t draw;
+    uint64_t extreme;   /* draws that came out as exactly 0 or RAND_MAX */
 } rng_t;
 
 static double rng_uniform(rng_t* r)
 {
     if (r->mode == DRT_ORACLE_RNG_LIBC)
         return (double)rand() / RAND_MAX;
-    return (double)drt_rng_draw(r->path_key, r->draw++) / 2147483647.0;
+    {
+        const uint32_t v = drt_rng_draw(r->path_key, r->draw++);
+        if (v == 0u || v == 2147483647u)
+            r->extreme++;           /* uniform() exactly 0 or 1: the samplers' and the roulette's singular points */
+        return (double)v / 2147483647.0;
+    }
 }
 
 uint32_t drt_oracle_rng_u31(uint32_t seed, uint64_t path, uint32_t n)
@@ -599,6 +605,7 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
         }
     }
     free(vtx);
+    w.st.extreme_draws = w.rng.extreme;
     if (stats)
         *stats = w.st;
     if (n_vertices)

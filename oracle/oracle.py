@@ -42,7 +42,7 @@ def load_pkg():
 
 class OracleStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64),
-                ("zero_dir_segments", C.c_uint64), ("max_vertices", C.c_uint64), ("deepest", C.c_uint64)]
+                ("zero_dir_segments", C.c_uint64), ("max_vertices", C.c_uint64), ("deepest", C.c_uint64), ("extreme_draws", C.c_uint64)]
 
 
 VERTEX_DOUBLES = 16  # path, depth, o[3], d[3], shape, t, p[3], n[3]
@@ -116,7 +116,7 @@ def render(scene, cam, rp, backward: bool = False, adjoint: Optional[np.ndarray]
     return {"image": img, "grads": grads, "grad_image": gimg,
             "stats": {"paths": int(st.paths), "segments": int(st.segments),
                       "zero_dir_segments": int(st.zero_dir_segments),
-                      "max_vertices": int(st.max_vertices), "deepest": int(st.deepest)},
+                      "max_vertices": int(st.max_vertices), "deepest": int(st.deepest), "extreme_draws": int(st.extreme_draws)},
             "vertices": vtx[: nv.value] if vtx is not None else None}
 
 

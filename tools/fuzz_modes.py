@@ -77,14 +77,20 @@ for case in range(n_cases):
     # ... and both against the CPU restatement of the reference (which knows the extensions: max_depth, shards): ray counts
     # and gradients, wherever no path was cut short by the library's own depth limit and no chain is chaotic
     o = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, unbiased=unbiased, zero_dir_miss=unbiased)
-    if not (np.isfinite(o["grads"]).all() and np.isfinite(o["image"]).all()):
-        # rand() == RAND_MAX at the roulette of an absorb == 1 render: the reference divides by a survival probability of 0
-        # (tests/test_oracle_properties.py); the device ends the path.  Once in 2^31 draws: it happens in a long fuzz.
-        print(f"{case:3d} {name:22s} the reference's result is not finite (a roulette draw of exactly 1 at absorb == 1): skipped", flush=True)
+    if o["stats"]["extreme_draws"] or not (np.isfinite(o["grads"]).all() and np.isfinite(o["image"]).all()):
+        # A draw of exactly 0 or RAND_MAX -- uniform() = 0 or 1, once in 2^30 draws -- stands on a singular point of the
+        # reference: the roulette of an absorb == 1 render lets the path live and divides it by a survival probability of 0
+        # (NaN), the diffuse sampler's cos(asin(1)) is the rounding error of pi / 2 and its pdf with it (a pixel of 1e10),
+        # the glossy sampler's pdf is 0.  The device keeps theta draws one step inside the interval and ends the path
+        # (DESIGN.md section 5): nothing to compare on such a render.  It happens in a long fuzz.
+        print(f"{case:3d} {name:22s} a draw of exactly 0 or RAND_MAX ({o['stats']['extreme_draws']}) puts the reference on a singular point: skipped", flush=True)
         continue
     oscale = max(1e-300, float(np.abs(o["grads"]).max()))
     limit_hit = md == 0 and o["stats"]["deepest"] > 64
-    if not limit_hit and not (unbiased and o["stats"]["deepest"] >= 40):
+    # (forty vertices down a path -- biased or unbiased -- host and device no longer stand on the same point to better than
+    #  1e-5, see above: a ray may fall on the other side of an edge there, a few rays differ; such renders only get the
+    #  route-against-route checks)
+    if not limit_hit and not o["stats"]["deepest"] >= 40:
         assert q[2]["segments"] == o["stats"]["segments"], (case, name, kw, unbiased, q[2]["segments"], o["stats"]["segments"])
         assert float(np.abs(q[1] - o["grads"]).max() / oscale) < 1e-9, (case, name, kw, unbiased)
         np.testing.assert_allclose(q[0], o["image"].astype(np.float32), rtol=2e-7, atol=1e-12 if p > 0.35 else 1e-6 * float(o["image"].max()))
