@@ -63,7 +63,7 @@ for case in range(n_cases):
     # grows with every bounce off a sphere, and forty vertices down a chain a ray may fall on the other side of a light's edge
     # (measured: 4e-5 in a direction at depth 43 of one path in 4680; its gradient weight had long decayed to 0).  Chains
     # get that long only with a weak roulette and no user cap: there the counts may differ by a few rays.
-    deep = unbiased and p <= 0.3 and (md == 0 or md > 40)
+    deep = p <= 0.3 and (md == 0 or md > 40)            # (either operator: a weak roulette and no cap below forty vertices)
     if deep:
         assert abs(a[2]["segments"] - q[2]["segments"]) <= 2e-3 * q[2]["segments"], (case, name, kw, a[2]["segments"], q[2]["segments"])
     else:

@@ -76,7 +76,14 @@ for case in range(n_cases):
     e32 = float(np.abs(g32 - ref["grads"]).max() / scale)
     # (a path the depth limit cut short is reported -- capped_paths -- and its share of the gradient is missing or, under the
     #  unbiased operator, drawn from other numbers from there on: one path of a heavy-tailed scene can be 1e-4 of a gradient)
-    assert e64 < (1e-9 if capped == 0 else 1e-2) or on_a_singular_point(), (case, name, rp, unbiased, e64, capped)
+    if capped == 0 and not e64 < 1e-9 and not chaotic:
+        # same ray count, gradients off by more than rounding: forty vertices down a path a direction is only good to 1e-5,
+        # and what a glossy lobe of exponent 80 returns for it changes in the fourth digit -- on a path that deep only
+        deepest = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, unbiased=unbiased, zero_dir_miss=unbiased)["stats"]["deepest"]
+        assert (deepest >= 40 and e64 < 1e-5) or on_a_singular_point(), (case, name, rp, unbiased, e64, deepest)
+        chaotic = f", paths {deepest} deep: gradients to {e64:.0e}"
+        n_chaotic += 1
+    assert e64 < (1e-9 if capped == 0 and not chaotic else 1e-2) or on_a_singular_point(), (case, name, rp, unbiased, e64, capped)
     # (per pixel: with a weak roulette some paths run to forty vertices and more, where host and device no longer stand on
     #  the same point to better than 1e-5 -- see `chaotic` above -- and what such a vertex adds to its pixel carries that)
     try:
