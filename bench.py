@@ -36,8 +36,11 @@ sys.path.insert(0, ROOT)
 # with the context made between the group's creation and its first collective two of the context's streams ended up on one
 # queue -- frames in stream order, 0.716 instead of 0.658 ms (tools/allreduce_overlap.py --torch-dist-eager --context-between:
 # 0.716 with 2 or 4 queues, 0.657 with 8 or 16; every other workload of this file measures the same with 4 and 8).  Read by
-# the HIP runtime when it starts, so it is set before torch is imported; a value from the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the HIP runtime when it starts, so it is set before torch is imported; a value from the environment wins.  One process per
+# GPU, as the ranks of this file are: two processes of 8 queues each on ONE device oversubscribe its hardware queues and the
+# scheduler time-slices them (--same-gpu, the plumbing test: 45.7 ms per step instead of 1.7) -- there the default stays.
+if "--same-gpu" not in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6200.0        # measured float4 copy on the pool's boxes (profiles/r01_microbench_stream_roofs.txt; guide: 6.29)
