@@ -136,6 +136,19 @@ def test_oracle_vs_live_reference_on_fresh_random_scenes(pkg, oracle):
         assert a["stats"]["segments"] == b["stats"]["segments"]
 
 
+@pytest.mark.skipif("not __import__('os').path.exists('/root/reference/include/drt')")
+def test_oracle_vs_live_reference_fuzz(pkg, oracle):
+    """tools/fuzz_oracle.py, 150 cases: random renders -- every scene family, both integration operators, adjoint images, the
+    per-sample loss, gradient images -- through the restatement and through the reference itself: bit for bit.  (Round 4 ran
+    it for 60,000 cases: profiles/r04_fuzz_oracle_vs_reference.txt.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracle.py"), "150", "3"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "FUZZ ORACLE OK: 150 renders" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("name", LOSS_GOLDENS)
 def test_per_sample_squared_error_loss_bit_exact(pkg, oracle, name):
     """README.md:93-98, `loss = loss_func(radiance); loss.backward()` with loss_func = squared error against a target
