@@ -174,6 +174,10 @@ def main():
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     # launched by torch.distributed.run (also with one rank: exercises the in-library RCCL path on one GPU)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist and rank != 0:
+        # the launcher merges every rank's stdout, and RCCL writes a version banner there through C stdio when a communicator
+        # is made (it leaves the buffer when the process ends: possibly behind rank 0's line).  Only rank 0 has anything to say.
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if a.same_gpu:
         local_rank = 0
     if use_dist:
