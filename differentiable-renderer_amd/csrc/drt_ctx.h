@@ -97,6 +97,7 @@ struct drt_hip_ctx {
     bool overlap_next = false;            // set around render_launch by the callers whose renders do not wait
     bool slot_used[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
     DevBuf fpart2, gpart2, counts2;       // k_path's partial sums of the odd frames
+    DevBuf mesh_ovf[2];                   // k_path_mesh: traversal-stack entries beyond the ones in LDS, one area per k_path stream
     DevBuf ray_a[2], ray_b[2], ray_id[2], hit, hit2, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[DRT_HIP_FRAMES_IN_FLIGHT], film, gpart, grad[DRT_HIP_FRAMES_IN_FLIGHT], adjoint, out[DRT_HIP_FRAMES_IN_FLIGHT];   // one set per frame in flight (drt_hip_render_async; device frames that do not wait alternate between the first two), slot 0 otherwise
     std::vector<hipEvent_t> event_pool;

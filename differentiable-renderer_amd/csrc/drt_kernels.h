@@ -404,6 +404,81 @@ __device__ unsigned long long g_bvh_hist[24];
 __device__ unsigned long long g_walk_times[8192][3];
 #endif
 
+
+// ---- one visit of a QUANTISED node (64 B, drt_bvh.h: QNode; its four words are in w0..w3) ----------------------------------
+// Four slab tests in the node's own grid: a bound plane at origin + q * 2^e is crossed at
+//   t = ((origin - o) + q * 2^e) / d = A + q * B,   A = (origin - o) * inv_d,  B = 2^e * inv_d
+// -- one conversion and one fma per plane instead of decoding the box first (fma, sub, mul) -- and the
+// sign of d says which of a child's two planes per axis is the near one, so no min / max pairs either.
+// Rounding moves a t by ~2^-22 (|origin - o| + q 2^e) / |d|; the boxes are padded by 1e-5 of the mesh
+// diagonal for exactly this.  A miss sorts to the end with t = +inf.
+template <typename R>
+__device__ inline void quant_node_visit(uint4 w0, uint4 w1, uint4 w2, uint4 w3, V3<R> o, V3<R> inv_d, R tmin, R (&tc)[4], uint32_t (&lc)[4])
+{
+    const R ax = ((R)__uint_as_float(w0.x) - o.x) * inv_d.x, ay = ((R)__uint_as_float(w0.y) - o.y) * inv_d.y,
+            az = ((R)__uint_as_float(w0.z) - o.z) * inv_d.z;
+    const R bx = (R)__uint_as_float((w0.w & 0xFFu) << 23) * inv_d.x, by = (R)__uint_as_float((w0.w & 0xFF00u) << 15) * inv_d.y,
+            bz = (R)__uint_as_float((w0.w & 0xFF0000u) << 7) * inv_d.z;
+    const bool ngx = inv_d.x < R(0), ngy = inv_d.y < R(0), ngz = inv_d.z < R(0);
+    const uint32_t qnx = ngx ? w2.w : w2.x, qfx = ngx ? w2.x : w2.w;      // near / far plane bytes of the 4 children
+    const uint32_t qny = ngy ? w3.x : w2.y, qfy = ngy ? w2.y : w3.x;
+    const uint32_t qnz = ngz ? w3.y : w2.z, qfz = ngz ? w2.z : w3.y;
+    lc[0] = w1.x; lc[1] = w1.y; lc[2] = w1.z; lc[3] = w1.w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const R tnx = fma_r((R)((qnx >> (8 * c)) & 0xFFu), bx, ax), tfx = fma_r((R)((qfx >> (8 * c)) & 0xFFu), bx, ax);
+        const R tny = fma_r((R)((qny >> (8 * c)) & 0xFFu), by, ay), tfy = fma_r((R)((qfy >> (8 * c)) & 0xFFu), by, ay);
+        const R tnz = fma_r((R)((qnz >> (8 * c)) & 0xFFu), bz, az), tfz = fma_r((R)((qfz >> (8 * c)) & 0xFFu), bz, az);
+        const R tn = max_r(max_r(tnx, tny), max_r(tnz, R(0)));
+        const R tf = min_r(min_r(tfx, tfy), min_r(tfz, tmin));
+        tc[c] = (tn <= tf && lc[c] != DRT_BVH_LEAF) ? tn : (R)INFINITY;
+    }
+}
+
+// near-to-far order of four (t, link) pairs: a 5-comparator network (a miss sorts to the end with t = +inf)
+template <typename R>
+__device__ inline void sort4_by_t(R (&tc)[4], uint32_t (&lc)[4])
+{
+#define DRT_CSWAP(i, j) { const bool sw = tc[j] < tc[i]; const R tt = sw ? tc[j] : tc[i]; const R tu = sw ? tc[i] : tc[j]; \
+                          const uint32_t lt = sw ? lc[j] : lc[i]; const uint32_t lu = sw ? lc[i] : lc[j];                \
+                          tc[i] = tt; tc[j] = tu; lc[i] = lt; lc[j] = lu; }
+    DRT_CSWAP(0, 1) DRT_CSWAP(2, 3) DRT_CSWAP(0, 2) DRT_CSWAP(1, 3) DRT_CSWAP(1, 2)
+#undef DRT_CSWAP
+}
+
+// the triangles of one leaf (<= 4, all requested before the first is tested: one round trip per leaf): closest hit so far
+// in (tmin, prim, best_flat); exact ties keep the primitive that comes first in the flattened scene (pathtracer.hpp:80)
+template <typename R>
+__device__ inline void leaf_visit(const typename Q4<R>::T* __restrict__ tri, uint32_t link, int n_shapes, V3<R> o, V3<R> d,
+                                  R& tmin, int& prim, uint32_t& best_flat)
+{
+    typedef typename Q4<R>::T R4;
+    const uint32_t first = (link & 0x7FFFFFFFu) >> 3, count = link & 7u;
+    R4 ta[4], tb[4], tcc[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if (j < count) {
+            const R4* __restrict__ tp = tri + (size_t)(first + j) * 3;
+            ta[j] = tp[0];
+            tb[j] = tp[1];
+            tcc[j] = tp[2];
+        }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+        if (j < count) {
+            R t;
+            if (tri_intersect(mk<R>(ta[j].x, ta[j].y, ta[j].z), mk<R>(ta[j].w, tb[j].x, tb[j].y),
+                              mk<R>(tb[j].z, tb[j].w, tcc[j].x), o, d, t)) {
+                const uint32_t flat = pid_unpack(tcc[j].z);
+                if (t < tmin || (t == tmin && flat < best_flat)) {
+                    tmin = t;
+                    prim = n_shapes + (int)pid_unpack(tcc[j].y);
+                    best_flat = flat;
+                }
+            }
+        }
+}
+
 template <typename R>
 __global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 ? DRT_WALK_MIN_BLOCKS : 1))
 k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh, HitRec<R>* hit,
@@ -561,49 +636,22 @@ k_intersect_mesh(BatchArgs a, const DevScene<R>* __restrict__ sc, DevBvh<R> bvh,
             if ((threadIdx.x & 63) == 0) DRT_STAT(5, 1);          // (stats: interior wave-iterations)
             if (!descending)
                 continue;
-            uint4 w0, w1, w2, w3;
+            R tc[4];
+            uint32_t lc[4];
             DRT_STAT(cur < n_lds ? 1 : 2, 1);
 #ifdef DRT_BVH_STATS
             ++stat_visits;
             if (stat_cur_t > (float)tmin) DRT_STAT(8, 1);
 #endif
+            uint4 w0, w1, w2, w3;
             if (cur < n_lds) {
                 w0 = s_node[cur][0]; w1 = s_node[cur][1]; w2 = s_node[cur][2]; w3 = s_node[cur][3];
             } else {
                 const uint4* p = bvh.node + (size_t)cur * 4;
                 w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
             }
-            // Four slab tests in the node's own grid: a bound plane at origin + q * 2^e is crossed at
-            //   t = ((origin - o) + q * 2^e) / d = A + q * B,   A = (origin - o) * inv_d,  B = 2^e * inv_d
-            // -- one conversion and one fma per plane instead of decoding the box first (fma, sub, mul) -- and the
-            // sign of d says which of a child's two planes per axis is the near one, so no min / max pairs either.
-            // Rounding moves a t by ~2^-22 (|origin - o| + q 2^e) / |d|; the boxes are padded by 1e-5 of the mesh
-            // diagonal for exactly this.  A miss sorts to the end with t = +inf.
-            const R ax = ((R)__uint_as_float(w0.x) - o.x) * inv_d.x, ay = ((R)__uint_as_float(w0.y) - o.y) * inv_d.y,
-                    az = ((R)__uint_as_float(w0.z) - o.z) * inv_d.z;
-            const R bx = (R)__uint_as_float((w0.w & 0xFFu) << 23) * inv_d.x, by = (R)__uint_as_float((w0.w & 0xFF00u) << 15) * inv_d.y,
-                    bz = (R)__uint_as_float((w0.w & 0xFF0000u) << 7) * inv_d.z;
-            const bool ngx = inv_d.x < R(0), ngy = inv_d.y < R(0), ngz = inv_d.z < R(0);
-            const uint32_t qnx = ngx ? w2.w : w2.x, qfx = ngx ? w2.x : w2.w;      // near / far plane bytes of the 4 children
-            const uint32_t qny = ngy ? w3.x : w2.y, qfy = ngy ? w2.y : w3.x;
-            const uint32_t qnz = ngz ? w3.y : w2.z, qfz = ngz ? w2.z : w3.y;
-            R tc[4];
-            uint32_t lc[4] = {w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const R tnx = fma_r((R)((qnx >> (8 * c)) & 0xFFu), bx, ax), tfx = fma_r((R)((qfx >> (8 * c)) & 0xFFu), bx, ax);
-                const R tny = fma_r((R)((qny >> (8 * c)) & 0xFFu), by, ay), tfy = fma_r((R)((qfy >> (8 * c)) & 0xFFu), by, ay);
-                const R tnz = fma_r((R)((qnz >> (8 * c)) & 0xFFu), bz, az), tfz = fma_r((R)((qfz >> (8 * c)) & 0xFFu), bz, az);
-                const R tn = max_r(max_r(tnx, tny), max_r(tnz, R(0)));
-                const R tf = min_r(min_r(tfx, tfy), min_r(tfz, tmin));
-                tc[c] = (tn <= tf && lc[c] != DRT_BVH_LEAF) ? tn : (R)INFINITY;
-            }
-            // near-to-far order: 5-comparator sorting network on (t, link)
-#define DRT_CSWAP(i, j) { const bool sw = tc[j] < tc[i]; const R tt = sw ? tc[j] : tc[i]; const R tu = sw ? tc[i] : tc[j]; \
-                          const uint32_t lt = sw ? lc[j] : lc[i]; const uint32_t lu = sw ? lc[i] : lc[j];                \
-                          tc[i] = tt; tc[j] = tu; lc[i] = lt; lc[j] = lu; }
-            DRT_CSWAP(0, 1) DRT_CSWAP(2, 3) DRT_CSWAP(0, 2) DRT_CSWAP(1, 3) DRT_CSWAP(1, 2)
-#undef DRT_CSWAP
+            quant_node_visit<R>(w0, w1, w2, w3, o, inv_d, tmin, tc, lc);
+            sort4_by_t<R>(tc, lc);
             // farthest first onto the stack, nearest becomes current
 #ifdef DRT_BVH_STATS
             if (tc[3] < (R)INFINITY) stat_t[sp] = (float)tc[3];

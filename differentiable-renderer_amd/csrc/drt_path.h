@@ -46,6 +46,7 @@ struct PathArgs {
     int32_t min_bounces, depth_cap, cap_is_roulette, cap_draws;   // (cap_draws: BatchArgs)
     uint32_t rr_threshold, seed, rng_stream;   // rng_stream: drt_rng_stream(seed, 0)
     uint32_t regen_min;             // regenerating form: idle lanes it takes to run the camera code (see k_path)
+    uint32_t shade_min, descend_min;   // k_path_mesh (drt_path_mesh.h): lanes it takes to run the vertex step / to keep the node loop going
     int32_t gimg_param;             // >= 0: the lanes' gradient sums of this parameter also leave per pixel (gradient image)
     double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
     // camera
@@ -111,8 +112,8 @@ struct TangentLds {              // per colour parameter, wave-uniform except wh
     uint32_t inc[DRT_FAST_PARAMS][4];    // counter increments of a bounce on this colour: n_p (low, high word), zc; [3] = zero-channel bits
 };
 
-template <typename R>
-__device__ inline void stage_tangents(TangentLds<R>& tl, const SceneLds<R>& lds)
+template <typename R, typename SL>
+__device__ inline void stage_tangents(TangentLds<R>& tl, const SL& lds)
 {
     // (after stage_scene's barrier; parameters beyond the scene's own read as (1, 1, 1))
     if (threadIdx.x < DRT_FAST_PARAMS) {
@@ -158,8 +159,8 @@ struct Tangents {
 // LOSS (DRT_RENDER_LOSS_L2, the end of a path only): `g` holds the lane's TARGET pixel and the seed is the derivative of the
 // sample's own squared error, 2 (L - target), with L the path's radiance INCLUDING this emission -- final where the path ends
 // on a light without BxDF, which is the only emissive vertex of a path in the scenes this form is used for.
-template <typename R, int NP, int NC, bool LOSS = false>
-__device__ inline void add_emission(const SceneLds<R>& lds, const TangentLds<R>& tl, const R* __restrict__ params, uint32_t eid, R inv_pk,
+template <typename R, int NP, int NC, bool LOSS = false, typename SL = SceneLds<R>>
+__device__ inline void add_emission(const SL& lds, const TangentLds<R>& tl, const R* __restrict__ params, uint32_t eid, R inv_pk,
                                     V3<R> T, V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
 {
     const V3<R> E = load_param<R, (NP > 0)>(lds, params, (int)eid) * inv_pk;
@@ -819,8 +820,9 @@ k_film_parts(const double* __restrict__ fpart, uint32_t n_ranges, uint32_t Pb, u
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path_finish(PathArgs a, const double* __restrict__ fpart, float* __restrict__ out, uint32_t film_blocks,
               const double* __restrict__ gpart, int n_blocks, int n_rows, int row_stride, double* __restrict__ grad, uint32_t grad_words,
-              const uint32_t* __restrict__ counts, uint32_t n_waves, unsigned long long* __restrict__ total)
+              const uint32_t* __restrict__ counts, uint32_t n_waves, unsigned long long* __restrict__ total, uint32_t count_rows = 2)
 {
+    // (count_rows = 3, k_path_mesh: a third word per wave, the rays its BVH walk took -> total[5])
     __shared__ double red[DRT_BLOCK];
     if (blockIdx.x < film_blocks) {
         const uint32_t stride = film_blocks * DRT_BLOCK;
@@ -859,18 +861,22 @@ k_path_finish(PathArgs a, const double* __restrict__ fpart, float* __restrict__ 
     }
     {
         const uint32_t nb = gridDim.x - film_blocks - grad_words, me = blockIdx.x - film_blocks - grad_words;
-        unsigned long long seg = 0, cap = 0;
+        unsigned long long seg = 0, cap = 0, wlk = 0;
         for (uint32_t i = me * DRT_BLOCK + threadIdx.x; i < n_waves; i += nb * DRT_BLOCK) {
             seg += counts[i];
             cap += counts[(size_t)n_waves + i];
+            if (count_rows > 2)
+                wlk += counts[(size_t)n_waves * 2 + i];
         }
         for (int off = DRT_WAVE / 2; off > 0; off >>= 1) {
             seg += __shfl_down(seg, off);
             cap += __shfl_down(cap, off);
+            wlk += __shfl_down(wlk, off);
         }
         if ((threadIdx.x & (DRT_WAVE - 1)) == 0) {
             if (seg) atomicAdd(total, seg);
             if (cap) atomicAdd(total + 3, cap);
+            if (wlk) atomicAdd(total + 5, wlk);
         }
     }
 }

@@ -158,6 +158,7 @@ struct Shard {
     hipFunction_t loss_kernel = nullptr;   // ... on k_path: the LOSS instantiation, made at run time only (drt_jit.h)
     bool can_fuse;                  // K2 folded into K3: analytic scenes, unless DRT_RENDER_UNFUSED asks for the textbook pipeline
     bool use_path, path_regen;      // the whole path in one launch (k_path); its regenerating form
+    bool mesh_path;                 // ... in a scene with a mesh: k_path_mesh (drt_path_mesh.h), the BVH walk inside the launch
     bool shade_tail;                // mesh scenes: the launch that produces a ray also intersects it with the analytic shapes and
                                     // builds the BVH walk's candidate lists (k_raygen / k_shade / k_adj_vertex <TAIL>)
     bool overlap_ok;                // this frame's k_path may run beside its neighbours' (its own stream and lane of partial sums)
@@ -246,12 +247,21 @@ void shard_plan(Shard<R>& s)
     // roulette removes `absorb` of the rest from min_bounces on -- and the regenerating form (a lane whose path ended starts
     // its next sample at once) otherwise: roulette-terminated paths under the default cap of 64, the reference's own
     // defaults (-b 1 -p 0.5).
-    s.use_path = s.can_fuse && ctx->prog_ok && D > 0 && (!(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) &&
+    // Scenes with a mesh: k_path_mesh, the same launch with the BVH walk inside -- for SMALL frames (the frames of an
+    // optimisation loop): one launch instead of ~20, 2-2.8 x the queue route's rate up to ~0.5 M camera samples, even at ~2 M,
+    // half its rate at 16 M (a wave's lanes split between the vertex step and the walk: 20 of 64 per instruction;
+    // profiles/r05_mesh_small_frames.txt, r05_mesh_fused_pmc.txt).  Biased operator, seeds linear in the radiance; the unbiased
+    // operator, the per-sample loss and more than 8 parameters keep the queue wavefront.
+    // (decided by the size of the FRAME, not of this shard's part of it: the shards of a frame take one route and tile it bit for bit)
+    const bool mesh_ok = ctx->has_mesh && (long long)s.cam->width * s.cam->height * s.spp <= tuning().mesh_path_max && ctx->prog_sorted && !(rp->flags & DRT_RENDER_UNFUSED) && !s.unbiased &&
+                         !s.loss_l2;
+    s.use_path = ((s.can_fuse && ctx->prog_ok) || mesh_ok) && D > 0 && (!(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) &&
                  rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path == -1;
-    s.path_regen = tuning().path_regen > 0;
+    s.mesh_path = s.use_path && ctx->has_mesh;
+    s.path_regen = tuning().path_regen > 0 || s.mesh_path;    // (k_path_mesh: every lane on its own, always)
     if (s.unbiased)
         s.path_regen = false;                  // (k_path_unbiased walks its samples in lockstep)
-    if (s.use_path && tuning().path_regen < 0 && !s.unbiased) {
+    if (s.use_path && !s.mesh_path && tuning().path_regen < 0 && !s.unbiased) {
         // lockstep: a wave runs until the longest of its 64 paths ends -- the depth cap for fixed-depth renders, under the
         // roulette about the depth that 1 path in 256 reaches; regenerating: every lane runs the mean path length, at
         // ~1.7 x the cost per bounce (per-lane depth bookkeeping) + the camera code inside the loop.
@@ -346,7 +356,7 @@ void shard_plan(Shard<R>& s)
     s.fpart_buf = odd ? &ctx->fpart2 : &ctx->fpart;
     s.gpart_buf = odd ? &ctx->gpart2 : &ctx->gpart;
     s.counts_buf = odd ? &ctx->counts2 : &ctx->counts;
-    s.cw = s.use_path ? 2 * s.path_waves                        // [segments | capped paths] per wave
+    s.cw = s.use_path ? (s.mesh_path ? 3 : 2) * s.path_waves      // [segments | capped paths (| rays the BVH walk took)] per wave
                       : (size_t)(D + 1) * s.max_regions;          // counts[depth][region] of one batch
     // a k_path launch that covers the whole frame is followed by ONE finishing launch that WRITES image, gradients and
     // totals (k_path_finish); every other route accumulates into zeroed buffers
@@ -372,6 +382,11 @@ int shard_buffers(Shard<R>& s)
         if ((rc = ensure(ctx, *s.fpart_buf, (size_t)s.path_ranges * 3 * s.Pb * sizeof(double))) != DRT_OK) return rc;
         if (s.gimg_param >= 0)
             if ((rc = ensure(ctx, ctx->gpix, (size_t)s.path_ranges * 3 * s.Pb * sizeof(double))) != DRT_OK) return rc;
+        if (s.mesh_path) {   // the traversal stack's entries beyond the ones in LDS, per thread of the grid (one area per k_path stream)
+            const size_t threads = ((s.path_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE)) * DRT_BLOCK;
+            if ((rc = ensure(ctx, ctx->mesh_ovf[(s.overlap_ok && (ctx->slot & 1)) ? 1 : 0],
+                             threads * (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) * sizeof(uint32_t))) != DRT_OK) return rc;
+        }
     } else {
         for (int i = 0; i < 2; ++i) {
             if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
@@ -498,6 +513,8 @@ int path_batch(Shard<R>& s)
     pa.min_bounces = a.min_bounces; pa.depth_cap = a.depth_cap; pa.cap_is_roulette = a.cap_is_roulette; pa.cap_draws = a.cap_draws;
     pa.rr_threshold = a.rr_threshold; pa.seed = a.seed; pa.rng_stream = a.rng_stream;
     pa.regen_min = (uint32_t)tuning().path_regen_min;
+    pa.shade_min = (uint32_t)tuning().mesh_shade_min;
+    pa.descend_min = a.bvh_descend_min;
     pa.p_rr = 1.0 - rp->absorb;
     pa.inv_p_rr = rp->absorb < 1.0 ? 1.0 / (1.0 - rp->absorb) : 0.0;   // (never used when every path ends at min_bounces)
     for (int i = 0; i < 3; ++i) {
@@ -520,7 +537,7 @@ int path_batch(Shard<R>& s)
     // other analytic scene reads its kinds at run time (the kind-sorted program) until it has rendered enough for a kernel
     // of its own to pay (drt_jit.h; f32 only: the f64 mode keeps the reference's literal shape loop for such scenes).
     const bool builtin = tuning().builtin_program && ctx->jit_mode >= 0 && ctx->n_shapes == DRT_NSIG_CORNELL &&
-                         ctx->prog_sig[0] == DRT_SIG_CORNELL && !s.loss_kernel;
+                         ctx->prog_sig[0] == DRT_SIG_CORNELL && !s.loss_kernel && !s.mesh_path;
     unsigned long long* ptotal = s.path_finish ? s.totals : (unsigned long long*)nullptr;
     // (frames that overlap: this frame's grid goes to the lane's own stream, behind whoever still uses the lane's buffers, and
     //  the finishing launch on the context's stream waits for it.  Scene and parameter uploads block until they are done, so
@@ -544,7 +561,7 @@ int path_batch(Shard<R>& s)
     const bool tangents = backward || s.gimg_param >= 0;
     hipFunction_t jit = s.loss_kernel;
     ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(s.D > 0 ? s.D : 1);
-    if (!jit && !builtin && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
+    if (!jit && !builtin && !s.mesh_path && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
         jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false), ctx->jit_mode > 1);
     st->path_program = builtin ? DRT_PROGRAM_BUILTIN : (jit ? DRT_PROGRAM_SPECIALISED : DRT_PROGRAM_SORTED);
     int rc;
@@ -572,6 +589,19 @@ int path_batch(Shard<R>& s)
             hipLaunchKernelGGL((k_path_unbiased<R, SPEC, NP, SigNone>), dim3(gpath), dim3(DRT_BLOCK), 0, ks, pa,               \
                                d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal);                                    \
     } while (0)
+    uint32_t* ovf = s.mesh_path ? (uint32_t*)ctx->mesh_ovf[(s.overlap_ok && lane2) ? 1 : 0].p : (uint32_t*)nullptr;
+    const uint32_t ovf_stride = (uint32_t)gpath * DRT_BLOCK;
+    const DevBvh<R> bvh = s.bvh;
+#define DRT_LAUNCH_MESH(SPEC, NP, NC)                                                                              \
+    hipLaunchKernelGGL((k_path_mesh<R, SPEC, NP, NC>), dim3(gpath), dim3(DRT_BLOCK), 0, ks, pa, d_scene, d_params, \
+                       d_adjoint, bvh, ovf, ovf_stride, gpart, fpart, counts, ptotal, gpix)
+    if (s.mesh_path) {
+        if (tangents && ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 8, 8); else DRT_LAUNCH_MESH(false, 8, 8); }
+        else if (tangents && three) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 4, 3); else DRT_LAUNCH_MESH(false, 4, 3); }
+        else if (tangents) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 4, 4); else DRT_LAUNCH_MESH(false, 4, 4); }
+        else { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 0, 0); else DRT_LAUNCH_MESH(false, 0, 0); }
+    } else
+#undef DRT_LAUNCH_MESH
     if (jit) {
         void* args_path[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal, &gpix};
         void* args_unb[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal};
@@ -599,7 +629,7 @@ int path_batch(Shard<R>& s)
     }
     st->launches[DRT_K_PATH]++;
     st->path_bytes += (s.film ? (uint64_t)pa.n_ranges * a.Pb * 3 * sizeof(double) : 0) +
-                      (backward ? (uint64_t)gpath * DRT_FAST_PARAMS * 3 * sizeof(double) : 0) + 2 * n_waves * sizeof(uint32_t);
+                      (backward ? (uint64_t)gpath * DRT_FAST_PARAMS * 3 * sizeof(double) : 0) + (s.mesh_path ? 3 : 2) * n_waves * sizeof(uint32_t);
     if (s.path_finish) {
         // image, gradients and totals of the frame in one launch (timed in the film slot)
         const uint32_t film_blocks = s.film ? (uint32_t)grid_for(ctx, a.Pb) : 0u;
@@ -608,7 +638,8 @@ int path_batch(Shard<R>& s)
         DRT_TIMED(s, DRT_K_FILM,
                   hipLaunchKernelGGL(k_path_finish, dim3(film_blocks + grad_words + count_blocks), dim3(DRT_BLOCK), 0, ctx->stream, pa,
                                      (const double*)fpart, s.d_out_rgb, film_blocks, (const double*)gpart, gpath, s.n_fast * 3,
-                                     DRT_FAST_PARAMS * 3, s.grad, grad_words, (const uint32_t*)counts, (uint32_t)n_waves, s.totals));
+                                     DRT_FAST_PARAMS * 3, s.grad, grad_words, (const uint32_t*)counts, (uint32_t)n_waves, s.totals,
+                                     s.mesh_path ? 3u : 2u));
         st->units[DRT_K_FILM] += a.n_paths;
         if (gpix && s.d_out_gimg) {   // the gradient image: the same sums over the sample ranges, its own output
             const uint32_t gb = (uint32_t)grid_for(ctx, a.Pb);

@@ -336,7 +336,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
             }
             const double pad = std::max(1e-5 * (diag > 0 ? diag : 1.0), 2e-6 * extent);
             const drt_bvh::Built built = drt_bvh::build(tris, DRT_BVH_LDS_NODES, pad);
-            if (built.stack_need > DRT_BVH_STACK)      // not even a balanced tree fits (> ~2 M triangles)
+            if (built.stack_need > DRT_BVH_STACK || built.nodes.size() >= ((size_t)1 << 24))      // not even a balanced tree fits (> ~2 M triangles)
                 return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: the BVH of this mesh needs a deeper traversal stack than the device kernel has");
             if ((rc = upload_bvh<float>(ctx, built, tris, &ctx->bvh_f)) != DRT_OK) return rc;
             if ((rc = upload_bvh<double>(ctx, built, tris, &ctx->bvh_d)) != DRT_OK) return rc;

@@ -28,6 +28,8 @@ struct Tuning {
     int shade_list_group = 4;      // DRT_HIP_SHADE_LIST_GROUP     region lists the walk pulls at a time
     int bvh_refill = -1;           // DRT_HIP_BVH_REFILL           idle lanes before the walk's waves refill; -1 = DRT_BVH_REFILL (16)
     int bvh_descend_min = -1;      // DRT_HIP_BVH_DESCEND_MIN      lanes that keep the interior-node loop going; -1 = DRT_BVH_DESCEND_MIN (32)
+    long long mesh_path_max = 1 << 20;   // DRT_HIP_MESH_PATH_MAX   mesh scenes: frames of at most this many camera samples take the one-launch k_path_mesh (0: never), larger ones the queue wavefront
+    int mesh_shade_min = 32;       // DRT_HIP_MESH_SHADE_MIN       k_path_mesh: lanes with a final hit (or without a path) it takes to run the shade step
     // ---- host buffers, groups
     int copy_blocks = 64;          // DRT_HIP_COPY_BLOCKS      blocks of the launch that carries an asynchronous frame to the pinned block
     bool async_copy_inline = false;// DRT_HIP_ASYNC_COPY       inline: asynchronous frames on ONE stream, the finishing kernels store into the pinned block
@@ -57,11 +59,15 @@ inline const Tuning& tuning()
         v.shade_list_group = (int)num("DRT_HIP_SHADE_LIST_GROUP", 4);
         v.bvh_refill = (int)num("DRT_HIP_BVH_REFILL", -1);
         v.bvh_descend_min = (int)num("DRT_HIP_BVH_DESCEND_MIN", -1);
+        v.mesh_path_max = num("DRT_HIP_MESH_PATH_MAX", 1 << 20);
+        v.mesh_shade_min = (int)num("DRT_HIP_MESH_SHADE_MIN", 32);
         v.copy_blocks = (int)num("DRT_HIP_COPY_BLOCKS", 64);
         v.async_copy_inline = getenv("DRT_HIP_ASYNC_COPY") && !strcmp(getenv("DRT_HIP_ASYNC_COPY"), "inline");
         v.group_threads = !off("DRT_HIP_GROUP_THREADS");
         v.dump_path = num("DRT_HIP_DUMP_PATH", -1);
         if (v.path_regen_min < 1) v.path_regen_min = 1;
+        if (v.mesh_shade_min < 1) v.mesh_shade_min = 1;
+        if (v.mesh_shade_min > 64) v.mesh_shade_min = 64;
         if (v.shade_list_group < 1) v.shade_list_group = 1;
         if (v.copy_blocks < 1) v.copy_blocks = 1;
         return v;

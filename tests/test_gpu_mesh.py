@@ -34,6 +34,79 @@ def test_50k_triangle_bvh_matches_brute_force(pkg, hip, oracle):
     assert grad_rel_err(grads, ref["grads"]) <= 1e-4
 
 
+@pytest.mark.parametrize("name,W,H,spp,kw", [
+    ("mesh10x12", 24, 24, 3, dict(min_bounces=4, absorb=1.0)),
+    ("mesh40x40", 48, 48, 4, dict(min_bounces=5, absorb=1.0)),
+    ("mesh10x12", 29, 28, 3, dict(min_bounces=1, absorb=0.5)),                     # the reference's default roulette
+    ("mesh40x40", 40, 30, 4, dict(min_bounces=2, absorb=0.3, max_depth=6)),        # a user cap that cuts paths short
+    ("mesh10x12", 33, 17, 5, dict(min_bounces=0, absorb=0.25, max_depth=12)),      # roulette at depth 0
+])
+def test_one_launch_mesh_route_against_the_oracle_and_the_queue_route(pkg, hip, oracle, name, W, H, spp, kw):
+    """Small frames of a mesh scene take k_path_mesh (csrc/drt_path_mesh.h): the whole path in one launch, the BVH walk inside.
+    f64: the oracle's segment and capped-path counts exactly, gradients to 1e-9, image to f32 rounding; f32: the f32 bounds;
+    and the queue wavefront (bounces_per_launch = 1) walks the same candidates."""
+    scene = pkg.scene_by_name(name)
+    cam = pkg.cornell_camera(W, H)
+    rp = pkg.RenderParams(spp=spp, seed=3, **kw)
+    rq = dataclasses.replace(rp, bounces_per_launch=1)
+    hip.upload_scene(scene)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    for f64 in (True, False):
+        img, grads, st = hip.render(cam, rp, backward=True, f64=f64)
+        imq, gq, stq = hip.render(cam, rq, backward=True, f64=f64)
+        assert st["kernels"]["path"]["launches"] == 1 and st["kernels"]["shade"]["launches"] == 0
+        assert stq["kernels"]["path"]["launches"] == 0 and stq["kernels"]["intersect_mesh"]["launches"] > 0
+        if f64:
+            assert st["segments"] == ref["stats"]["segments"] == stq["segments"]
+            assert st["capped_paths"] == stq["capped_paths"]
+            assert st["kernels"]["intersect_mesh"]["units"] == stq["kernels"]["intersect_mesh"]["units"]   # rays that reach the mesh bounds
+            assert grad_rel_err(grads, ref["grads"]) < 1e-9
+            np.testing.assert_allclose(img, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+        else:
+            assert abs(st["segments"] - ref["stats"]["segments"]) <= 8
+            assert grad_rel_err(grads, ref["grads"]) <= 1e-4 and grad_rel_err(grads, gq) <= 1e-4
+            bad = np.abs(img.astype(np.float64) - ref["image"]).max(-1) > 2e-4 * np.abs(ref["image"]).max()
+            assert bad.sum() <= 1
+
+
+def test_one_launch_mesh_route_adjoint_gradient_image_and_shards(pkg, hip):
+    """k_path_mesh with a per-pixel adjoint, as a gradient image, and as shards of the frame: the queue route's numbers to f32
+    rounding, the shards tile the frame bit for bit and their gradients add up."""
+    scene = pkg.scene_by_name("mesh40x40")
+    cam = pkg.cornell_camera(64, 48)
+    rp = pkg.RenderParams(spp=6, min_bounces=4, absorb=1.0, seed=9, band_rows=4)
+    rq = dataclasses.replace(rp, bounces_per_launch=1)
+    hip.upload_scene(scene)
+    rs = np.random.RandomState(5)
+    adj = rs.uniform(0.0, 2.0, (48, 64, 3)).astype(np.float32)
+    img, g, st = hip.render(cam, rp, backward=True, adjoint=adj)
+    imq, gq, _ = hip.render(cam, rq, backward=True, adjoint=adj)
+    assert st["kernels"]["path"]["launches"] == 1
+    assert grad_rel_err(g, gq) < 2e-5
+    np.testing.assert_allclose(img, imq, rtol=2e-5, atol=1e-7)
+    white = scene.param_names.index("white")
+    _, gi, sti = hip.render_gradient_image(cam, rp, white)
+    _, giq, _ = hip.render_gradient_image(cam, rq, white)
+    assert sti["kernels"]["path"]["launches"] == 1
+    np.testing.assert_allclose(gi, giq, rtol=1e-4, atol=1e-6 * float(np.abs(giq).max()))
+    img1, g1, _ = hip.render(cam, rp, backward=True)
+    acc, gsum = np.zeros_like(img1), np.zeros_like(g1)
+    for s in range(3):
+        im_s, g_s, st_s = hip.render(cam, dataclasses.replace(rp, shard=s, n_shards=3), backward=True)
+        assert st_s["kernels"]["path"]["launches"] == 1
+        rows = pkg.shard_rows(48, rp.band_rows, 3, s)
+        acc[rows] = im_s[rows]
+        gsum += g_s
+    np.testing.assert_array_equal(acc, img1)
+    np.testing.assert_allclose(gsum, g1, rtol=1e-9)
+    # forward only, and twice the same bits
+    f1, _, stf = hip.render(cam, rp, backward=False)
+    f2, _, _ = hip.render(cam, rp, backward=False)
+    assert stf["kernels"]["path"]["launches"] == 1
+    np.testing.assert_array_equal(f1, f2)
+    np.testing.assert_array_equal(f1, img1)
+
+
 def test_per_face_parameters_use_the_general_gradient_path(pkg, hip, oracle):
     """12 per-face albedos + the 4 Cornell parameters = 16 > 8: K6's LDS columns + fp64 atomics."""
     scene = pkg.cornell_with_mesh(24, 24, per_face_params=12)

@@ -4,6 +4,8 @@
 set -eu
 N=$1; shift
 mkdir -p build
+# (the device headers as string literals for hiprtc: the same step the Makefile and build_native() run first)
+python3 differentiable-renderer_amd/csrc/embed_sources.py
 hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -shared -Iinclude "$@" \
       -o build/$N.so differentiable-renderer_amd/csrc/drt_hip.hip -lrccl -lhiprtc
 echo "build/$N.so"
