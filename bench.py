@@ -672,11 +672,21 @@ def main():
         hrp = pkg.RenderParams(spp=a.spp, min_bounces=a.min_bounces, absorb=a.absorb, seed=1, batch_paths=a.batch_paths)
         n_host = max(2, min(2 * a.steps, 40))     # (a pipeline: enough frames that its fill and drain do not set the rate)
         unb = a.unbiased and backward
-        r.render(cam, hrp, backward=backward, unbiased=unb)
+        # (the synchronous call the way a render loop makes it: the same image buffer every frame, no statistics --
+        #  in pageable memory, and pinned once with drt_hip_pin_host so that the finishing kernel stores the image straight into it)
+        sync_img = np.zeros((a.height, a.width, 3), dtype=np.float32)
+        r.render(cam, hrp, backward=backward, unbiased=unb, img_out=sync_img, want_stats=False)
         t3 = time.perf_counter()
         for _ in range(n_host):
-            r.render(cam, hrp, backward=backward, unbiased=unb)
+            r.render(cam, hrp, backward=backward, unbiased=unb, img_out=sync_img, want_stats=False)
         dt3 = (time.perf_counter() - t3) / n_host
+        r.pin_host(sync_img)
+        r.render(cam, hrp, backward=backward, unbiased=unb, img_out=sync_img, want_stats=False)
+        t3 = time.perf_counter()
+        for _ in range(n_host):
+            r.render(cam, hrp, backward=backward, unbiased=unb, img_out=sync_img, want_stats=False)
+        dt3p = (time.perf_counter() - t3) / n_host
+        r.unpin_host(sync_img)
         r.wait(r.render_async(cam, hrp, backward=backward, unbiased=unb))
         n_fly = pkg.FRAMES_IN_FLIGHT
         bufs = [(np.zeros((a.height, a.width, 3), dtype=np.float32), np.zeros((scene.n_params, 3), dtype=np.float64)) for _ in range(n_fly)]
@@ -697,8 +707,12 @@ def main():
                         "frac_of_value": round((total_segments / dt3a * 1e-6) / value, 4) if value > 0 else None,
                         "note": "drt_hip_render_async + drt_hip_wait with host out_rgb / out_param_grad, up to four frames in flight "
                                 "(PCIe D2H of image and gradients included, overlapped with the next frame's kernels)",
-                        "sync": {"value": round(total_segments / dt3 * 1e-6, 2), "ms_per_step": round(dt3 * 1e3, 4),
-                                 "note": "drt_hip_render: returns with the results in the caller's buffers"}}
+                        "sync": {"value": round(total_segments / dt3p * 1e-6, 2), "ms_per_step": round(dt3p * 1e3, 4),
+                                 "note": "drt_hip_render: returns with the results in the caller's buffers; out_rgb pinned once with "
+                                         "drt_hip_pin_host (the finishing kernel stores the image straight into it; the wait polls a completion word)",
+                                 "pageable": {"value": round(total_segments / dt3 * 1e-6, 2), "ms_per_step": round(dt3 * 1e3, 4),
+                                              "note": "the same call with out_rgb in pageable memory: image stored into the context's pinned "
+                                                      "block, then a 3 MB memcpy on the host"}}}
 
     # N > 1: efficiency against the stored single-GPU value of the SAME per-GPU workload (profiles/n1_reference.json, written by
     # a 1-GPU run with --store-n1; the driver computes its own figure from its own N = 1 run)

@@ -43,7 +43,7 @@ FRAMES_IN_FLIGHT = 4          # drt_hip_render_async: DRT_HIP_FRAMES_IN_FLIGHT
 MAX_DEPTH = 64
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]
-ABI_VERSION = 6
+ABI_VERSION = 7
 UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3: "DRT_ERR_HIP",
@@ -460,7 +460,7 @@ _ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create",
                 "drt_hip_group_size", "drt_hip_destroy",
                 "drt_hip_comm_unique_id", "drt_hip_comm_init_rank", "drt_hip_comm_size", "drt_hip_comm_destroy",
                 "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_set_specialisation", "drt_hip_render", "drt_hip_render_async", "drt_hip_wait",
-                "drt_hip_render_gradient_image", "drt_hip_stream",
+                "drt_hip_render_gradient_image", "drt_hip_pin_host", "drt_hip_unpin_host", "drt_hip_stream",
                 "drt_hip_synchronize", "drt_hip_last_error", "drt_hip_kernel_name"]
 
 
@@ -494,6 +494,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.drt_hip_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(HipStats)]
     lib.drt_hip_render_gradient_image.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(RenderParamsDesc),
                                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HipStats)]
+    lib.drt_hip_pin_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.drt_hip_unpin_host.argtypes = [C.c_void_p, C.c_void_p]
     lib.drt_hip_stream.argtypes = [C.c_void_p]
     lib.drt_hip_stream.restype = C.c_void_p
     lib.drt_hip_synchronize.argtypes = [C.c_void_p]
@@ -532,6 +534,7 @@ class HipRenderer:
                 raise DrtHipError(f"drt_hip_create(device={device}) failed: {STATUS_NAMES.get(rc, rc)}")
         self.device = device
         self.scene: Optional[Scene] = None
+        self._pinned = []                 # arrays handed to drt_hip_pin_host (kept alive while pinned)
 
     @property
     def group_size(self) -> int:
@@ -571,9 +574,21 @@ class HipRenderer:
         self._check(self.lib.drt_hip_update_params(self.ctx, p.ctypes.data_as(C.POINTER(C.c_double))),
                     "drt_hip_update_params")
 
+    def pin_host(self, array: np.ndarray):
+        """drt_hip_pin_host: renders whose img_out is (inside) this array get their image written straight into it by the
+        finishing kernel.  The array must outlive the pinning (unpin_host, or close())."""
+        assert array.flags.c_contiguous
+        self._check(self.lib.drt_hip_pin_host(self.ctx, array.ctypes.data_as(C.c_void_p), array.nbytes), "drt_hip_pin_host")
+        self._pinned.append(array)
+
+    def unpin_host(self, array: np.ndarray):
+        self._check(self.lib.drt_hip_unpin_host(self.ctx, array.ctypes.data_as(C.c_void_p)), "drt_hip_unpin_host")
+        self._pinned = [a for a in self._pinned if a is not array]
+
     def render(self, cam: Camera, rp: RenderParams, backward: bool = False,
                adjoint: Optional[np.ndarray] = None, timing: bool = False, f64: bool = False,
-               unbiased: bool = False, loss_l2: bool = False):
+               unbiased: bool = False, loss_l2: bool = False, img_out: Optional[np.ndarray] = None,
+               want_stats: bool = True):
         """Host-buffer render. -> (image float32 [H,W,3], grads float64 [P,3] or None, stats dict).
         loss_l2: `adjoint` is a TARGET image and every sample is back-propagated through its own squared-error loss
         (DRT_RENDER_LOSS_L2; README.md:93-98 of the reference)."""
@@ -591,7 +606,8 @@ class HipRenderer:
             flags |= RENDER_LOSS_L2
         d = rp.to_desc()
         d.flags = flags
-        img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        img = img_out if img_out is not None else np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        assert img.dtype == np.float32 and img.shape == (cam.height, cam.width, 3) and img.flags.c_contiguous
         grads = np.zeros((self.scene.n_params, 3), dtype=np.float64) if backward else None
         adj_ptr = None
         if adjoint is not None:
@@ -603,9 +619,9 @@ class HipRenderer:
         rc = self.lib.drt_hip_render(self.ctx, C.byref(cd), C.byref(d), adj_ptr,
                                      img.ctypes.data_as(C.c_void_p),
                                      grads.ctypes.data_as(C.c_void_p) if backward else None,
-                                     C.byref(stats))
+                                     C.byref(stats) if (want_stats or timing) else None)
         self._check(rc, "drt_hip_render")
-        return img, grads, stats.as_dict()
+        return img, grads, (stats.as_dict() if (want_stats or timing) else {})
 
     def render_async(self, cam: Camera, rp: RenderParams, backward: bool = False, adjoint: Optional[np.ndarray] = None,
                      f64: bool = False, unbiased: bool = False, img_out: Optional[np.ndarray] = None,
@@ -701,6 +717,7 @@ class HipRenderer:
         if getattr(self, "ctx", None) and self.ctx.value:
             self.lib.drt_hip_destroy(self.ctx)
             self.ctx = C.c_void_p()
+            self._pinned = []
 
     def __del__(self):
         try:

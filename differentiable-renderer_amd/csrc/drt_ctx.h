@@ -29,14 +29,16 @@ struct RenderJob {
     drt_hip_stats* stats = nullptr;
     int gimg_param = -1;
     bool backward = false, dev_out = false, timing = false, want_segments = false, sync = true;
-    bool zero_copy = false;               // the image is written straight into the pinned block (drt_hip_render_async, one-stream form)
+    bool zero_copy = false;               // the image is written straight into the pinned block (synchronous host-buffer renders; drt_hip_render_async, one-stream form)
+    bool direct_out = false, direct_gimg = false;   // ... or into the caller's own buffer, pinned with drt_hip_pin_host: nothing to hand over
+    uint64_t done_seq = 0;                // the value the frame's last launch stores into the pinned block's completion word (0: none)
     bool copy_kernel = false;             // image, gradients and totals go to the pinned block by ONE launch on the copy stream
     int n_shards = 1, shard = 0, band = 1;
     uint32_t n_local_pixels = 0;
     size_t n_count_words = 0;
     float* d_out = nullptr;
     float* d_gimg = nullptr;
-    size_t off_grad = 0, off_img = 0, off_gimg = 0, img_bytes = 0, grad_bytes = 0;
+    size_t off_grad = 0, off_img = 0, off_gimg = 0, off_adj = 0, img_bytes = 0, grad_bytes = 0;
     drt_hip_stats st;
     std::chrono::steady_clock::time_point t0;
 };
@@ -105,6 +107,8 @@ struct drt_hip_ctx {
     std::vector<TimedLaunch> timed;
     unsigned long long h_segments = 0;
     unsigned long long* h_probe = nullptr;   // pinned: queue-length polls of deep-cap renders
+    double* h_params = nullptr;              // pinned: the values of the last drt_hip_update_params, read by the launch that installs them
+    size_t h_params_cap = 0;
     // pinned staging of everything a host-buffer render returns: [segments 8 B | grads | image | gradient
     // image] arrive by DMA in one go, then plain memcpys into the caller's (pageable) buffers -- a
     // pageable hipMemcpy of the 3 MB image alone cost 1 ms
@@ -117,7 +121,14 @@ struct drt_hip_ctx {
     RenderJob pending[DRT_HIP_FRAMES_IN_FLIGHT];
     bool in_flight[DRT_HIP_FRAMES_IN_FLIGHT] = {};
     uint64_t next_ticket = 1;
-    bool zero_copy_next = false;          // set around the render_launch of an asynchronous host-buffer render
+    const void* adj_src_host = nullptr;   // a host-buffer render's adjoint image in pinned memory (render_launch), ...
+    const void* adj_src_dev = nullptr;    // ... as the device addresses it; render_impl either hands this to the kernels or copies it
+    size_t adj_bytes = 0;
+    bool adj_pending = false;
+    bool zero_copy_next = false;          // set around the render_launch of a host-buffer render whose finishing kernels store the image into the pinned block
+    struct PinnedRange { uint8_t* host; size_t bytes; uint8_t* dev; };
+    std::vector<PinnedRange> pinned;      // drt_hip_pin_host: caller buffers the finishing kernels may write directly
+    uint64_t done_seq = 0;                // completion words handed out so far (render_collect)
     uint64_t dev_frames = 0;              // renders made with DRT_RENDER_ALLREDUCE_ASYNC (their gradient set alternates)
     int slot = 0;                         // which of the double-buffered sets (grad, segtotal, out, h_stage) this render uses
     DevBuf probe;

@@ -139,6 +139,10 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
     if (ctx->d_params_d) (void)hipFree(ctx->d_params_d);
     if (ctx->h_probe)
         (void)hipHostFree(ctx->h_probe);
+    if (ctx->h_params)
+        (void)hipHostFree(ctx->h_params);
+    for (const drt_hip_ctx::PinnedRange& r : ctx->pinned)
+        (void)hipHostUnregister(r.host);
     for (int i = 0; i < DRT_HIP_FRAMES_IN_FLIGHT; ++i) {
         if (ctx->h_stage[i])
             (void)hipHostFree(ctx->h_stage[i]);
@@ -164,6 +168,49 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
 } // extern "C"
 
 extern "C" {
+
+// ---- caller buffers the finishing kernels write directly (ABI v7) -----------------------------------------------------
+int drt_hip_pin_host(drt_hip_ctx* ctx, void* ptr, size_t bytes)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    if (!ctx->members.empty())
+        return fail(ctx, DRT_ERR_UNSUPPORTED, "pin_host: not on a group context");
+    if (!ptr || bytes == 0)
+        return fail(ctx, DRT_ERR_INVALID, "pin_host: NULL or empty range");
+    for (const drt_hip_ctx::PinnedRange& r : ctx->pinned)
+        if ((uint8_t*)ptr < r.host + r.bytes && r.host < (uint8_t*)ptr + bytes)
+            return fail(ctx, DRT_ERR_INVALID, "pin_host: the range overlaps one that is pinned already");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    void* dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, ptr, 0);
+    if (e != hipSuccess || !dev) {
+        (void)hipHostUnregister(ptr);
+        (void)hipGetLastError();
+        return fail(ctx, DRT_ERR_HIP, "pin_host: the range cannot be mapped into the device's address space");
+    }
+    ctx->pinned.push_back({(uint8_t*)ptr, bytes, (uint8_t*)dev});
+    return DRT_OK;
+}
+
+int drt_hip_unpin_host(drt_hip_ctx* ctx, void* ptr)
+{
+    if (!ctx)
+        return DRT_ERR_INVALID;
+    for (size_t i = 0; i < ctx->pinned.size(); ++i)
+        if (ctx->pinned[i].host == (uint8_t*)ptr) {
+            for (int f = 0; f < DRT_HIP_FRAMES_IN_FLIGHT; ++f)
+                if (ctx->in_flight[f])
+                    return fail(ctx, DRT_ERR_INVALID, "unpin_host: asynchronous frames are in flight -- drt_hip_wait for them first");
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipHostUnregister(ptr));
+            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+            return DRT_OK;
+        }
+    return fail(ctx, DRT_ERR_INVALID, "unpin_host: not the start of a pinned range");
+}
 
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats)

@@ -17,6 +17,18 @@ static void for_each_band(int height, int band, int n_shards, int shard, F&& fn)
 
 static int ensure_stage(drt_hip_ctx* ctx, RenderJob& j);
 
+// the device's view of [p, p + bytes) if the caller pinned a range that contains it (drt_hip_pin_host), else nullptr
+static uint8_t* pinned_alias(const drt_hip_ctx* ctx, const void* p, size_t bytes)
+{
+    const uint8_t* q = (const uint8_t*)p;
+    if (!q)
+        return nullptr;
+    for (const drt_hip_ctx::PinnedRange& r : ctx->pinned)
+        if (q >= r.host && q + bytes <= r.host + r.bytes)
+            return r.dev + (q - r.host);
+    return nullptr;
+}
+
 // phase 1: validate, set up, enqueue the whole pipeline; the gradient of THIS context's shard ends up in ctx->grad[ctx->slot]
 static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                          const float* adjoint_rgb, float* out_rgb, double* out_param_grad, drt_hip_stats* stats,
@@ -83,8 +95,14 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     const float* d_adj = nullptr;
     if (out_rgb) {
         if ((rc = ensure(ctx, ctx->film, (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double))) != DRT_OK) return rc;
+        uint8_t* pinned_out = j.dev_out ? nullptr : pinned_alias(ctx, out_rgb, npix_all * 3 * sizeof(float));
         if (j.dev_out) {
             j.d_out = out_rgb;
+        } else if (pinned_out) {
+            // (the caller pinned this buffer, drt_hip_pin_host: the finishing kernels write the image straight into it)
+            j.direct_out = true;
+            if ((rc = ensure_stage(ctx, j)) != DRT_OK) return rc;
+            j.d_out = (float*)pinned_out;
         } else {
             if (ctx->zero_copy_next) {
                 // (the finishing kernels write the image into the pinned block of this frame: no device image, no copy)
@@ -103,8 +121,20 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
             if (j.dev_out) {
                 d_adj = adjoint_rgb;
             } else {
+                // The adjoint image in pinned memory: the caller's own buffer if he pinned it (drt_hip_pin_host), else a copy in the
+                // context's pinned block.  render_impl decides how the kernels get it (adjoint_to_device): small frames on the
+                // one-launch route read it from there, one 12-byte load per pixel -- no DMA in front of the frame, ~20 us of a
+                // small frame --, everything else gets it copied into device memory (the tape route reads it per PATH).
                 if ((rc = ensure(ctx, ctx->adjoint, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
-                HIPCHK(ctx, hipMemcpyAsync(ctx->adjoint.p, adjoint_rgb, npix_all * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                ctx->adj_src_host = adjoint_rgb;
+                ctx->adj_src_dev = pinned_alias(ctx, adjoint_rgb, npix_all * 3 * sizeof(float));
+                if (!ctx->adj_src_dev) {
+                    if ((rc = ensure_stage(ctx, j)) != DRT_OK) return rc;
+                    memcpy(ctx->h_stage[ctx->slot] + j.off_adj, adjoint_rgb, npix_all * 3 * sizeof(float));
+                    ctx->adj_src_host = ctx->adj_src_dev = ctx->h_stage[ctx->slot] + j.off_adj;
+                }
+                ctx->adj_bytes = npix_all * 3 * sizeof(float);
+                ctx->adj_pending = true;
                 d_adj = (const float*)ctx->adjoint.p;
             }
         }
@@ -113,8 +143,12 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         const size_t fb = (size_t)(j.n_local_pixels ? j.n_local_pixels : 1) * 3 * sizeof(double);
         if ((rc = ensure(ctx, ctx->gfilm, fb)) != DRT_OK) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->gfilm.p, 0, fb, ctx->stream));
+        uint8_t* pinned_gimg = j.dev_out ? nullptr : pinned_alias(ctx, out_gimg, npix_all * 3 * sizeof(float));
         if (j.dev_out) {
             j.d_gimg = out_gimg;
+        } else if (pinned_gimg) {
+            j.direct_gimg = true;
+            j.d_gimg = (float*)pinned_gimg;
         } else {
             if ((rc = ensure(ctx, ctx->gimg_out, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
             j.d_gimg = (float*)ctx->gimg_out.p;
@@ -131,6 +165,9 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
         else
             rc = render_impl<float>(ctx, cam, rp, d_adj, j.d_out, j.backward, j.timing, &j.st, j.n_local_pixels,
                                     depth_cap, &j.n_count_words, d_film, gimg_param, (double*)ctx->gfilm.p, j.d_gimg);
+    }
+    if (ctx->adj_pending) {          // (no kernel wanted it: a shard without rows)
+        ctx->adj_pending = false;
     }
     return rc;
 }
@@ -183,16 +220,18 @@ static int ensure_copy_stream(drt_hip_ctx* ctx)
     return DRT_OK;
 }
 
-// the context's pinned block of one render: [totals 64 B | gradients | image | gradient image]
+// the context's pinned block of one render: [totals 64 B | completion word (a line of its own) | gradients | image | gradient image | adjoint image]
+#define DRT_STAGE_DONE 64
 static int ensure_stage(drt_hip_ctx* ctx, RenderJob& j)
 {
     const size_t npix_all = (size_t)j.cam.width * j.cam.height;
     j.img_bytes = npix_all * 3 * sizeof(float);
     j.grad_bytes = (size_t)ctx->n_user_params * 3 * sizeof(double);
-    j.off_grad = 64;
+    j.off_grad = 128;
     j.off_img = j.off_grad + ((j.grad_bytes + 15) & ~(size_t)15);
     j.off_gimg = j.off_img + j.img_bytes;
-    const size_t need = j.off_gimg + j.img_bytes;
+    j.off_adj = j.off_gimg + j.img_bytes;
+    const size_t need = j.off_adj + ((j.adjoint_rgb && !j.dev_out) ? j.img_bytes : 0);
     if (ctx->h_stage_cap[ctx->slot] < need) {
         if (ctx->h_stage[ctx->slot])
             (void)hipHostFree(ctx->h_stage[ctx->slot]);
@@ -206,15 +245,25 @@ static int ensure_stage(drt_hip_ctx* ctx, RenderJob& j)
 
 // asynchronous host-buffer renders: gradients and totals of the frame -> the pinned block, written by the device (one
 // small launch in stream order; the image got there from the finishing kernels)
+// The LAST launch of a synchronous host-buffer render: with everything of the frame stored (this wave's own words fenced
+// behind it), it sets the block's completion word to `seq` -- the caller polls that word instead of waiting for the
+// runtime to notice the end of the stream (render_finish).
 __global__ void __launch_bounds__(DRT_WAVE) k_results_to_host(const double* __restrict__ grad, int n_grad, const uint8_t* __restrict__ requires_grad_dev,
                                                               const unsigned long long* __restrict__ totals, double* __restrict__ h_grad,
-                                                              unsigned long long* __restrict__ h_totals)
+                                                              unsigned long long* __restrict__ h_totals, unsigned long long* __restrict__ h_done = nullptr,
+                                                              unsigned long long seq = 0)
 {
     (void)requires_grad_dev;
     for (int i = threadIdx.x; i < n_grad; i += DRT_WAVE)
         h_grad[i] = grad[i];
-    if (threadIdx.x < DRT_TOTAL_WORDS)
+    if (totals && threadIdx.x < DRT_TOTAL_WORDS)
         h_totals[threadIdx.x] = totals[threadIdx.x];
+    if (h_done) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(h_done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // the same for the two-stream form, image included: the rows of this shard (full-frame layout on both sides), float by float
@@ -274,24 +323,12 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t c
         if (rc != DRT_OK) return rc;
     }
     (void)npix_all;
-    if (j.zero_copy) {
-        // (asynchronous host-buffer render: the image is in the pinned block already -- the finishing kernels wrote it
-        //  there; gradients and totals follow by one small launch)
-        ctx->h_segments = 0;
-        j.want_segments = j.stats && j.n_count_words;
-        hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(DRT_WAVE), 0, cs, (const double*)ctx->grad[ctx->slot].p,
-                           (j.backward && j.out_param_grad && with_grad) ? ctx->n_user_params * 3 : 0, (const uint8_t*)nullptr,
-                           (const unsigned long long*)ctx->segtotal[ctx->slot].p, (double*)(ctx->h_stage[ctx->slot] + j.off_grad),
-                           (unsigned long long*)ctx->h_stage[ctx->slot]);
-        HIPCHK(ctx, hipGetLastError());
-        return DRT_OK;
-    }
     if (j.copy_kernel) {
         // (asynchronous host-buffer render, two-stream form: everything of the frame crosses the link in one launch on the
         //  copy stream while the next frame's kernels run)
         ctx->h_segments = 0;
         j.want_segments = j.stats && j.n_count_words;
-        const bool img = j.out_rgb && j.n_local_pixels;
+        const bool img = j.out_rgb && j.n_local_pixels && !j.direct_out;   // (a pinned caller buffer holds its image already)
         const int copy_blocks = tuning().copy_blocks;
         hipLaunchKernelGGL(k_frame_to_host, dim3(copy_blocks), dim3(DRT_BLOCK), 0, cs, img ? (const float*)j.d_out : (const float*)nullptr,
                            (float*)(ctx->h_stage[ctx->slot] + j.off_img), (uint32_t)j.cam.width * 3u,
@@ -302,6 +339,8 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t c
         HIPCHK(ctx, hipGetLastError());
         return DRT_OK;
     }
+    ctx->h_segments = 0;
+    j.want_segments = j.stats && j.n_count_words;
     if (!j.dev_out) {
         const size_t row_bytes = (size_t)j.cam.width * 3 * sizeof(float);
         hipError_t e = hipSuccess;
@@ -312,18 +351,24 @@ static int render_collect(drt_hip_ctx* ctx, bool with_grad = true, hipStream_t c
                                        (size_t)(y1 - y0) * row_bytes, hipMemcpyDeviceToHost, cs);
             });
         };
-        if (j.out_rgb && j.n_local_pixels)
+        // (the image is where it belongs already when the finishing kernels stored it into the pinned block -- synchronous
+        //  renders, the one-stream asynchronous form -- or into the caller's own pinned buffer)
+        if (j.out_rgb && j.n_local_pixels && !j.zero_copy && !j.direct_out)
             rows_to_stage(j.d_out, j.off_img);
-        if (j.gimg_param >= 0 && j.out_gimg && j.n_local_pixels)
+        if (j.gimg_param >= 0 && j.out_gimg && j.n_local_pixels && !j.direct_gimg)
             rows_to_stage(j.d_gimg, j.off_gimg);
         HIPCHK(ctx, e);
-        if (j.backward && j.out_param_grad && with_grad)
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage[ctx->slot] + j.off_grad, ctx->grad[ctx->slot].p, j.grad_bytes, hipMemcpyDeviceToHost, cs));
-    }
-    ctx->h_segments = 0;
-    j.want_segments = j.stats && j.n_count_words;
-    if (j.want_segments)
+        // gradients, totals and the completion word: ONE small launch behind everything else of the frame
+        j.done_seq = ++ctx->done_seq;
+        hipLaunchKernelGGL(k_results_to_host, dim3(1), dim3(DRT_WAVE), 0, cs, (const double*)ctx->grad[ctx->slot].p,
+                           (j.backward && j.out_param_grad && with_grad) ? ctx->n_user_params * 3 : 0, (const uint8_t*)nullptr,
+                           j.want_segments ? (const unsigned long long*)ctx->segtotal[ctx->slot].p : (const unsigned long long*)nullptr,
+                           (double*)(ctx->h_stage[ctx->slot] + j.off_grad), (unsigned long long*)ctx->h_stage[ctx->slot],
+                           (unsigned long long*)(ctx->h_stage[ctx->slot] + DRT_STAGE_DONE), (unsigned long long)j.done_seq);
+        HIPCHK(ctx, hipGetLastError());
+    } else if (j.want_segments) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_stage[ctx->slot], ctx->segtotal[ctx->slot].p, DRT_TOTAL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    }
     return DRT_OK;
 }
 
@@ -334,8 +379,25 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true, hipEvent_t don
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (done)
         HIPCHK(ctx, hipEventSynchronize(done));       // (an asynchronous render: its copies are complete; later frames may still run)
-    else if (j.sync)
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    else if (j.sync) {
+        // A host-buffer render ends with a launch that sets the block's completion word: poll it (the runtime's own wait
+        // notices the end of a stream ~10-20 us late, a third of a small frame) -- for a bounded time, so that a fault on the
+        // device still surfaces through hipStreamSynchronize.
+        bool seen = false;
+        if (j.done_seq && !j.timing && tuning().sync_spin_us > 0 && ctx->h_stage[ctx->slot]) {
+            const volatile unsigned long long* w = (const volatile unsigned long long*)(ctx->h_stage[ctx->slot] + DRT_STAGE_DONE);
+            const auto t_spin = std::chrono::steady_clock::now();
+            for (uint32_t it = 0;; ++it) {
+                if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == (unsigned long long)j.done_seq) { seen = true; break; }
+                __builtin_ia32_pause();
+                if ((it & 255u) == 255u &&
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_spin).count() > (double)tuning().sync_spin_us)
+                    break;
+            }
+        }
+        if (!seen)
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     unsigned long long h_tot[DRT_TOTAL_WORDS] = {0};
     if (j.want_segments)
         memcpy(h_tot, ctx->h_stage[ctx->slot], sizeof h_tot);
@@ -347,9 +409,9 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true, hipEvent_t don
                 memcpy((uint8_t*)dst + (size_t)y0 * row_bytes, ctx->h_stage[ctx->slot] + off + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes);
             });
         };
-        if (j.out_rgb && j.n_local_pixels)
+        if (j.out_rgb && j.n_local_pixels && !j.direct_out)
             rows_to_caller(j.out_rgb, j.off_img);
-        if (j.gimg_param >= 0 && j.out_gimg && j.n_local_pixels)
+        if (j.gimg_param >= 0 && j.out_gimg && j.n_local_pixels && !j.direct_gimg)
             rows_to_caller(j.out_gimg, j.off_gimg);
         if (j.backward && j.out_param_grad && with_grad) {
             memcpy(j.out_param_grad, ctx->h_stage[ctx->slot] + j.off_grad, j.grad_bytes);
@@ -525,8 +587,11 @@ static int render_common(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copied[ctx->slot], 0));
     }
     ctx->overlap_next = (ar_async || dev_async) && !(rp->flags & DRT_RENDER_SERIAL);
+    // (host buffers: the finishing kernels store the image into the context's pinned block -- no copy launch behind them)
+    ctx->zero_copy_next = rp && !(rp->flags & DRT_RENDER_DEVICE_OUT) && tuning().sync_zero_copy;
     rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, stats, gimg_param, out_gimg);
     ctx->overlap_next = false;
+    ctx->zero_copy_next = false;
     if (rc != DRT_OK) {
         abort_comm_after_failure(ctx, rp);
         ctx->slot = 0;

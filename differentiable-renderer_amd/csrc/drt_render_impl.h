@@ -958,6 +958,15 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     memcpy(&s.bvh, sizeof(R) == 4 ? (const void*)&ctx->bvh_f : (const void*)&ctx->bvh_d, sizeof s.bvh);
     shard_plan(s);
     int rc;
+    if (ctx->adj_pending && s.d_adjoint) {
+        // a host-buffer render's adjoint image sits in pinned memory: the one-launch routes read a pixel's seed ONCE per lane, so
+        // a small frame takes it from there; everything else (the tape route reads it per path) gets the copy in device memory
+        ctx->adj_pending = false;
+        if (s.use_path && (size_t)n_local_pixels * 3 * sizeof(float) <= ((size_t)1 << 20))
+            s.d_adjoint = (const float*)ctx->adj_src_dev;
+        else
+            HIPCHK(ctx, hipMemcpyAsync(ctx->adjoint.p, ctx->adj_src_host, ctx->adj_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     if ((rc = shard_buffers(s)) != DRT_OK) return rc;
     *n_count_words = s.cw;
     if (!s.path_finish) {

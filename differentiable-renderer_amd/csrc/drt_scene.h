@@ -373,6 +373,16 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     return DRT_OK;
 }
 
+// new parameter values -> both compute types' vectors, in stream order (one launch that reads the context's pinned copy)
+__global__ void __launch_bounds__(DRT_BLOCK) k_set_params(const double* __restrict__ h_params, int n, float* __restrict__ pf, double* __restrict__ pd)
+{
+    for (int i = threadIdx.x; i < n; i += DRT_BLOCK) {
+        const double v = h_params[i];
+        pf[i] = (float)v;
+        pd[i] = v;
+    }
+}
+
 int update_params_one(drt_hip_ctx* ctx, const double* params)
 {
     if (!ctx)
@@ -382,12 +392,26 @@ int update_params_one(drt_hip_ctx* ctx, const double* params)
     if (!params)
         return fail(ctx, DRT_ERR_INVALID, "params is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<float> pf((size_t)ctx->n_user_params * 3);   // internal constants keep their values
-    for (size_t i = 0; i < pf.size(); ++i)
-        pf[i] = (float)params[i];
+    const size_t n = (size_t)ctx->n_user_params * 3;   // internal constants keep their values
+    if (n == 0)
+        return DRT_OK;
+    // (everything enqueued so far has read the old values by the time the pinned copy is overwritten: renders that do not
+    //  wait -- device pointers, asynchronous frames -- are the only ones that can still be running here)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(ctx->d_params_f, pf.data(), pf.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->d_params_d, params, pf.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; ++i)
+        if (ctx->path_stream[i])
+            HIPCHK(ctx, hipStreamSynchronize(ctx->path_stream[i]));
+    if (ctx->h_params_cap < n) {
+        if (ctx->h_params)
+            (void)hipHostFree(ctx->h_params);
+        ctx->h_params = nullptr;
+        ctx->h_params_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_params, n * sizeof(double)));
+        ctx->h_params_cap = n;
+    }
+    memcpy(ctx->h_params, params, n * sizeof(double));
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, (const double*)ctx->h_params, (int)n, ctx->d_params_f, ctx->d_params_d);
+    HIPCHK(ctx, hipGetLastError());
     return DRT_OK;
 }
 

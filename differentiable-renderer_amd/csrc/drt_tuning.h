@@ -32,6 +32,8 @@ struct Tuning {
     int mesh_shade_min = 32;       // DRT_HIP_MESH_SHADE_MIN       k_path_mesh: lanes with a final hit (or without a path) it takes to run the shade step
     // ---- host buffers, groups
     int copy_blocks = 64;          // DRT_HIP_COPY_BLOCKS      blocks of the launch that carries an asynchronous frame to the pinned block
+    bool sync_zero_copy = true;    // DRT_HIP_SYNC_ZERO_COPY   0: a synchronous host-buffer render copies its image with hipMemcpyAsync after the finishing kernel instead of having it stored into the pinned block
+    int sync_spin_us = 2000;       // DRT_HIP_SYNC_SPIN_US     how long a synchronous host-buffer render polls its completion word before it falls back to hipStreamSynchronize (0: never polls)
     bool async_copy_inline = false;// DRT_HIP_ASYNC_COPY       inline: asynchronous frames on ONE stream, the finishing kernels store into the pinned block
     bool group_threads = true;     // DRT_HIP_GROUP_THREADS    0: a group context's members enqueue in turn, not from a thread each
     // ---- debugging
@@ -62,6 +64,8 @@ inline const Tuning& tuning()
         v.mesh_path_max = num("DRT_HIP_MESH_PATH_MAX", 1 << 20);
         v.mesh_shade_min = (int)num("DRT_HIP_MESH_SHADE_MIN", 32);
         v.copy_blocks = (int)num("DRT_HIP_COPY_BLOCKS", 64);
+        v.sync_zero_copy = !off("DRT_HIP_SYNC_ZERO_COPY");
+        v.sync_spin_us = (int)num("DRT_HIP_SYNC_SPIN_US", 2000);
         v.async_copy_inline = getenv("DRT_HIP_ASYNC_COPY") && !strcmp(getenv("DRT_HIP_ASYNC_COPY"), "inline");
         v.group_threads = !off("DRT_HIP_GROUP_THREADS");
         v.dump_path = num("DRT_HIP_DUMP_PATH", -1);

@@ -37,6 +37,10 @@
  *                           create_group = one process, n devices; comm_init_rank = one process per
  *                           GPU (the launcher broadcasts the 128-byte id out of band).
  *
+ *   drt_hip_pin_host        nothing in the reference (its image is a `new Vector<double,3>[W*H]` the loop writes in place,
+ *                           src/render.cpp:66,82): lets the device do the same -- write the frame straight into the caller's
+ *                           buffer -- for callers that render frame after frame.
+ *
  * There is NO CPU fallback behind this ABI: without a HIP device drt_hip_create fails with
  * DRT_ERR_NO_DEVICE.
  */
@@ -57,7 +61,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 6
+#define DRT_HIP_ABI_VERSION 7
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -296,6 +300,14 @@ int drt_hip_set_specialisation(drt_hip_ctx* ctx, int mode);
 int drt_hip_render(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_params* rp,
                    const float* adjoint_rgb, float* out_rgb, double* out_param_grad,
                    drt_hip_stats* stats);
+/* A caller that renders frame after frame into the SAME host buffers (the loop of src/render.cpp:72-90 inside an optimisation
+ * loop) can hand them to the context once: drt_hip_pin_host page-locks [ptr, ptr + bytes) and maps it into the device's
+ * address space (hipHostRegister), and every later render whose out_rgb (or out_grad_rgb) lies inside a pinned range gets its
+ * image written THERE by the finishing kernel -- no staging block, no memcpy at the end of the call (config 3: 3 MB per
+ * frame).  The range must stay allocated until drt_hip_unpin_host(ptr) or drt_hip_destroy; results are bit-identical.
+ * Plain contexts (a group context's members render into their own staging blocks). */
+int drt_hip_pin_host(drt_hip_ctx* ctx, void* ptr, size_t bytes);
+int drt_hip_unpin_host(drt_hip_ctx* ctx, void* ptr);
 #define DRT_HIP_FRAMES_IN_FLIGHT 4
 
 /* The same call WITHOUT the wait at its end, for callers that render frame after frame (the loop of src/render.cpp:72-90

@@ -408,3 +408,55 @@ def test_bench_eight_ranks_plumbing():
     assert "8 ranks" in line["config"]["parallelism"]
     assert line["config"]["paths_per_step"] == 8 * 128 * 128 * 2
     assert "weak_scaling" in line
+
+
+def test_pinned_caller_buffers_get_the_same_bits(pkg):
+    """drt_hip_pin_host (ABI v7): a render whose out_rgb (or gradient image) lies inside a pinned range is written there by the
+    finishing kernel -- same bits as through the staging block, for k_path, the queue wavefront, shards, the gradient image
+    and asynchronous frames; overlapping ranges and unknown pointers are refused; after unpin the buffer is an ordinary one."""
+    r = pkg.HipRenderer(0)
+    try:
+        scene = pkg.cornell_box()
+        cam = pkg.cornell_camera(96, 64)
+        r.upload_scene(scene)
+        rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=5, band_rows=8)
+        adj = np.random.RandomState(2).uniform(0, 1, (64, 96, 3)).astype(np.float32)
+        ref, gref, _ = r.render(cam, rp, backward=True, adjoint=adj)
+        block = np.zeros((3, 64, 96, 3), dtype=np.float32)        # one pinned range, three images in it
+        r.pin_host(block)
+        with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
+            r.pin_host(block[1])                                   # overlaps
+        img, g, st = r.render(cam, rp, backward=True, adjoint=adj, img_out=block[1])
+        assert img is block[1] and st["segments"] > 0
+        np.testing.assert_array_equal(img, ref)
+        np.testing.assert_array_equal(g, gref)
+        assert not block[0].any() and not block[2].any()
+        # the adjoint itself may be pinned too (no staging copy)
+        block[2][:] = adj
+        img, g, _ = r.render(cam, rp, backward=True, adjoint=block[2], img_out=block[0], want_stats=False)
+        np.testing.assert_array_equal(img, ref)
+        np.testing.assert_array_equal(g, gref)
+        # the queue wavefront and a shard of the frame
+        rq = dataclasses.replace(rp, bounces_per_launch=1, shard=1, n_shards=2)
+        want, gq, _ = r.render(cam, rq, backward=True)
+        block[0][:] = -1.0
+        img, g, _ = r.render(cam, rq, backward=True, img_out=block[0])
+        rows = pkg.shard_rows(64, 8, 2, 1)
+        np.testing.assert_array_equal(img[rows], want[rows])
+        np.testing.assert_array_equal(g, gq)
+        other = np.setdiff1d(np.arange(64), rows)
+        assert (img[other] == -1.0).all()                          # rows of the other shard are not touched
+        # asynchronous frames into pinned buffers
+        hs = [r.render_async(cam, dataclasses.replace(rp, seed=s), backward=True, img_out=block[i]) for i, s in enumerate((7, 8, 9))]
+        outs = [r.wait(h) for h in hs]
+        for (im, gg, _), s in zip(outs, (7, 8, 9)):
+            w, gw, _ = r.render(cam, dataclasses.replace(rp, seed=s), backward=True)
+            np.testing.assert_array_equal(im, w)
+            np.testing.assert_array_equal(gg, gw)
+        with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
+            r.unpin_host(block[1])                                 # not the start of a pinned range
+        r.unpin_host(block)
+        img, g, _ = r.render(cam, rp, backward=True, adjoint=adj, img_out=block[1])
+        np.testing.assert_array_equal(img, ref)
+    finally:
+        r.close()

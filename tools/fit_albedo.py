@@ -64,6 +64,12 @@ class DeviceRender:
         self.r = pkg.HipRenderer(0)
         self.r.upload_scene(self.scene)
         self.params0 = np.array(self.scene.params, dtype=np.float64)
+        # the loop renders into the same two image buffers (the forward frame's, the gradient frame's), pinned once: the
+        # finishing kernel stores a frame straight into its buffer
+        self.img = [np.zeros((size, size, 3), dtype=np.float32) for _ in range(2)]
+        if not use_async:
+            for im in self.img:
+                self.r.pin_host(im)
         self.calls = 0
         self.target, _ = self(self.params0, 1, False, None, spp=256)
         self.target = self.target.astype(np.float64)
@@ -76,7 +82,7 @@ class DeviceRender:
         if self.use_async:
             img, g, _ = self.r.wait(self.r.render_async(self.cam, rp, backward=backward, adjoint=adjoint), want_stats=False)
         else:
-            img, g, _ = self.r.render(self.cam, rp, backward=backward, adjoint=adjoint)
+            img, g, _ = self.r.render(self.cam, rp, backward=backward, adjoint=adjoint, img_out=self.img[1 if backward else 0], want_stats=False)
         return img, g
 
 
