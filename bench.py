@@ -114,6 +114,9 @@ def parse_args(argv):
                     help="roulette absorption probability (the reference's -p; 1 = every path ends at --depth, the configs' setting)")
     ap.add_argument("--min-bounces", type=int, default=0,
                     help="the reference's -b; default = --depth.  '--absorb 0.5 --min-bounces 1' = the reference's own defaults")
+    ap.add_argument("--per-face", action="store_true",
+                    help="mesh scenes: an albedo parameter of its own for EVERY face (drt_mesh_desc::face_param; config 4 as SURVEY 8d "
+                         "words it: 50,880 + 4 parameters, a 1.2 MB gradient vector through K6's fp64 atomics, K7 and the all-reduce)")
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--unbiased", action="store_true", help="backward with the unbiased integration operator")
     ap.add_argument("--batch-paths", type=int, default=0)
@@ -148,11 +151,14 @@ def parse_args(argv):
     a.spp = a.spp or cfg["spp"]
     a.depth = a.depth or cfg["depth"]
     a.scene = a.scene or cfg["scene"]
+    if a.per_face and a.scene.startswith("mesh") and "f" not in a.scene[4:]:
+        a.scene += "fall"
     a.forward_only = a.forward_only or cfg["forward_only"]
     a.min_bounces = a.min_bounces or a.depth
     a.roulette = a.absorb < 1.0
-    a.is_config = all(getattr(a, k) == v for k, v in cfg.items() if k != "name") and not a.roulette and a.min_bounces == a.depth
-    a.config_name = cfg["name"] if a.is_config else "custom"
+    a.is_config = all(getattr(a, k) == v or (k == "scene" and a.per_face and getattr(a, k) == v + "fall") for k, v in cfg.items() if k != "name") and \
+                  not a.roulette and a.min_bounces == a.depth
+    a.config_name = (cfg["name"] + (", an albedo parameter per face" if a.per_face else "")) if a.is_config else "custom"
     return a
 
 

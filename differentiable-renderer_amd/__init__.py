@@ -58,7 +58,7 @@ class ShapeDesc(C.Structure):
 class MeshDesc(C.Structure):
     _fields_ = [("n_vertices", C.c_int32), ("n_triangles", C.c_int32),
                 ("vertices", C.POINTER(C.c_double)), ("indices", C.POINTER(C.c_uint32)),
-                ("face_material", C.POINTER(C.c_int32))]
+                ("face_material", C.POINTER(C.c_int32)), ("face_param", C.POINTER(C.c_int32))]
 
 
 class MaterialDesc(C.Structure):
@@ -127,6 +127,7 @@ class Scene:
     emitters: List[int] = field(default_factory=list)                       # param
     shapes: List[Tuple[int, int, int, Tuple[float, float, float, float]]] = field(default_factory=list)
     meshes: list = field(default_factory=list)   # (vertices f64 [nv,3], indices u32 [nt,3], face_material i32 [nt] | None)
+    mesh_face_param: list = field(default_factory=list)   # per mesh: colour-parameter index per face i32 [nt] (-1: the material's) | None
 
     # Vector<T,3,true>(value, requires_grad), vector.hpp:228-234
     def parameter(self, rgb: Sequence[float], requires_grad: bool = True, name: str = "") -> int:
@@ -168,18 +169,49 @@ class Scene:
         return len(self.shapes) - 1
 
     # extension: a triangle mesh standing for its triangles at this position of the scene
-    def mesh(self, vertices, indices, material: int = -1, emitter: int = -1, face_material=None) -> int:
+    def mesh(self, vertices, indices, material: int = -1, emitter: int = -1, face_material=None, face_param=None) -> int:
+        """face_param: a colour parameter of its own per face (drt_mesh_desc::face_param: the face's BxDF has the type and
+        exponent of its material and this colour; -1 = the material's own)."""
         v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
         i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
         fm = None if face_material is None else np.ascontiguousarray(face_material, dtype=np.int32).reshape(-1)
-        assert i.max() < len(v) and (fm is None or len(fm) == len(i))
+        fp = None if face_param is None else np.ascontiguousarray(face_param, dtype=np.int32).reshape(-1)
+        assert i.max() < len(v) and (fm is None or len(fm) == len(i)) and (fp is None or len(fp) == len(i))
         self.meshes.append((v, i, fm))
+        while len(self.mesh_face_param) < len(self.meshes) - 1:
+            self.mesh_face_param.append(None)
+        self.mesh_face_param.append(fp)
         self.shapes.append((SHAPE_MESH, material, emitter, (float(len(self.meshes) - 1), 0.0, 0.0, 0.0)))
         return len(self.shapes) - 1
 
     @property
     def n_params(self) -> int:
         return len(self.params)
+
+    def with_face_params_as_materials(self) -> "Scene":
+        """The same scene with every per-face colour parameter spelled out as a material of its own (what the reference
+        does: a BxDF object per face) -- for the reference harness and for pinning face_param against face_material."""
+        import copy
+        s = copy.deepcopy(self)
+        s.mesh_face_param = [None] * len(s.meshes)
+        for k, (v, idx, fm) in enumerate(self.meshes):
+            fp = self.mesh_face_param[k] if k < len(self.mesh_face_param) else None
+            if fp is None:
+                continue
+            shape_mat = next(m for (t, m, e, p) in self.shapes if t == SHAPE_MESH and int(p[0]) == k)
+            base = fm if fm is not None else np.full(len(idx), shape_mat, dtype=np.int32)
+            new_fm = base.copy()
+            made = {}
+            for t in range(len(idx)):
+                if fp[t] >= 0 and base[t] >= 0 and self.materials[base[t]][0] != BXDF_MIRROR:
+                    key = (int(base[t]), int(fp[t]))
+                    if key not in made:
+                        ty, _, ex = self.materials[base[t]]
+                        s.materials.append((ty, int(fp[t]), ex))
+                        made[key] = len(s.materials) - 1
+                    new_fm[t] = made[key]
+            s.meshes[k] = (v, idx, new_fm)
+        return s
 
     def to_desc(self):
         """-> (SceneDesc, keepalive list). Pointers stay valid while keepalive is referenced."""
@@ -195,22 +227,21 @@ class Scene:
         emis = (EmitterDesc * max(1, len(self.emitters)))()
         for i, p in enumerate(self.emitters):
             emis[i].param = p
-        params = (C.c_double * max(1, 3 * len(self.params)))()
-        for i, rgb in enumerate(self.params):
-            for j in range(3):
-                params[3 * i + j] = rgb[j]
-        rg = (C.c_uint8 * max(1, len(self.params)))()
-        for i, r in enumerate(self.requires_grad):
-            rg[i] = 1 if r else 0
+        pa = np.ascontiguousarray(np.asarray(self.params, dtype=np.float64).reshape(-1)) if self.params else np.zeros(3)
+        params = (C.c_double * max(1, 3 * len(self.params))).from_buffer_copy(pa.tobytes()) if self.params else (C.c_double * 1)()
+        rga = np.asarray([1 if r else 0 for r in self.requires_grad], dtype=np.uint8)
+        rg = (C.c_uint8 * max(1, len(self.params))).from_buffer_copy(rga.tobytes()) if self.params else (C.c_uint8 * 1)()
         meshes = (MeshDesc * max(1, len(self.meshes)))()
         for i, (v, idx, fm) in enumerate(self.meshes):
             meshes[i].n_vertices, meshes[i].n_triangles = len(v), len(idx)
             meshes[i].vertices = v.ctypes.data_as(C.POINTER(C.c_double))
             meshes[i].indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
             meshes[i].face_material = fm.ctypes.data_as(C.POINTER(C.c_int32)) if fm is not None else None
+            fp = self.mesh_face_param[i] if i < len(self.mesh_face_param) else None
+            meshes[i].face_param = fp.ctypes.data_as(C.POINTER(C.c_int32)) if fp is not None else None
         d = SceneDesc(len(self.shapes), len(self.materials), len(self.emitters), len(self.params),
                       shapes, mats, emis, params, rg, len(self.meshes), 0, meshes)
-        return d, [shapes, mats, emis, params, rg, meshes, self.meshes]
+        return d, [shapes, mats, emis, params, rg, meshes, self.meshes, self.mesh_face_param]
 
 
 def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front_mirror: bool = False,
@@ -324,16 +355,27 @@ def displaced_sphere_mesh(n_lat: int, n_lon: int, center=(0., -1.2, 3.6), radius
 def cornell_with_mesh(n_lat: int = 160, n_lon: int = 160, per_face_params: int = 0, seed: int = 1234) -> Scene:
     """BASELINE config 4 shape: the Cornell box of render.cpp with a displaced-sphere mesh in it
     (in place of sphere_front).  per_face_params > 0 gives the mesh that many albedo parameters,
-    assigned to faces round-robin (per-face materials)."""
+    assigned to faces round-robin (per-face materials); per_face_params < 0 gives EVERY face an albedo of its own
+    (drt_mesh_desc::face_param: 50,880 parameters for the 160 x 160 mesh -- config 4 as SURVEY 8d words it)."""
     s = cornell_box()
     v, idx = displaced_sphere_mesh(n_lat, n_lon, seed=seed)
     white_mat = 2
     fm = None
+    fp = None
     if per_face_params > 0:
         rs = np.random.RandomState(seed + 1)
         mats = [s.diffuse(s.parameter(rs.uniform(0.2, 0.9, 3), True, f"face{i}")) for i in range(per_face_params)]
         fm = np.array([mats[t % per_face_params] for t in range(len(idx))], dtype=np.int32)
+    elif per_face_params < 0:
+        rs = np.random.RandomState(seed + 1)
+        first = len(s.params)
+        alb = rs.uniform(0.2, 0.9, (len(idx), 3))
+        s.params.extend(tuple(float(x) for x in a) for a in alb)
+        s.requires_grad.extend([True] * len(idx))
+        s.param_names.extend(f"face{i}" for i in range(len(idx)))
+        fp = np.arange(first, first + len(idx), dtype=np.int32)
     s.meshes.append((v, idx, fm))
+    s.mesh_face_param.append(fp)
     s.shapes[0] = (SHAPE_MESH, white_mat, -1, (float(len(s.meshes) - 1), 0.0, 0.0, 0.0))
     return s
 
@@ -354,10 +396,10 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box(front_specular=True, mirror_wall=True)
     if name.startswith("random"):
         return random_scene(int(name[len("random"):]))
-    if name.startswith("mesh"):          # mesh<n_lat>x<n_lon>[f<per-face params>]
+    if name.startswith("mesh"):          # mesh<n_lat>x<n_lon>[f<per-face params> | fall: an albedo per face]
         body, _, pf = name[4:].partition("f")
         a, b = body.split("x")
-        return cornell_with_mesh(int(a), int(b), int(pf) if pf else 0)
+        return cornell_with_mesh(int(a), int(b), -1 if pf == "all" else (int(pf) if pf else 0))
     raise KeyError(name)
 
 

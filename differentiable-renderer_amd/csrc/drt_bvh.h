@@ -21,7 +21,7 @@ struct Tri {
     double n[3];          // normalize(cross(e1, e2)), computed like the oracle does
     uint32_t global;      // index among all triangles of the scene (meshes in scene order)
     uint32_t flat;        // position in the flattened scene (tie order, pathtracer.hpp:80)
-    uint32_t ids;         // material | emitter << 16 (0xFFFF = none)
+    uint32_t ids;         // colour parameter (0xFFFF = no BxDF) | material << 16 (0xFF = none) | emitter << 24 (0xFF = none)
 };
 
 // child link: bit 31 clear = interior node index; bit 31 set = leaf, (first << 3) | count in the

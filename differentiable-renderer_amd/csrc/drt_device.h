@@ -101,7 +101,8 @@ __device__ inline uint32_t pid_unpack(double v) { return (uint32_t)v; }
 //   tri[j][0..2] (leaf order) = (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, global index, flat index, -): ONE 48-byte record per
 //                triangle -- as three arrays a leaf visit touched three cache lines, as records one or two, and a line
 //                is what a visit pays for (walk 4.17 -> 4.01 ms, profiles/r03_walk_experiments.txt)
-//   tri_shade[g] (global triangle order) = (normal.xyz, material | emitter << 16)
+//   tri_shade[g] (global triangle order) = (normal.xyz, colour parameter | material << 16 | emitter << 24): the face's own
+//                colour parameter (drt_mesh_desc::face_param) or its material's; 0xFFFF / 0xFF = none
 template <typename R>
 struct DevBvh {
     const uint4* node;                  // [n_nodes][4]

@@ -809,22 +809,25 @@ __device__ inline void load_shade_in(ShadeIn<R>& in, uint32_t slot, bool have, b
     }
 }
 
-// what was hit: position, normal (as the reference's Shape::normal returns it), material, emitter
+// what was hit: position, normal (as the reference's Shape::normal returns it), material, emitter, and the colour parameter
+// of its BxDF (the material's, or -- a mesh face with drt_mesh_desc::face_param -- the face's own)
 template <typename R, bool MESHES = true>
 __device__ inline void resolve_hit(const SceneLds<R>& lds, const typename Q4<R>::T* __restrict__ tri_shade,
-                                   int prim, V3<R> P, V3<R>& nrm, int& material, int& emitter)
+                                   int prim, V3<R> P, V3<R>& nrm, int& material, int& emitter, uint32_t& cparam)
 {
     if (!MESHES || prim < lds.sc.n_shapes) {
         const DevShape<R>& sh = lds.sc.shapes[prim];
         nrm = shape_normal(sh, P);
         material = sh.material;
         emitter = sh.emitter;
+        cparam = material >= 0 ? (uint32_t)lds.sc.materials[material].param : DRT_ID_NONE;
     } else {                                       // triangle: per-triangle record
         const typename Q4<R>::T ts = tri_shade[prim - lds.sc.n_shapes];
         const uint32_t ids = pid_unpack(ts.w);
         nrm = mk<R>(ts.x, ts.y, ts.z);
-        material = (ids & 0xFFFFu) == 0xFFFFu ? -1 : (int)(ids & 0xFFFFu);
-        emitter = (ids >> 16) == 0xFFFFu ? -1 : (int)(ids >> 16);
+        cparam = ids & 0xFFFFu;
+        material = ((ids >> 16) & 0xFFu) == 0xFFu ? -1 : (int)((ids >> 16) & 0xFFu);
+        emitter = (ids >> 24) == 0xFFu ? -1 : (int)(ids >> 24);
     }
 }
 
@@ -1024,20 +1027,28 @@ template <> struct GradAcc<float, 8> : GradAccF32<8> {};
 // The pointer travels through the accumulator interface as R (*)[DRT_BLOCK]; it points at DRT_LDS_PARAMS * 3 doubles.
 template <typename R>
 struct GradAcc<R, 0> {
+    // The first DRT_FAST_PARAMS parameters stay in registers here too: in a room with a mesh they are the walls' colours and
+    // the light -- most vertices of most paths -- and as LDS atomics they all land on the same few words (config 4 with an
+    // albedo per face, 50,884 parameters: K6 4.1 ms that way).  One-hot accumulation like GradAcc<R, 8>; ids beyond add nothing there.
+    GradAcc<R, DRT_FAST_PARAMS> fast;
     __device__ inline void init(R (*acc)[DRT_BLOCK])
     {
+        fast.init(acc);
         double* blk = reinterpret_cast<double*>(acc);
         for (int r = threadIdx.x; r < DRT_LDS_PARAMS * 3; r += DRT_BLOCK)
             blk[r] = 0.0;                        // (visible to the block after stage_scene's barrier)
     }
     __device__ inline void add(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
     {
-        double* dst = id < DRT_LDS_PARAMS ? reinterpret_cast<double*>(acc) + id * 3 : grad + id * 3;
-        atomicAdd(dst + 0, (double)v.x);
-        atomicAdd(dst + 1, (double)v.y);
-        atomicAdd(dst + 2, (double)v.z);
+        fast.add(acc, grad, id, v);
+        if (id >= DRT_FAST_PARAMS) {
+            double* dst = id < DRT_LDS_PARAMS ? reinterpret_cast<double*>(acc) + id * 3 : grad + id * 3;
+            atomicAdd(dst + 0, (double)v.x);
+            atomicAdd(dst + 1, (double)v.y);
+            atomicAdd(dst + 2, (double)v.z);
+        }
     }
-    __device__ inline double get(R (*)[DRT_BLOCK], int) const { return 0.0; }
+    __device__ inline double get(R (*acc)[DRT_BLOCK], int row) const { return fast.get(acc, row); }
 };
 
 // end of a gradient kernel: this block's sums -> gpart[block][row_stride] (fixed-order reduction over blocks: K7)
@@ -1046,6 +1057,17 @@ __device__ inline void flush_grad_block(GradAcc<R, NP>& ga, R (*acc)[DRT_BLOCK],
                                         double* __restrict__ gpart, int n_rows, int row_stride)
 {
     if (NP == 0) {
+        // the register rows (ids < DRT_FAST_PARAMS): thread -> wave by shuffles, then one LDS add per wave and row
+        const int lane0 = threadIdx.x & (DRT_WAVE - 1);
+#pragma unroll
+        for (int r = 0; r < DRT_FAST_PARAMS * 3; ++r) {
+            double v = ga.get(acc, r);
+#pragma unroll
+            for (int off = DRT_WAVE / 2; off > 0; off >>= 1)
+                v += __shfl_down(v, off);
+            if (lane0 == 0 && v != 0.0)
+                atomicAdd(reinterpret_cast<double*>(acc) + r, v);
+        }
         __syncthreads();
         const double* blk = reinterpret_cast<const double*>(acc);
         for (int r = threadIdx.x; r < n_rows; r += DRT_BLOCK)
@@ -1414,7 +1436,8 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                     const V3<R> P = o + d * h.t;                   // pathtracer.hpp:83
                     V3<R> nrm;
                     int material, emitter;
-                    resolve_hit<R, !FUSED>(lds, tri_shade, h.prim, P, nrm, material, emitter);
+                    uint32_t cparam;
+                    resolve_hit<R, !FUSED>(lds, tri_shade, h.prim, P, nrm, material, emitter, cparam);
                     // emission (pathtracer.hpp:113-114) is only RECORDED here: the tape walk adds it
                     const uint32_t eid = emitter >= 0 ? (uint32_t)lds.sc.emitter_param[emitter] : DRT_ID_NONE;
                     write_tape = true;
@@ -1446,7 +1469,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                         if (next_cap && !a.cap_is_roulette)
                             capped = !next_rr || !(rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold);
                         tr.m = mk_;
-                        tr.ids = (uint32_t)m.param | (eid << 16);
+                        tr.ids = cparam | (eid << 16);
                         ended = !alive;
                         const V3<R> no = P + wo * R(1e-3);         // pathtracer.hpp:99
                         na.x = no.x; na.y = no.y; na.z = no.z; na.w = wo.x;
@@ -1829,7 +1852,8 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
                 const V3<R> P = o + d * h.t;
                 V3<R> nrm;
                 int material, emitter;
-                resolve_hit(lds, tri_shade, h.prim, P, nrm, material, emitter);
+                uint32_t cparam;
+                resolve_hit(lds, tri_shade, h.prim, P, nrm, material, emitter, cparam);
                 const uint32_t eid = emitter >= 0 ? (uint32_t)lds.sc.emitter_param[emitter] : DRT_ID_NONE;
                 R4 wrec;
                 wrec.x = wrec.y = wrec.z = wrec.w = R(0);
@@ -1837,7 +1861,7 @@ k_adj_vertex(BatchArgs a, int r, const DevScene<R>* __restrict__ sc, const R* __
                 nv[i] = (uint32_t)s;                            // no suffix vertices unless K3 says so
                 if (material >= 0) {
                     const DevMaterial<R>& m = lds.sc.materials[material];
-                    cid = (uint32_t)m.param;
+                    cid = cparam;
                     const uint32_t n = cs.ndraw[i];
                     V3<R> wo;
                     R q, bs;

@@ -188,12 +188,11 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                 if (prim >= n_shapes) {                   // a triangle: its record comes from L2
                     const R4 ts = bvh.tri_shade[prim - n_shapes];
                     const uint32_t wd = pid_unpack(ts.w);
-                    const uint32_t mat = wd & 0xFFFFu, em = wd >> 16;
+                    const uint32_t mat = (wd >> 16) & 0xFFu, em = wd >> 24;       // (colour parameter | material << 16 | emitter << 24)
                     nrm = mk<R>(ts.x, ts.y, ts.z);
-                    material = mat == 0xFFFFu ? 0 : (int)mat;
-                    const uint32_t c_id = mat == 0xFFFFu ? DRT_ID_NONE : (uint32_t)lds.sc.materials[mat].param;
-                    const uint32_t e_id = em == 0xFFFFu ? DRT_ID_NONE : (uint32_t)lds.sc.emitter_param[em];
-                    ids = c_id | (e_id << 16);
+                    material = mat == 0xFFu ? 0 : (int)mat;
+                    const uint32_t e_id = em == 0xFFu ? DRT_ID_NONE : (uint32_t)lds.sc.emitter_param[em];
+                    ids = (wd & 0xFFFFu) | (e_id << 16);
                 } else {
                     const DevShape<R>& sh = lds.sc.shapes[hit ? prim : 0];   // (a miss reads record 0, uses nothing of it)
                     ids = (uint32_t)sh.pad;

@@ -217,6 +217,10 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
                 for (int t = 0; t < m.n_triangles; ++t)
                     if (m.face_material[t] < -1 || m.face_material[t] >= s->n_materials)
                         return fail(ctx, DRT_ERR_INVALID, "scene: face material index out of range");
+            if (m.face_param)
+                for (int t = 0; t < m.n_triangles; ++t)
+                    if (m.face_param[t] < -1 || m.face_param[t] >= s->n_params)
+                        return fail(ctx, DRT_ERR_INVALID, "scene: face parameter index out of range");
         } else if (sh.type != DRT_SHAPE_PLANE && sh.type != DRT_SHAPE_SPHERE)
             return fail(ctx, DRT_ERR_INVALID, "scene: unknown shape type");
         if (sh.material < -1 || sh.material >= s->n_materials || sh.emitter < -1 || sh.emitter >= s->n_emitters)
@@ -282,6 +286,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     release_mesh(ctx);
     {
         std::vector<drt_bvh::Tri> tris;
+        int max_face_param = -1;
         uint32_t flat = 0;
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int i = 0; i < s->n_shapes; ++i) {
@@ -307,7 +312,16 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
                 t.global = (uint32_t)tris.size();
                 t.flat = flat;
                 const int mat = m.face_material ? m.face_material[k] : sh.material;
-                t.ids = (uint32_t)(mat < 0 ? 0xFFFF : mat) | ((uint32_t)(sh.emitter < 0 ? 0xFFFF : sh.emitter) << 16);
+                // the face's colour parameter: its own (face_param) or its material's; a mirror's internal constant either way
+                uint32_t cpar = DRT_ID_NONE;
+                if (mat >= 0) {
+                    const bool mirror = s->materials[mat].type == DRT_BXDF_MIRROR;
+                    cpar = mirror ? (uint32_t)s->n_params
+                                  : (uint32_t)((m.face_param && m.face_param[k] >= 0) ? m.face_param[k] : s->materials[mat].param);
+                    if (!mirror)
+                        max_face_param = std::max(max_face_param, (int)cpar);
+                }
+                t.ids = cpar | ((uint32_t)(mat < 0 ? 0xFF : mat) << 16) | ((uint32_t)(sh.emitter < 0 ? 0xFF : sh.emitter) << 24);
                 tris.push_back(t);
             }
         }
@@ -341,6 +355,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
             if ((rc = upload_bvh<float>(ctx, built, tris, &ctx->bvh_f)) != DRT_OK) return rc;
             if ((rc = upload_bvh<double>(ctx, built, tris, &ctx->bvh_d)) != DRT_OK) return rc;
             ctx->has_mesh = true;
+            ctx->max_colour_param = std::max(ctx->max_colour_param, max_face_param);
             ctx->bvh_bytes = (uint64_t)built.nodes.size() * 64 + (uint64_t)tris.size() * 48;   // f32 image: nodes + three 16-byte triangle lanes
         }
     }

@@ -205,6 +205,7 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
         md.vertices = f.mesh_vertices[m].data();
         md.indices = f.mesh_indices[m].data();
         md.face_material = nullptr;
+        md.face_param = nullptr;
         f.meshes.push_back(md);
     }
     return f;

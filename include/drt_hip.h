@@ -103,6 +103,11 @@ typedef struct drt_mesh_desc {
     const double* vertices;        /* n_vertices x 3 */
     const uint32_t* indices;       /* n_triangles x 3 */
     const int32_t* face_material;  /* n_triangles material indices, or NULL: the shape's material */
+    const int32_t* face_param;     /* n_triangles colour-parameter indices, or NULL.  A face with an entry >= 0 has a BxDF of its
+                                      own -- type and exponent of the face's material, colour = that parameter: the reference's
+                                      `Triangle(..., std::make_shared<DiffuseBxDF<T>>(albedo_of_this_face))` per face, 50,880
+                                      albedos for BASELINE config 4's mesh without 50,880 material records; -1 = the material's
+                                      own colour.  (A face without material has no BxDF; a mirror has no colour.) */
 } drt_mesh_desc;
 
 typedef struct drt_material_desc {

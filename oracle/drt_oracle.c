@@ -162,12 +162,13 @@ typedef struct {
     int tri;        /* triangle within the mesh, -1 for analytic shapes */
     int flat;       /* position in the flattened scene (every triangle counts as a shape) */
     int material;   /* resolved material index (per-face or the shape's), -1 = none */
+    int param;      /* colour parameter of the hit's BxDF: the face's own (drt_mesh_desc::face_param) or its material's; -1 = none */
 } hit_t;
 
 static hit_t raycast(const drt_scene_desc* sc, v3 orig, v3 dir, v3* point, v3* normal, double* t_out)
 {
     double tmin = INFINITY;
-    hit_t hit = {-1, -1, -1, -1};
+    hit_t hit = {-1, -1, -1, -1, -1};
     int flat = 0;
     for (int i = 0; i < sc->n_shapes; ++i) {
         const drt_shape_desc* sh = &sc->shapes[i];
@@ -184,6 +185,8 @@ static hit_t raycast(const drt_scene_desc* sc, v3 orig, v3 dir, v3* point, v3* n
                 *normal = v3_normalize(v3_cross(e1, e2));
                 hit.shape = i; hit.tri = k; hit.flat = flat;
                 hit.material = m->face_material ? m->face_material[k] : sh->material;
+                hit.param = hit.material < 0 ? -1 : (m->face_param && m->face_param[k] >= 0 && sc->materials[hit.material].type != DRT_BXDF_MIRROR
+                                                         ? m->face_param[k] : sc->materials[hit.material].param);
             }
             continue;
         }
@@ -196,6 +199,7 @@ static hit_t raycast(const drt_scene_desc* sc, v3 orig, v3 dir, v3* point, v3* n
         *point = v3_add(orig, v3_scale(dir, t));
         *normal = shape_normal(sh, *point);
         hit.shape = i; hit.tri = -1; hit.flat = flat; hit.material = sh->material;
+        hit.param = sh->material >= 0 ? sc->materials[sh->material].param : -1;
         ++flat;
     }
     *t_out = tmin;
@@ -351,7 +355,7 @@ static void vertex_eval(const drt_scene_desc* sc, vertex_t* v, v3 dir_out)
     const drt_material_desc* m = v->material >= 0 ? &sc->materials[v->material] : NULL;
     if (m) {
         v->bscalar = bxdf_scalar(m, v->normal, v->dir_in, dir_out, &v->bdiv);
-        v3 color = m->param >= 0 ? param_rgb(sc, m->param) : v3_make(1, 1, 1);   /* mirror: no colour */
+        v3 color = v->color_param >= 0 ? param_rgb(sc, v->color_param) : v3_make(1, 1, 1);   /* mirror: no colour */
         v->f = v->bdiv ? v3_div(color, v->bscalar) : v3_scale(color, v->bscalar);
     } else {
         v->bscalar = 0;
@@ -385,7 +389,7 @@ static int walk(walk_ctx* w, v3 orig, v3 dir, int depth, vertex_t* vtx, v3* L)
         int zero_dir = dir.v[0] == 0 && dir.v[1] == 0 && dir.v[2] == 0;
         hit_t hit;
         if (zero_dir && w->zero_dir_miss) {
-            hit.shape = -1; hit.tri = -1; hit.flat = -1; hit.material = -1;
+            hit.shape = -1; hit.tri = -1; hit.flat = -1; hit.material = -1; hit.param = -1;
             t = INFINITY;
         } else {
             hit = raycast(scene, orig, dir, &point, &normal, &t);
@@ -416,7 +420,7 @@ static int walk(walk_ctx* w, v3 orig, v3 dir, int depth, vertex_t* vtx, v3* L)
         vertex_t* v = &vtx[nv++];
         v->p = p;
         v->emis_param = sh->emitter >= 0 ? scene->emitters[sh->emitter].param : -1;
-        v->color_param = m ? m->param : -1;
+        v->color_param = m ? hit.param : -1;
         v->material = hit.material;
         v->point = point;
         v->normal = normal;
@@ -625,6 +629,7 @@ int drt_oracle_abi_layout(int which)
     case 4: return (int)sizeof(drt_camera_desc);
     case 5: return (int)sizeof(drt_render_params);
     case 6: return (int)sizeof(drt_hip_stats);
+    case 7: return (int)sizeof(drt_mesh_desc);
     case 10: return (int)offsetof(drt_shape_desc, p);
     case 11: return (int)offsetof(drt_scene_desc, shapes);
     case 12: return (int)offsetof(drt_camera_desc, eye);

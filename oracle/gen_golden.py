@@ -126,6 +126,10 @@ SMALL = [
          absorb=0.4, seed=19, unbiased=True),
     dict(name="g11_mesh40x40_48x48x4_d5", scene="mesh40x40", width=48, height=48, spp=4, min_bounces=5,
          absorb=1.0, seed=9),
+    # an albedo parameter of its own for EVERY face (drt_mesh_desc::face_param; the harness gets the scene spelled out as a
+    # DiffuseBxDF per face, which is what the reference does): 216 + 4 parameters
+    dict(name="g14_mesh10x12fall_36x30x4_rr", scene="mesh10x12fall", width=36, height=30, spp=4, min_bounces=2,
+         absorb=0.25, seed=21, adjoint_seed=4),
     # a per-SAMPLE loss that is not linear in the radiance (README.md:93-98: loss = loss_func(radiance); loss.backward()):
     # squared error against a target image, through the reference's own autograd (`loss l2` of the harness)
     dict(name="l1_loss_l2_cornell_48x32x6_d5", scene="cornell", width=48, height=32, spp=6, min_bounces=5,

@@ -61,7 +61,7 @@ LOSS_GOLDENS = ["l1_loss_l2_cornell_48x32x6_d5", "l2_loss_l2_emissive_wall_40x30
 SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_64x64x8_rr",
                  "g4_specular_64x64x8_d8", "g4b_emissive_wall_48x32x8_adj", "g7_random3_40x30x6",
                  "g8_random8_36x36x6_d5", "g9_mesh6x8_40x30x4", "g10_mesh10x12f5_32x32x4_d4",
-                 "g11_mesh40x40_48x48x4_d5", "m1_mirror_48x48x6_d6", "m2_mirror_wall_40x32x6_rr_adj"]
+                 "g11_mesh40x40_48x48x4_d5", "g14_mesh10x12fall_36x30x4_rr", "m1_mirror_48x48x6_d6", "m2_mirror_wall_40x32x6_rr_adj"]
 
 
 UNBIASED_GOLDENS = ["u1_unbiased_cornell_40x30x4_rr", "u2_unbiased_cornell_48x48x4_d4",

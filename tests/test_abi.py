@@ -42,6 +42,7 @@ def test_ctypes_mirror_matches_the_c_layout(pkg, oracle):
     assert L(4) == C.sizeof(pkg.CameraDesc)
     assert L(5) == C.sizeof(pkg.RenderParamsDesc)
     assert L(6) == C.sizeof(pkg.HipStats)
+    assert L(7) == C.sizeof(pkg.MeshDesc)
     assert L(10) == pkg.ShapeDesc.p.offset
     assert L(11) == pkg.SceneDesc.shapes.offset
     assert L(12) == pkg.CameraDesc.eye.offset

@@ -51,6 +51,42 @@ def test_config4_share_1024x1024x32_mesh(pkg, hip, oracle):
 
 
 @pytest.mark.timeout(900)
+def test_config4_with_an_albedo_per_face_row_against_the_oracle(pkg, hip, oracle):
+    """config 4 as SURVEY 8d words it -- "per-face or single albedo": every one of the 50,880 faces an albedo parameter of its
+    own (drt_mesh_desc::face_param), a 1.2 MB gradient vector (what `bench.py --config 4 --per-face` times).  One row through
+    the mesh at 2 spp against the oracle's brute-force triangle loop: exact in the f64 mode, to the f32 bounds otherwise, and
+    the Cornell parameters' gradients do not change with the mesh's parametrisation."""
+    scene = pkg.scene_by_name("mesh160x160fall")
+    assert scene.n_params == 50884
+    cam = pkg.cornell_camera(1024, 1024)
+    rp = pkg.RenderParams(spp=32, min_bounces=8, absorb=1.0, seed=1)
+    row = 560
+    rr = one_row(rp, row, 1024, spp=2)
+    hip.upload_scene(scene)
+    ref = oracle.render(scene, cam, rr, backward=True)
+    i64, g64, s64 = hip.render(cam, rr, backward=True, f64=True)
+    assert s64["segments"] == ref["stats"]["segments"]
+    np.testing.assert_allclose(g64, ref["grads"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(i64[row], ref["image"][row].astype(np.float32), rtol=2e-7, atol=1e-12)
+    faces = np.abs(ref["grads"][4:]).sum(1) > 0
+    assert 50 < faces.sum() < 5000                  # the faces this row's 2048 paths reach
+    i32, g32, s32 = hip.render(cam, rr, backward=True)
+    assert abs(s32["segments"] - ref["stats"]["segments"]) <= 64
+    assert grad_rel_err(g32, ref["grads"]) <= 1e-4
+    assert not g32[4:][~faces].any() or (np.abs(g32[4:][~faces]).max() <= 1e-4 * np.abs(ref["grads"]).max())
+    # a band of the frame at the share's 32 spp: finite, linear in the emission, and the faces' gradients sum to what the one
+    # shared albedo of the plain config-4 scene gets, up to the albedos' values (d/dc of c^n: not comparable) -- so compare
+    # the gradient of the LIGHT, which does not know how the mesh is parametrised, with the plain scene of the same albedos
+    band = dataclasses.replace(rp, shard=35, n_shards=64, band_rows=16)
+    img, grads, st = hip.render(cam, band, backward=True)
+    assert np.isfinite(img).all() and np.isfinite(grads).all() and st["kernels"]["backward"]["launches"] >= 1
+    e = scene.param_names.index("emission")
+    rows = pkg.shard_rows(1024, 16, 64, 35)
+    total = img[rows].astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[e] * np.array(scene.params[e]), total, rtol=5e-6)
+
+
+@pytest.mark.timeout(900)
 def test_config5_share_2048x2048_depth16_specular(pkg, hip, oracle):
     """config 5: 2048 x 2048, depth 16, diffuse + specular (1024 spp over 8 GPUs = 128 per GPU; 8 spp here -- the
     per-sample work is what the test exercises, bench.py --config 5 runs the 128)."""

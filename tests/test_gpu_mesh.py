@@ -123,6 +123,39 @@ def test_per_face_parameters_use_the_general_gradient_path(pkg, hip, oracle):
     assert np.abs(ref["grads"][4:]).min() > 0        # every face parameter is reached
 
 
+def test_an_albedo_parameter_per_face(pkg, hip, oracle):
+    """drt_mesh_desc::face_param: every face of the mesh a BxDF of its own (config 4 as SURVEY 8d words it) -- 1104 + 4
+    parameters here: beyond the 256 that K6 keeps in LDS, so the fp64 atomics on the gradient vector run too.  The oracle's
+    face_param is pinned, bit for bit, to a material per face (tests/test_oracle_golden.py), which the reference harness runs."""
+    scene = pkg.scene_by_name("mesh24x24fall")
+    assert scene.n_params == 4 + 2 * 24 * 23
+    cam = pkg.cornell_camera(56, 48)
+    rp = pkg.RenderParams(spp=4, min_bounces=3, absorb=0.2, seed=4, max_depth=7)
+    ref = oracle.render(scene, cam, rp, backward=True)
+    hip.upload_scene(scene)
+    i64, g64, st = hip.render(cam, rp, backward=True, f64=True)
+    assert st["kernels"]["path"]["launches"] == 0            # more than 8 parameters: the tape route
+    assert st["segments"] == ref["stats"]["segments"]
+    np.testing.assert_allclose(g64, ref["grads"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(i64, ref["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    _, g32, _ = hip.render(cam, rp, backward=True)
+    assert grad_rel_err(g32, ref["grads"]) <= 1e-4
+    reached = np.abs(ref["grads"][4:]).sum(1) > 0
+    assert reached.sum() > 100                                # a couple of hundred faces see light in this frame
+    # faces no path met keep an exactly zero gradient on the device too
+    assert not g64[4:][~reached].any() and not g32[4:][~reached].any()
+    # a parameter that does not require grad stays zero, its neighbours are untouched
+    scene.requires_grad[4 + int(np.argmax(reached))] = False
+    hip.upload_scene(scene)
+    _, g2, _ = hip.render(cam, rp, backward=True, f64=True)
+    k = 4 + int(np.argmax(reached))
+    assert not g2[k].any()
+    np.testing.assert_array_equal(np.delete(g2, k, 0), np.delete(g64, k, 0))
+    # the gradient image of one face's albedo
+    _, gi, _ = hip.render_gradient_image(cam, rp, 4 + int(np.argmax(np.abs(ref["grads"][4:]).sum(1))), f64=True)
+    assert np.isfinite(gi).all() and np.abs(gi).max() > 0
+
+
 def test_mesh_scene_properties_at_scale(pkg, hip):
     """Config-4-shaped render (50k triangles, 256 x 256 x 16): linearity in emission, determinism,
     sharding."""

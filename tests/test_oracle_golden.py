@@ -32,6 +32,25 @@ def test_oracle_bit_exact_vs_reference_golden(pkg, oracle, name):
         assert r2["stats"]["segments"] == int(g["segments"]) and r2["stats"]["zero_dir_segments"] == 0
 
 
+def test_per_face_colour_parameters_are_a_material_per_face(pkg, oracle):
+    """drt_mesh_desc::face_param in the restatement = the same scene with a BxDF (material record) per face, bit for bit: that
+    form is what the reference harness runs (fixture g14; oracle.write_scene_file spells face_param out that way)."""
+    scene = pkg.scene_by_name("mesh10x12fall")
+    assert scene.n_params == 4 + 216 and scene.mesh_face_param[0] is not None
+    spelled = scene.with_face_params_as_materials()
+    assert len(spelled.materials) == len(scene.materials) + 216 and spelled.mesh_face_param == [None]
+    cam = pkg.cornell_camera(30, 22)
+    for kw in (dict(min_bounces=3, absorb=1.0), dict(min_bounces=1, absorb=0.4)):
+        for unbiased in (False, True):
+            rp = pkg.RenderParams(spp=3, seed=8, **kw)
+            a = oracle.render(scene, cam, rp, backward=True, unbiased=unbiased)
+            b = oracle.render(spelled, cam, rp, backward=True, unbiased=unbiased)
+            np.testing.assert_array_equal(a["image"], b["image"])
+            np.testing.assert_array_equal(a["grads"], b["grads"])
+            assert a["stats"]["segments"] == b["stats"]["segments"]
+            assert np.count_nonzero(np.abs(a["grads"][4:]).sum(1)) > 10
+
+
 @pytest.mark.parametrize("name", ["g12_gradimage_red_48x36x8_d4", "g13_gradimage_white_40x40x6_rr",
                                   "m4_mirror_gradimage_white_32x32x6"])
 def test_gradient_image_bit_exact(pkg, oracle, name):
