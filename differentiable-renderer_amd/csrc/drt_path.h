@@ -90,6 +90,59 @@ __device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __rest
 #define DRT_NSIG_CORNELL 9
 typedef KindSig<DRT_SIG_CORNELL, 0ull, 0ull, 0ull, DRT_NSIG_CORNELL> SigCornell;
 
+#define DRT_PATH_LDS_PARAMS 136      // parameters staged in LDS: every analytic scene's (<= 64 materials + 64 emitters + the mirrors' constant); more: read from L2
+
+// the part of the scene a vertex of the one-launch kernels needs, compact (SceneLds carries the whole DevScene and 256
+// parameters: 10.4 KB; this is 5.2 KB in f32 -- a block per CU more for the regenerating k_path)
+template <typename R>
+struct PathSceneLds {
+    struct {
+        int n_shapes, n_materials, n_emitters, n_params;
+        DevShape<R> shapes[DRT_MAX_SHAPES];
+        DevMaterial<R> materials[DRT_MAX_MATERIALS];
+        int emitter_param[DRT_MAX_EMITTERS];
+        int flat[DRT_MAX_SHAPES];
+    } sc;
+    R params[DRT_PATH_LDS_PARAMS * 3];
+};
+
+template <typename R, bool ALL_LDS = false>
+__device__ inline V3<R> load_param(const PathSceneLds<R>& lds, const R* __restrict__ params, int id)
+{
+    if (ALL_LDS || id < DRT_PATH_LDS_PARAMS)
+        return mk<R>(lds.params[id * 3], lds.params[id * 3 + 1], lds.params[id * 3 + 2]);
+    return mk<R>(params[id * 3], params[id * 3 + 1], params[id * 3 + 2]);
+}
+
+template <typename R>
+__device__ inline void stage_path_scene(PathSceneLds<R>& lds, const DevScene<R>* __restrict__ sc, const R* __restrict__ params)
+{
+    const int ns = sc->n_shapes, nm = sc->n_materials, ne = sc->n_emitters;
+    if (threadIdx.x < 4)
+        reinterpret_cast<int*>(&lds.sc)[threadIdx.x] = reinterpret_cast<const int*>(sc)[threadIdx.x];
+    {
+        const int* src = reinterpret_cast<const int*>(sc->shapes);
+        int* dst = reinterpret_cast<int*>(lds.sc.shapes);
+        for (int i = threadIdx.x; i < ns * (int)(sizeof(DevShape<R>) / sizeof(int)); i += blockDim.x)
+            dst[i] = src[i];
+    }
+    {
+        const int* src = reinterpret_cast<const int*>(sc->materials);
+        int* dst = reinterpret_cast<int*>(lds.sc.materials);
+        for (int i = threadIdx.x; i < nm * (int)(sizeof(DevMaterial<R>) / sizeof(int)); i += blockDim.x)
+            dst[i] = src[i];
+    }
+    for (int i = threadIdx.x; i < ne; i += blockDim.x)
+        lds.sc.emitter_param[i] = sc->emitter_param[i];
+    for (int i = threadIdx.x; i < ns; i += blockDim.x)
+        lds.sc.flat[i] = sc->flat[i];
+    const int np = sc->n_params < DRT_PATH_LDS_PARAMS ? sc->n_params : DRT_PATH_LDS_PARAMS;
+    for (int i = threadIdx.x; i < np * 3; i += blockDim.x)
+        lds.params[i] = params[i];
+    __syncthreads();
+}
+
+
 // per-lane gradient state: NP parameters (0 = none), of which only the first NC can be a BxDF's colour (the others are
 // emission-only parameters: the reference's scene has three albedos and one emission, render.cpp:26-29).
 //
@@ -159,7 +212,7 @@ struct Tangents {
 // LOSS (DRT_RENDER_LOSS_L2, the end of a path only): `g` holds the lane's TARGET pixel and the seed is the derivative of the
 // sample's own squared error, 2 (L - target), with L the path's radiance INCLUDING this emission -- final where the path ends
 // on a light without BxDF, which is the only emissive vertex of a path in the scenes this form is used for.
-template <typename R, int NP, int NC, bool LOSS = false, typename SL = SceneLds<R>>
+template <typename R, int NP, int NC, bool LOSS = false, typename SL = PathSceneLds<R>>
 __device__ inline void add_emission(const SL& lds, const TangentLds<R>& tl, const R* __restrict__ params, uint32_t eid, R inv_pk,
                                     V3<R> T, V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
 {
@@ -220,13 +273,15 @@ struct PathVertex {
 };
 
 template <typename R, bool SPEC, int NP, int NC, typename SG>
-__device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, const TangentLds<R>& tl, const DevScene<R>* __restrict__ sc,
+__device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds, const TangentLds<R>& tl, const DevScene<R>* __restrict__ sc,
                                    const R* __restrict__ params, const ProgRecs<SG::n, R>& recs, uint32_t key,
                                    R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
                                    typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
                                    bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr,
-                                   bool last = false)
+                                   bool last = false, const float* __restrict__ seed_px = nullptr)
 {
+    // (seed_px, the regenerating form: where the pixel's adjoint seed stands in the caller's image -- read only where a vertex
+    //  emits, instead of carrying it in registers for a lane that changes pixel with every path)
     // `last` (wave-uniform; the lockstep kernel at the deepest vertex a path can have): no lane's path goes on from here, so
     // nothing is sampled -- the reference does sample a direction there, and the trace() it hands it to is absorbed before it
     // casts a ray (pathtracer.hpp:128): a factor of exactly 0.  What is left of the bounce is the hit, the light it may have
@@ -247,8 +302,11 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
     light = eid;
     if (last && !vo) {
         if (wave_any(emits && has_bxdf)) {
-            if (emits && has_bxdf)
+            if (emits && has_bxdf) {
+                if (NP > 0 && seed_px)
+                    g = mk<R>((R)seed_px[0], (R)seed_px[1], (R)seed_px[2]);
                 add_emission<R, NP, NC>(lds, tl, params, eid, inv_pk, T, g, L, tg);
+            }
         }
         alive = false;
         capped = false;
@@ -272,8 +330,11 @@ __device__ inline void path_bounce(const PathArgs& a, const SceneLds<R>& lds, co
         vo->scattered = hit && has_bxdf;
     }
     if (wave_any(emits && has_bxdf)) {
-        if (emits && has_bxdf)
+        if (emits && has_bxdf) {
+            if (NP > 0 && seed_px)
+                g = mk<R>((R)seed_px[0], (R)seed_px[1], (R)seed_px[2]);
             add_emission<R, NP, NC>(lds, tl, params, eid, inv_pk, T, g, L, tg);
+        }
     }
     // the BxDF: sample, evaluate (pathtracer.hpp:91-111)
     const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
@@ -336,6 +397,19 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
     }
     return key;
 }
+// ... of sample `sl` of pixel `gpix`, for a lane that is not bound to one pixel (k_path's regenerating form): `cl` holds that
+// pixel's constants; the f64 mode needs the pixel's coordinates too
+template <typename R>
+__device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& cl, uint32_t gpix, uint32_t sl,
+                                       typename Q4<R>::T& ra, typename Q2<R>::T& rb)
+{
+    uint32_t px = 0, py = 0;
+    if (sizeof(R) != 4) {
+        py = gpix / (uint32_t)a.W;
+        px = gpix - py * (uint32_t)a.W;
+    }
+    return path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+}
 
 // ---- the kernel -----------------------------------------------------------------------------------
 // The bounce loop is written WITHOUT per-lane branches: every lane of the wave executes every bounce of the sample --
@@ -360,10 +434,10 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         total[threadIdx.x] = 0;                           // (the finishing kernel behind this launch adds into them)
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
-    __shared__ SceneLds<R> lds;
+    __shared__ PathSceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
     __shared__ TangentLds<R> s_tl;
-    stage_scene(lds, sc, params);
+    stage_path_scene(lds, sc, params);
     const TangentLds<R>& tl = s_tl;
     if (NC > 0)
         stage_tangents(s_tl, lds);
@@ -459,8 +533,29 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
     }
     }
+    // ---- REGEN: a wave owns 64 pixels x its sample range, and its LANES are not bound to pixels: a lane whose path has ended
+    // takes the NEXT camera sample of the wave (item n = pixel n % 64, sample n / 64: wave-uniform counter + the lane's rank
+    // among the takers), so all 64 lanes stay busy until the wave's samples run out -- with a lane = a pixel the wave lasted as
+    // long as its unluckiest lane's 32 paths (82 bounces where the mean lane has 62 under the reference's -b 1 -p 0.5: a
+    // quarter of the wave-time idle).  What belongs to a PIXEL -- camera constants, radiance sum -- therefore
+    // lives in per-wave tables in LDS (slot = the pixel's lane of the static layout, which also writes the sums out at the
+    // end); radiance is added there with ds_add_f64.  (The sums of f32 values in f64 are exact unless a pixel's samples span
+    // more than 2^24 in magnitude, so their order does not show; gradient sums are per lane and summed over lanes anyway.)
+    __shared__ R s_pcs[REGEN ? DRT_BLOCK : 1], s_pct[REGEN ? DRT_BLOCK : 1];
+    __shared__ uint32_t s_pgpix[REGEN ? DRT_BLOCK : 1];
+    __shared__ double s_film[REGEN ? 3 : 1][REGEN ? DRT_BLOCK : 1];
+    if (REGEN) {
+        s_pcs[threadIdx.x] = cl.cs0;
+        s_pct[threadIdx.x] = cl.ct0;
+        s_pgpix[threadIdx.x] = have ? gpix : 0xFFFFFFFFu;       // (no such pixel: its samples are skipped)
+        s_film[0][threadIdx.x] = 0.0; s_film[REGEN ? 1 : 0][threadIdx.x] = 0.0; s_film[REGEN ? 2 : 0][threadIdx.x] = 0.0;
+        __syncthreads();
+    }
     if (range < a.n_ranges && REGEN) {
-        uint32_t sl = s_begin, key = 0;                   // the lane's next sample; RNG key of its current path
+        const uint32_t wbase = threadIdx.x & ~(uint32_t)(DRT_WAVE - 1);      // this wave's first slot in the pixel tables
+        const uint32_t n_items = DRT_WAVE * (s_end - s_begin);
+        uint32_t n_next = 0;                              // wave-uniform: the next camera sample of the wave to hand out
+        uint32_t key = 0, pix = wbase, pgpix = 0;         // RNG key, pixel slot and pixel of the lane's current path
         int kk = 0;                                       // depth of the lane's current path
         bool live = false;
         R4 ra;
@@ -472,27 +567,36 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             tg.new_path();
         const int first_rr = a.min_bounces > 1 ? a.min_bounces : 1;
         for (;;) {
-            // ---- lanes without a path start their next sample -- once enough of them wait (the whole wave walks
+            // ---- lanes without a path take the wave's next samples -- once enough of them wait (the whole wave walks
             // through the camera code), or as many as still run
-            const bool start = have && !live && sl < s_end;
-            const uint32_t n_idle = (uint32_t)__popcll(wave_ballot(start)), n_run = (uint32_t)__popcll(wave_ballot(live));
-            if (n_idle >= a.regen_min || (n_idle > 0 && n_idle >= n_run)) {
-                if (start) {
-                    key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
-                    ++sl;
-                    kk = 0;
-                    live = a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
-                    T = mk<R>(R(1), R(1), R(1));
-                    L = mk<R>(R(0), R(0), R(0));
-                    if (NC > 0)
-                        tg.new_path();
+            const uint64_t idle_mask = wave_ballot(!live);
+            const uint32_t n_idle = (uint32_t)__popcll(idle_mask), n_run = DRT_WAVE - n_idle;
+            if (n_next < n_items && (n_idle >= a.regen_min || n_idle >= n_run)) {
+                const uint32_t n = n_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                if (!live && n < n_items) {
+                    pix = wbase + (n & (DRT_WAVE - 1));
+                    const uint32_t gp = s_pgpix[pix];
+                    if (gp != 0xFFFFFFFFu) {
+                        pgpix = gp;
+                        CameraLane<R> pc;
+                        pc.cs0 = s_pcs[pix];
+                        pc.ct0 = s_pct[pix];
+                        key = path_camera<R>(a, pc, gp, s_begin + (n >> 6), ra, rb);
+                        kk = 0;
+                        live = a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
+                        T = mk<R>(R(1), R(1), R(1));
+                        L = mk<R>(R(0), R(0), R(0));
+                        if (NC > 0)
+                            tg.new_path();
+                    }
                 }
+                n_next += n_idle < n_items - n_next ? n_idle : n_items - n_next;
             }
             const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
             if (n_live == 0) {
-                if (!wave_any(have && sl < s_end))
-                    break;                                // every lane is through its samples
-                continue;                                 // (all fresh paths were absorbed at depth 0)
+                if (n_next >= n_items)
+                    break;                                // the wave is through its samples
+                continue;                                 // (all fresh paths were absorbed at depth 0, or belong to no pixel)
             }
             n_seg += n_live;
             // ---- one bounce, every lane at its own depth
@@ -505,22 +609,36 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             const bool next_cap = (kk + 1) >= a.depth_cap;
             bool alive, capped, on_light;
             uint32_t light;
-            path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, g,
-                                                    ra, rb, T, L, tg, alive, capped, on_light, light);
+            // the seed of the path's pixel (render.cpp:80: all ones; else the caller's image): read where a path meets a light
+            V3<R> gp3 = mk<R>(R(1), R(1), R(1));
+            const float* seed_px = (NP > 0 && adjoint) ? adjoint + (size_t)pgpix * 3 : (const float*)nullptr;
+            path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, gp3,
+                                                    ra, rb, T, L, tg, alive, capped, on_light, light, nullptr, false, seed_px);
             if (!a.cap_is_roulette)
                 n_capped += (uint32_t)__popcll(wave_ballot(capped));
-            // ---- paths that ended here hand their radiance to the pixel
+            // ---- paths that ended here hand their radiance to their pixel
             const bool ended = live && !alive;
             if (wave_any(ended)) {
                 if (ended) {
-                    if (on_light)
-                        add_emission<R, NP, NC, LOSS>(lds, tl, params, light, inv_pk, T, g, L, tg);
-                    fx += (double)L.x; fy += (double)L.y; fz += (double)L.z;
+                    if (on_light) {
+                        if (seed_px)
+                            gp3 = mk<R>((R)seed_px[0], (R)seed_px[1], (R)seed_px[2]);
+                        add_emission<R, NP, NC, LOSS>(lds, tl, params, light, inv_pk, T, gp3, L, tg);
+                    }
+                    if (L.x != R(0) || L.y != R(0) || L.z != R(0)) {
+                        atomicAdd(&s_film[0][pix], (double)L.x);
+                        atomicAdd(&s_film[REGEN ? 1 : 0][pix], (double)L.y);
+                        atomicAdd(&s_film[REGEN ? 2 : 0][pix], (double)L.z);
+                    }
                 }
             }
             live = alive;
             ++kk;
         }
+    }
+    if (REGEN) {
+        __syncthreads();                                  // (every wave's adds have landed)
+        fx = s_film[0][threadIdx.x]; fy = s_film[REGEN ? 1 : 0][threadIdx.x]; fz = s_film[REGEN ? 2 : 0][threadIdx.x];
     }
 
     if (range < a.n_ranges) {
@@ -576,7 +694,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
 // without BxDF (its zero-direction continuation is traced "faithfully" before it misses; oracle/ref_harness.cpp).
 // One walk = the bounce of k_path (path_bounce, forward-only) iterated while any lane of the wave still traces.
 template <typename R, bool SPEC, typename SG>
-__device__ inline void unbiased_walk(const PathArgs& a, const SceneLds<R>& lds, const TangentLds<R>& tl, const DevScene<R>* __restrict__ sc,
+__device__ inline void unbiased_walk(const PathArgs& a, const PathSceneLds<R>& lds, const TangentLds<R>& tl, const DevScene<R>* __restrict__ sc,
                                      const R* __restrict__ params, const ProgRecs<SG::n, R>& recs, uint32_t key,
                                      R pk_rr, R inv_p_rr, bool live, typename Q4<R>::T ra, typename Q2<R>::T rb, int kk,
                                      uint32_t& nd, uint32_t& n_seg, uint32_t& n_capped, V3<R>& L, PathVertex<R>& first, bool& any_vertex)
@@ -629,9 +747,9 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
         total[threadIdx.x] = 0;
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
-    __shared__ SceneLds<R> lds;
+    __shared__ PathSceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
-    stage_scene(lds, sc, params);
+    stage_path_scene(lds, sc, params);
     const TangentLds<R>& tl = *reinterpret_cast<const TangentLds<R>*>(&lds);   // (forward-only walks never touch it)
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);

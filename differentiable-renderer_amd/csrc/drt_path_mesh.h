@@ -24,59 +24,9 @@
 #ifndef DRT_MESH_LDS_STACK
 #define DRT_MESH_LDS_STACK 16
 #endif
-#define DRT_MESH_LDS_PARAMS 64       // parameters staged in LDS (more: read from L2; gradients need <= DRT_FAST_PARAMS anyway)
 #ifndef DRT_MESH_MIN_BLOCKS
 #define DRT_MESH_MIN_BLOCKS 4
 #endif
-
-// the part of the scene a vertex needs, compact (SceneLds carries the whole DevScene: 10 KB; this is 4.4 KB in f32)
-template <typename R>
-struct MeshSceneLds {
-    struct {
-        int n_shapes, n_materials, n_emitters, n_params;
-        DevShape<R> shapes[DRT_MAX_SHAPES];
-        DevMaterial<R> materials[DRT_MAX_MATERIALS];
-        int emitter_param[DRT_MAX_EMITTERS];
-        int flat[DRT_MAX_SHAPES];
-    } sc;
-    R params[DRT_MESH_LDS_PARAMS * 3];
-};
-
-template <typename R, bool ALL_LDS = false>
-__device__ inline V3<R> load_param(const MeshSceneLds<R>& lds, const R* __restrict__ params, int id)
-{
-    if (ALL_LDS || id < DRT_MESH_LDS_PARAMS)
-        return mk<R>(lds.params[id * 3], lds.params[id * 3 + 1], lds.params[id * 3 + 2]);
-    return mk<R>(params[id * 3], params[id * 3 + 1], params[id * 3 + 2]);
-}
-
-template <typename R>
-__device__ inline void stage_mesh_scene(MeshSceneLds<R>& lds, const DevScene<R>* __restrict__ sc, const R* __restrict__ params)
-{
-    const int ns = sc->n_shapes, nm = sc->n_materials, ne = sc->n_emitters;
-    if (threadIdx.x < 4)
-        reinterpret_cast<int*>(&lds.sc)[threadIdx.x] = reinterpret_cast<const int*>(sc)[threadIdx.x];
-    {
-        const int* src = reinterpret_cast<const int*>(sc->shapes);
-        int* dst = reinterpret_cast<int*>(lds.sc.shapes);
-        for (int i = threadIdx.x; i < ns * (int)(sizeof(DevShape<R>) / sizeof(int)); i += blockDim.x)
-            dst[i] = src[i];
-    }
-    {
-        const int* src = reinterpret_cast<const int*>(sc->materials);
-        int* dst = reinterpret_cast<int*>(lds.sc.materials);
-        for (int i = threadIdx.x; i < nm * (int)(sizeof(DevMaterial<R>) / sizeof(int)); i += blockDim.x)
-            dst[i] = src[i];
-    }
-    for (int i = threadIdx.x; i < ne; i += blockDim.x)
-        lds.sc.emitter_param[i] = sc->emitter_param[i];
-    for (int i = threadIdx.x; i < ns; i += blockDim.x)
-        lds.sc.flat[i] = sc->flat[i];
-    const int np = sc->n_params < DRT_MESH_LDS_PARAMS ? sc->n_params : DRT_MESH_LDS_PARAMS;
-    for (int i = threadIdx.x; i < np * 3; i += blockDim.x)
-        lds.params[i] = params[i];
-    __syncthreads();
-}
 
 enum { DRT_MS_DONE = 0, DRT_MS_NEW = 1, DRT_MS_HIT = 2, DRT_MS_WALK = 3 };
 
@@ -91,14 +41,14 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
         total[threadIdx.x] = 0;                           // (the finishing kernel behind this launch adds into them)
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
-    __shared__ MeshSceneLds<R> lds;
+    __shared__ PathSceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
     __shared__ TangentLds<R> s_tl;
     __shared__ ProgLds s_prog;                            // f32: the kind-sorted program of the analytic shapes
     __shared__ uint32_t s_stack[DRT_MESH_LDS_STACK][DRT_BLOCK];
     __shared__ R s_acc[NP > 0 ? NP * 3 : 1][DRT_BLOCK];
     stage_tail_program(s_prog, sc);
-    stage_mesh_scene(lds, sc, params);                    // (ends with a barrier)
+    stage_path_scene(lds, sc, params);                    // (ends with a barrier)
     const TangentLds<R>& tl = s_tl;
     if (NC > 0)
         stage_tangents(s_tl, lds);

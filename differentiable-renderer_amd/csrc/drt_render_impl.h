@@ -261,7 +261,10 @@ void shard_plan(Shard<R>& s)
     s.path_regen = tuning().path_regen > 0 || s.mesh_path;    // (k_path_mesh: every lane on its own, always)
     if (s.unbiased)
         s.path_regen = false;                  // (k_path_unbiased walks its samples in lockstep)
-    if (s.use_path && !s.mesh_path && tuning().path_regen < 0 && !s.unbiased) {
+    const bool lane_is_pixel = s.gimg_param >= 0 && !s.mesh_path;   // the gradient image is the lanes' own sums: lockstep form only
+    if (lane_is_pixel)
+        s.path_regen = false;
+    if (s.use_path && !s.mesh_path && !lane_is_pixel && tuning().path_regen < 0 && !s.unbiased) {
         // lockstep: a wave runs until the longest of its 64 paths ends -- the depth cap for fixed-depth renders, under the
         // roulette about the depth that 1 path in 256 reaches; regenerating: every lane runs the mean path length, at
         // ~1.7 x the cost per bounce (per-lane depth bookkeeping) + the camera code inside the loop.
