@@ -129,6 +129,9 @@ def parse_args(argv):
                     help="nccl (= RCCL, the real thing) | gloo: rendezvous only, lets ranks share ONE GPU to exercise the "
                          "N > 1 path on a single-GPU box (with --same-gpu); the numbers of such a run mean nothing")
     ap.add_argument("--same-gpu", action="store_true", help="every rank uses device 0 (testing only)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="the ABI's OTHER multi-GPU form: ONE process, drt_hip_create_group over --gpus devices (host buffers, the "
+                         "gradient summed inside the call by one grouped ncclAllReduce); an auxiliary measurement, not the contract line's mode")
     ap.add_argument("--store-n1", action="store_true",
                     help="1-GPU runs: store value under this workload's key in profiles/n1_reference.json (N > 1 runs print "
                          "weak_scaling.efficiency against it)")
@@ -162,9 +165,63 @@ def parse_args(argv):
     return a
 
 
+def single_process_main(a):
+    """--single-process: one process, drt_hip_create_group over a.gpus devices.  Weak scaling like the contract's mode: every
+    device renders a.spp samples of its interleaved row bands' pixels... of a frame of a.spp x N samples per pixel."""
+    import json
+    import time
+    import numpy as np
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    n = max(1, a.gpus)
+    have = pkg.load_library().drt_hip_device_count()
+    if have < n and not a.same_gpu:
+        print(f"bench.py --single-process: {n} devices asked for, {have} present", file=sys.stderr)
+        return 3
+    ids = [0] * n if a.same_gpu else list(range(n))
+    r = pkg.HipRenderer(ids)
+    r.set_specialisation(pkg.SPECIALISE_NOW)
+    scene = pkg.scene_by_name(a.scene)
+    r.upload_scene(scene)
+    cam = pkg.cornell_camera(a.width, a.height)
+    backward = not a.forward_only
+    rp = pkg.RenderParams(spp=a.spp * n, min_bounces=a.min_bounces, absorb=a.absorb, seed=1, band_rows=16, batch_paths=a.batch_paths,
+                          bounces_per_launch=a.bounces_per_launch)
+    img = np.zeros((a.height, a.width, 3), dtype=np.float32)
+    t_end = time.perf_counter() + a.preheat_ms * 1e-3
+    while time.perf_counter() < t_end:
+        r.render(cam, rp, backward=backward, img_out=img, want_stats=False)
+    for _ in range(a.warmup):
+        r.render(cam, rp, backward=backward, img_out=img, want_stats=False)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r.render(cam, rp, backward=backward, img_out=img, want_stats=False)
+    dt = (time.perf_counter() - t0) / a.steps
+    _, _, st = r.render(cam, rp, backward=backward, timing=True)
+    devices = [r.pci_bus_id(i) for i in range(n)]
+    line = {"metric": f"Mray/s ({'fwd+bwd' if backward else 'fwd'}), {a.scene} {a.width}x{a.height} @{a.spp * n}spp, one process, drt_hip_create_group",
+            "value": round(st["segments"] / dt * 1e-6, 2), "unit": "Mray/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{a.config_name}; scene '{a.scene}' {a.width}x{a.height}, {a.spp} spp per GPU",
+                       "parallelism": f"1 process, {n} devices ({'; '.join(devices)}) in a group context (drt_hip_create_group): interleaved 16-row "
+                                      f"bands, host buffers, the gradient summed inside the call (members of one device added on it, the "
+                                      f"distinct devices by ONE grouped ncclAllReduce over {len(set(devices))} ranks)",
+                       "mode": "synchronous host-buffer calls (PCIe D2H of every member's rows inside the step): an auxiliary view, "
+                               "the contract line is `bench.py --gpus N` (one process per GPU, device buffers)"},
+            "segments_per_step": st["segments"],
+            "kernels_ms_slowest_member": {k: round(v["ms"], 4) for k, v in st["kernels"].items() if v["ms"] > 0},
+            "roofline": None, "cpu_baseline": None}
+    r.close()
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     argv = sys.argv[1:]
     a = parse_args(argv)
+    if a.single_process:
+        sys.exit(single_process_main(a))
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(a.gpus, argv))
 
@@ -220,10 +277,20 @@ def main():
     if use_dist and backward:
         reduce_mode = a.reduce
         if reduce_mode == "library" and not load_distributed().join_library_communicator(r, pkg):
-            # e.g. --same-gpu: RCCL refuses two ranks on one device
+            # The ONE collective of the path belongs to the library: a run that cannot make its communicator over the ranks it
+            # was given must not quietly measure something else.  (--same-gpu, the single-GPU plumbing test, is the one place
+            # where RCCL is known to refuse -- two ranks on one device -- and torch.distributed stands in.)
+            if not a.same_gpu:
+                print(f"bench.py: rank {rank}: the in-library RCCL communicator over {world} ranks could not be made "
+                      f"(drt_hip_comm_init_rank); refusing to fall back to torch.distributed -- pass --reduce torch to measure that",
+                      file=sys.stderr)
+                sys.exit(3)
             if rank == 0:
-                print("bench.py: in-library communicator unavailable; reducing with torch.distributed", file=sys.stderr)
+                print("bench.py: --same-gpu: in-library communicator unavailable; reducing with torch.distributed", file=sys.stderr)
             reduce_mode = "torch"
+    if reduce_mode == "library" and r.comm_size != world:
+        print(f"bench.py: rank {rank}: the library's communicator has {r.comm_size} ranks, the job {world}", file=sys.stderr)
+        sys.exit(3)
     # the library's all-reduce runs on the context's second stream and overlaps the next step's kernels
     # (DRT_RENDER_ALLREDUCE_ASYNC; the steps alternate between two gradient buffers, the fence waits for both streams)
     flags = (pkg.RENDER_UNBIASED if (a.unbiased and backward) else 0) | \
@@ -333,7 +400,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_segments, total_paths = float(t[0].item()), float(t[1].item())
         props = torch.cuda.get_device_properties(local_rank)
-        mine = f"rank {rank}: cuda:{local_rank} {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
+        # (what the LIBRARY's context renders on and how many ranks ITS communicator spans -- not what torch saw)
+        mine = f"rank {rank}: cuda:{local_rank} pci {r.pci_bus_id()} (torch: {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}), library communicator of {r.comm_size} ranks"
         devices = [None] * world
         dist.all_gather_object(devices, mine)
     else:
@@ -410,12 +478,24 @@ def main():
     register_resident = dominant == "path" or (dominant == "shade" and not kernel_launches["intersect"]
                                                and dk["launches_per_step"] < a.depth * max(1, stats["batches"]) and not a.unbiased)
     traffic = round(pmc["bytes_per_launch"] / (launch_ms * 1e-3) * 1e-9, 1) if pmc.get("bytes_per_launch") and launch_ms > 0 else None
+    pmc_launch_us = pmc.get("avg_launch_us")
     hbm_view = {"achieved": dk["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dk["achieved_GBs"] / HBM_PEAK_GBS, 4),
                 "frac_of_measured_copy_roof": round(dk["achieved_GBs"] / HBM_COPY_GBS, 4),
                 "note": "algorithmic bytes of the dominant kernel (units x bytes per unit) over its HIP-event time"}
     valu_view = None
-    if pmc.get("valu_insts_per_launch") and launch_ms > 0:
+    # The instruction count is a STORED figure (profiles/traffic.json): it describes this run only if the kernel is still the
+    # one that was profiled.  The profile also recorded the kernel's launch time: where the live time is off by more than 5 %
+    # (boxes of the pool differ by ~3 %) the count is withheld instead of being divided by a time it does not belong to.
+    stale = None
+    if pmc.get("valu_insts_per_launch") and pmc.get("avg_launch_us") and launch_ms > 0 and not pmc_note:
+        off = launch_ms * 1e3 / float(pmc["avg_launch_us"]) - 1.0
+        if abs(off) > 0.05:
+            stale = (f"profiles/traffic.json holds k_{dominant} at {float(pmc['avg_launch_us']):.1f} us per launch, this run measures "
+                     f"{launch_ms * 1e3:.1f} us ({off:+.1%}): the kernel (or the box) is not the profiled one -- instruction counts "
+                     f"withheld; tools/profile.sh regenerates the profile")
+            pmc_note = stale
+    if pmc.get("valu_insts_per_launch") and launch_ms > 0 and not stale:
         ginst = pmc["valu_insts_per_launch"] / (launch_ms * 1e-3) * 1e-9
         valu_view = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
                      "frac": round(ginst / VALU_PEAK_GINST, 4),
@@ -442,7 +522,7 @@ def main():
                 "avg_launch_ms": round(launch_ms, 4),
                 "mode": "one launch at a time: HIP events around every launch of frames rendered in stream order (as rocprofv3 "
                         "sees them with DRT_HIP_OVERLAP_FRAMES=0, profiles/); `value` pipelines two frames, see `pipelined`",
-                "pmc_note": pmc_note,
+                "pmc_note": pmc_note, "pmc_launch_us": pmc_launch_us,
                 "hbm": hbm_view, "valu": valu_view,
                 "kernels": per_kernel}
     if dominant == "path" and valu_view and dk["launches_per_step"] > 0:
@@ -730,12 +810,16 @@ def main():
         except Exception:
             n1 = {}
         if world == 1 and a.store_n1 and not use_dist:
-            n1[workload_key] = {"value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(ms_per_step, 4)}
+            n1[workload_key] = {"value": round(value, 2), "unit": "Mray/s", "ms_per_step": round(ms_per_step, 4),
+                                "serial_value": serial_view["value"] if serial_view else None}
             json.dump(n1, open(n1_path, "w"), indent=1, sort_keys=True)
         if world > 1 and workload_key in n1:
             ref1 = n1[workload_key]["value"]
             weak_scaling = {"efficiency": round(value / (world * ref1), 4), "n1_value": ref1, "unit": "Mray/s",
                             "note": f"value / ({world} x the stored 1-GPU value of this per-GPU workload, profiles/n1_reference.json)"}
+            # (the same against frames in stream order -- what an optimisation loop gets --, where both numbers exist)
+            if serial_view and n1[workload_key].get("serial_value"):
+                weak_scaling["efficiency_serial_frames"] = round(serial_view["value"] / (world * n1[workload_key]["serial_value"]), 4)
         elif world > 1:
             weak_scaling = {"efficiency": None, "note": f"no stored 1-GPU value for '{workload_key}' (run bench.py --store-n1 on one GPU)"}
 
@@ -768,6 +852,8 @@ def main():
                        "program": stats.get("path_program"), "specialise_ms": round(stats.get("jit_ms", 0.0), 1),
                        "paths_per_step": int(total_paths), "rays_per_step": int(total_segments),
                        "parallelism": par, "batches_per_step": stats["batches"],
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)") +
+                                            (" (set by this script before the HIP runtime started)" if "--same-gpu" not in sys.argv else ""),
                        "capped_paths_per_step": stats["capped_paths"]},
             "weak_scaling": weak_scaling,
             "serial_frame": serial_view, "generic_program": generic_view,

@@ -499,7 +499,7 @@ class DrtHipError(RuntimeError):
 
 
 _ABI_SYMBOLS = ["drt_hip_abi_version", "drt_hip_device_count", "drt_hip_create", "drt_hip_create_group",
-                "drt_hip_group_size", "drt_hip_destroy",
+                "drt_hip_group_size", "drt_hip_device_pci_bus_id", "drt_hip_destroy",
                 "drt_hip_comm_unique_id", "drt_hip_comm_init_rank", "drt_hip_comm_size", "drt_hip_comm_destroy",
                 "drt_hip_upload_scene", "drt_hip_update_params", "drt_hip_set_specialisation", "drt_hip_render", "drt_hip_render_async", "drt_hip_wait",
                 "drt_hip_render_gradient_image", "drt_hip_pin_host", "drt_hip_unpin_host", "drt_hip_stream",
@@ -520,6 +520,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.drt_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.drt_hip_create_group.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     lib.drt_hip_group_size.argtypes = [C.c_void_p]
+    lib.drt_hip_device_pci_bus_id.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     lib.drt_hip_comm_unique_id.argtypes = [C.c_void_p]
     lib.drt_hip_comm_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.drt_hip_comm_size.argtypes = [C.c_void_p]
@@ -581,6 +582,12 @@ class HipRenderer:
     @property
     def group_size(self) -> int:
         return int(self.lib.drt_hip_group_size(self.ctx))
+
+    def pci_bus_id(self, member: int = 0) -> str:
+        """the PCI bus id of the device (member `member` of) this context renders on, as the LIBRARY sees it"""
+        buf = C.create_string_buffer(64)
+        self._check(self.lib.drt_hip_device_pci_bus_id(self.ctx, member, buf, 64), "drt_hip_device_pci_bus_id")
+        return buf.value.decode()
 
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         """Join the communicator of a one-process-per-GPU job (collective). Afterwards renders with

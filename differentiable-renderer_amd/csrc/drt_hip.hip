@@ -366,6 +366,21 @@ int drt_hip_comm_init_rank(drt_hip_ctx* ctx, const drt_hip_unique_id* id, int ra
     return DRT_OK;
 }
 
+int drt_hip_device_pci_bus_id(const drt_hip_ctx* ctx, int member, char* out, int capacity)
+{
+    if (!ctx || !out || capacity < 16)
+        return DRT_ERR_INVALID;
+    const drt_hip_ctx* c = ctx;
+    if (!ctx->members.empty()) {
+        if (member < 0 || member >= (int)ctx->members.size())
+            return DRT_ERR_INVALID;
+        c = ctx->members[(size_t)member];
+    } else if (member != 0)
+        return DRT_ERR_INVALID;
+    out[0] = 0;
+    return hipDeviceGetPCIBusId(out, capacity, c->device) == hipSuccess ? DRT_OK : DRT_ERR_HIP;
+}
+
 int drt_hip_comm_size(const drt_hip_ctx* ctx)
 {
     if (!ctx)
@@ -558,7 +573,8 @@ extern "C" int drt_hip_debug_jit_compile(const char* arch, const char* name_expr
 {
     if (!arch || !name_expr)
         return DRT_ERR_INVALID;
-    const drt_jit::Code& c = drt_jit::compile(arch, name_expr);
+    const drt_jit::EntryPtr e = drt_jit::compile(arch, name_expr);
+    const drt_jit::Code& c = e->code;
     if (ms)
         *ms = c.ms;
     if (log && log_cap > 0) {

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -78,16 +79,40 @@ inline void build(const std::string& arch, const std::string& name_expr, Code& c
     c.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// build() behind a catch-all: nothing may leave a compile as an exception -- it would leave the cache entry "in progress" for
+// ever (every later compile() of that key waits on the condition variable) and cross the C ABI.  A failed allocation is a
+// failed compile.
+inline void build_guarded(const std::string& arch, const std::string& name_expr, Code& c) noexcept
+{
+    try {
+        build(arch, name_expr, c);
+    } catch (...) {
+        c.ok = false;
+        try {
+            c.bin.clear();
+            c.log = "hiprtc (" + name_expr + "): the compile ended in an exception (out of memory?)";
+        } catch (...) {
+        }
+    }
+}
+
 // The process-wide cache, by architecture and name expression.  An entry exists from the moment somebody asked for it;
-// `done` says whether its compile has finished (entries of a std::map do not move: the compiling thread keeps a reference).
+// `done` says whether its compile has finished.  Entries are shared: whoever got one keeps it alive, so the cache may drop
+// its own reference -- it holds at most DRT_JIT_CACHE_MAX finished code objects (a process that renders thousands of
+// different scenes, a fuzzer, must not keep every one of them; ROCm's own on-disk cache makes a recompile cheap).
+#ifndef DRT_JIT_CACHE_MAX
+#define DRT_JIT_CACHE_MAX 64
+#endif
 struct Entry {
     Code code;
     bool done = false;
 };
+typedef std::shared_ptr<Entry> EntryPtr;
 struct State {
     std::mutex m;
     std::condition_variable cv;
-    std::map<std::string, Entry> cache;
+    std::map<std::string, EntryPtr> cache;
+    std::vector<std::string> order;         // keys in the order they were added (the oldest finished ones go first)
     std::vector<std::thread> workers;       // background compiles (poll); joined when the library is unloaded
     ~State()
     {
@@ -95,52 +120,81 @@ struct State {
             if (t.joinable())
                 t.join();
     }
+    // (called with the lock held, before a new key is added)
+    void evict()
+    {
+        size_t i = 0;
+        while (cache.size() >= DRT_JIT_CACHE_MAX && i < order.size()) {
+            auto it = cache.find(order[i]);
+            if (it != cache.end() && it->second->done) {
+                cache.erase(it);
+                order.erase(order.begin() + (long)i);
+            } else
+                ++i;
+        }
+    }
 };
 inline State& state() { static State s; return s; }
 
 // compile the instantiation `name_expr` of a kernel template of drt_path.h for `arch` and WAIT for it (thread-safe: the
 // members of a group context launch from threads of their own; a compile already running in the background is joined)
-inline const Code& compile(const std::string& arch, const std::string& name_expr)
+inline EntryPtr compile(const std::string& arch, const std::string& name_expr)
 {
     State& st = state();
     const std::string key = arch + "|" + name_expr;
     std::unique_lock<std::mutex> lock(st.m);
     auto it = st.cache.find(key);
     if (it != st.cache.end()) {
-        Entry& e = it->second;
-        st.cv.wait(lock, [&e] { return e.done; });
-        return e.code;
+        EntryPtr e = it->second;
+        st.cv.wait(lock, [&e] { return e->done; });
+        return e;
     }
-    Entry& e = st.cache[key];
+    st.evict();
+    EntryPtr e = std::make_shared<Entry>();
+    st.cache[key] = e;
+    st.order.push_back(key);
     lock.unlock();
-    build(arch, name_expr, e.code);
+    build_guarded(arch, name_expr, e->code);
     lock.lock();
-    e.done = true;
+    e->done = true;
     st.cv.notify_all();
-    return e.code;
+    return e;
 }
 
 // the same WITHOUT waiting: nullptr while the compile runs -- started on a thread of its own by the first call -- and the
 // code once it is there.  What DRT_SPECIALISE_AUTO uses: the frames of a render loop never wait for the compiler, they
 // run the kind-sorted program (same results, bit for bit) until the specialised one has arrived.
-inline const Code* poll(const std::string& arch, const std::string& name_expr)
+inline EntryPtr poll(const std::string& arch, const std::string& name_expr)
 {
     State& st = state();
     const std::string key = arch + "|" + name_expr;
     std::lock_guard<std::mutex> lock(st.m);
     auto it = st.cache.find(key);
     if (it != st.cache.end())
-        return it->second.done ? &it->second.code : nullptr;
-    Entry& e = st.cache[key];
-    st.workers.emplace_back([arch, name_expr, &e, &st] {
-        build(arch, name_expr, e.code);
-        {
-            std::lock_guard<std::mutex> l(st.m);
-            e.done = true;
-        }
+        return it->second->done ? it->second : EntryPtr();
+    st.evict();
+    EntryPtr e = std::make_shared<Entry>();
+    st.cache[key] = e;
+    st.order.push_back(key);
+    try {
+        st.workers.emplace_back([arch, name_expr, e, &st] {
+            build_guarded(arch, name_expr, e->code);
+            {
+                std::lock_guard<std::mutex> l(st.m);
+                e->done = true;
+            }
+            st.cv.notify_all();
+        });
+    } catch (...) {
+        // (no thread to be had: the entry must not stay "in progress" for ever -- whoever asks next gets a failed compile and
+        //  renders with the kind-sorted program)
+        e->code.ok = false;
+        e->code.log = std::string("hiprtc (") + name_expr + "): could not start the compile thread";
+        e->done = true;
         st.cv.notify_all();
-    });
-    return nullptr;
+        return e;
+    }
+    return EntryPtr();
 }
 
 // wait for the background compiles that are still running (a context is being destroyed: the process may be about to exit,

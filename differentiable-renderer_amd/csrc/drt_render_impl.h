@@ -83,10 +83,10 @@ hipFunction_t jit_function(drt_hip_ctx* ctx, const std::string& name_expr, bool 
         return it->second;
     const auto t0 = std::chrono::steady_clock::now();
     hipFunction_t fn = nullptr;
-    const drt_jit::Code* pc = wait ? &drt_jit::compile(ctx->arch, name_expr) : drt_jit::poll(ctx->arch, name_expr);
-    if (!pc)
+    const drt_jit::EntryPtr pe = wait ? drt_jit::compile(ctx->arch, name_expr) : drt_jit::poll(ctx->arch, name_expr);
+    if (!pe)
         return nullptr;
-    const drt_jit::Code& c = *pc;
+    const drt_jit::Code& c = pe->code;
     if (!c.ok) {
         ctx->jit_error = c.log;
     } else {
@@ -288,8 +288,10 @@ void shard_plan(Shard<R>& s)
         // instantiation, which the library does not carry: it is compiled at run time (f32, unless the context may not
         // compile).  Everything else takes the tape route: two walks of the tape, k_radiance then k_backward.
         s.use_path = false;
+        // (DRT_SPECIALISE_AUTO: no frame waits for the compiler -- the compile runs on the library's own thread from the first
+        //  such frame on, and the tape route renders until it has delivered; DRT_SPECIALISE_NOW waits)
         if (sizeof(R) == 4 && !ctx->emissive_bxdf && ctx->jit_mode >= DRT_SPECIALISE_AUTO) {
-            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true));
+            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true), ctx->jit_mode > DRT_SPECIALISE_AUTO);
             s.use_path = s.loss_kernel != nullptr;
         }
     }

@@ -274,6 +274,18 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     const int n_dev_params = hf->n_params;   // user parameters + internal constants
     ctx->prog_ok = hf->prog_ok != 0;
     ctx->prog_sorted = hf->prog_sorted != 0;
+    // The kernels hiprtc made for the PREVIOUS scene's shape kinds are of no use to a scene with other kinds: unload them (a
+    // long-lived context that sees scene after scene -- an editor, a fuzzer -- otherwise keeps one loaded module per signature
+    // and variant until it is destroyed).  Nothing of this context is running: the streams were waited for above.
+    if (memcmp(ctx->prog_sig, sig, sizeof ctx->prog_sig) != 0 || ctx->n_shapes != s->n_shapes) {
+        for (int i = 0; i < 2; ++i)
+            if (ctx->path_stream[i])
+                (void)hipStreamSynchronize(ctx->path_stream[i]);
+        for (hipModule_t m : ctx->jit_modules)
+            (void)hipModuleUnload(m);
+        ctx->jit_modules.clear();
+        ctx->jit_fn.clear();
+    }
     for (int i = 0; i < 4; ++i)
         ctx->prog_sig[i] = sig[i];
     ctx->max_colour_param = -1;

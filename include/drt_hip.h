@@ -267,6 +267,9 @@ int drt_hip_create(int device_id, drt_hip_ctx** out);
  * (multi-node), normally 0 / 1.  A device may be listed more than once (testing on a single-GPU box). */
 int drt_hip_create_group(const int* device_ids, int n_devices, drt_hip_ctx** out);
 int drt_hip_group_size(const drt_hip_ctx* ctx);   /* members of a group context, 1 for a plain one */
+/* The PCI bus id ("0000:c1:00.0") of the device member `member` of the context renders on (0 for a plain context): what a
+ * launcher logs to show that N ranks -- or the N members of a group -- really sit on N different GPUs. */
+int drt_hip_device_pci_bus_id(const drt_hip_ctx* ctx, int member, char* out, int capacity);
 void drt_hip_destroy(drt_hip_ctx* ctx);
 /* One process per GPU: rank 0 calls drt_hip_comm_unique_id and hands the 128 bytes to the other ranks
  * out of band (torch.distributed store, MPI, a file); every rank then calls drt_hip_comm_init_rank on its
@@ -290,7 +293,9 @@ int drt_hip_update_params(drt_hip_ctx* ctx, const double* params /* n_params x 3
  *   DRT_SPECIALISE_AUTO    (default) once the scene has rendered 2^31 path-bounces through this context (~20 ms of
  *                          frames): small test frames never pay for a compile, a render loop does within its first frames
  *                          -- on a thread of the library's own: no frame waits for the compiler, the frames rendered
- *                          meanwhile use the run-time program (drt_hip_stats.path_program says which one ran)
+ *                          meanwhile use the run-time program (drt_hip_stats.path_program says which one ran).  The
+ *                          per-sample loss (DRT_RENDER_LOSS_L2) on the one-launch route is a kernel of this kind too: its
+ *                          compile starts with the first such frame, the tape route renders until it has delivered
  *   DRT_SPECIALISE_NOW     at the next render that can use it, which waits for the compile (a caller that knows it
  *                          will render many frames and wants every one of them on the fast kernel)
  * The environment variable DRT_HIP_JIT (-1 | 0 | 1 | force) sets the default of new contexts.  Group contexts: every member. */
