@@ -36,6 +36,8 @@
 
 #include "drt_kernels.h"
 
+#define DRT_DRAW_TABLE (3 * DRT_MAX_DEPTH + 8)     // camera 2 (+1), then per vertex theta, phi and the next depth's roulette
+
 struct PathArgs {
     // frame / sharding
     int32_t W, H, spp;
@@ -278,8 +280,11 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
                                    R pk, R inv_pk, uint32_t n_theta, bool next_rr, bool next_cap, bool live, V3<R> g,
                                    typename Q4<R>::T& ra, typename Q2<R>::T& rb, V3<R>& T, V3<R>& L, Tangents<R, NP, NC>& tg,
                                    bool& alive, bool& capped, bool& on_light, uint32_t& light, PathVertex<R>* vo = nullptr,
-                                   bool last = false, const float* __restrict__ seed_px = nullptr)
+                                   bool last = false, const float* __restrict__ seed_px = nullptr, const uint32_t* ih = nullptr)
 {
+    // (ih, the forms whose lanes stand at their own depths: the draw indices' hash rounds h(n) as a table in LDS -- where all
+    //  lanes of a wave share the index, the lockstep kernel, the scalar unit computes h(n) and the table would only cost)
+    auto draw = [&](uint32_t n) { return ih ? drt_rng_combine(ih[n], key) : rng_draw(a.rng_stream, key, n); };
     // (seed_px, the regenerating form: where the pixel's adjoint seed stands in the caller's image -- read only where a vertex
     //  emits, instead of carrying it in registers for a lane that changes pixel with every path)
     // `last` (wave-uniform; the lockstep kernel at the deepest vertex a path can have): no lane's path goes on from here, so
@@ -311,7 +316,7 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
         alive = false;
         capped = false;
         if (!a.cap_is_roulette) {                                      // (a user max_depth: had the roulette let the path live?)
-            const bool rr_kills = next_rr && rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold;
+            const bool rr_kills = next_rr && draw(n_theta + 2) < a.rr_threshold;
             capped = hit && has_bxdf && !rr_kills;
         }
         return;
@@ -340,11 +345,11 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
     const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? sh.material : 0];
     V3<R> wo;
     R q, bs;
-    sample_bxdf<R, SPEC>(m, nrm, d, rng_draw(a.rng_stream, key, n_theta), rng_draw(a.rng_stream, key, n_theta + 1), wo, q, bs);
+    sample_bxdf<R, SPEC>(m, nrm, d, draw(n_theta), draw(n_theta + 1), wo, q, bs);
     const R c = dot(nrm, wo);                                         // pathtracer.hpp:103
     const R mk_ = div_r(bs * c, q * pk);                              // T_{k+1} = T_k * colour * m_k (f32: v_rcp, 1 ulp)
     // roulette / cap of the next depth (pathtracer.hpp:128)
-    const bool rr_kills = next_rr && rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold;
+    const bool rr_kills = next_rr && draw(n_theta + 2) < a.rr_threshold;
     alive = hit && has_bxdf && !next_cap && !rr_kills;
     capped = hit && has_bxdf && next_cap && !a.cap_is_roulette && !rr_kills;
     // the throughput moves on only in lanes whose path goes on (the others stay frozen for the light's turn); with
@@ -544,7 +549,10 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     __shared__ R s_pcs[REGEN ? DRT_BLOCK : 1], s_pct[REGEN ? DRT_BLOCK : 1];
     __shared__ uint32_t s_pgpix[REGEN ? DRT_BLOCK : 1];
     __shared__ double s_film[REGEN ? 3 : 1][REGEN ? DRT_BLOCK : 1];
+    __shared__ uint32_t s_ih[REGEN ? DRT_DRAW_TABLE : 1];      // h(n) of every draw index a path of <= DRT_MAX_DEPTH vertices can reach
     if (REGEN) {
+        for (uint32_t n = threadIdx.x; n < DRT_DRAW_TABLE; n += DRT_BLOCK)
+            s_ih[REGEN ? n : 0] = drt_rng_index_hash(a.rng_stream, n);
         s_pcs[threadIdx.x] = cl.cs0;
         s_pct[threadIdx.x] = cl.ct0;
         s_pgpix[threadIdx.x] = have ? gpix : 0xFFFFFFFFu;       // (no such pixel: its samples are skipped)
@@ -613,7 +621,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             V3<R> gp3 = mk<R>(R(1), R(1), R(1));
             const float* seed_px = (NP > 0 && adjoint) ? adjoint + (size_t)pgpix * 3 : (const float*)nullptr;
             path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, gp3,
-                                                    ra, rb, T, L, tg, alive, capped, on_light, light, nullptr, false, seed_px);
+                                                    ra, rb, T, L, tg, alive, capped, on_light, light, nullptr, false, seed_px, s_ih);
             if (!a.cap_is_roulette)
                 n_capped += (uint32_t)__popcll(wave_ballot(capped));
             // ---- paths that ended here hand their radiance to their pixel

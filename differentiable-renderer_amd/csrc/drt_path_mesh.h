@@ -47,6 +47,9 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     __shared__ ProgLds s_prog;                            // f32: the kind-sorted program of the analytic shapes
     __shared__ uint32_t s_stack[DRT_MESH_LDS_STACK][DRT_BLOCK];
     __shared__ R s_acc[NP > 0 ? NP * 3 : 1][DRT_BLOCK];
+    __shared__ uint32_t s_ih[DRT_DRAW_TABLE];             // h(n) of every draw index (lanes stand at their own depths: drt_path.h)
+    for (uint32_t n = threadIdx.x; n < DRT_DRAW_TABLE; n += DRT_BLOCK)
+        s_ih[n] = drt_rng_index_hash(a.rng_stream, n);
     stage_tail_program(s_prog, sc);
     stage_path_scene(lds, sc, params);                    // (ends with a barrier)
     const TangentLds<R>& tl = s_tl;
@@ -171,11 +174,11 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                 const DevMaterial<R>& m = lds.sc.materials[has_bxdf ? material : 0];
                 V3<R> wo;
                 R q, bs;
-                sample_bxdf<R, SPEC>(m, nrm, d, rng_draw(a.rng_stream, key, n_theta), rng_draw(a.rng_stream, key, n_theta + 1), wo, q, bs);
+                sample_bxdf<R, SPEC>(m, nrm, d, drt_rng_combine(s_ih[n_theta], key), drt_rng_combine(s_ih[n_theta + 1], key), wo, q, bs);
                 const R c = dot(nrm, wo);                                   // pathtracer.hpp:103
                 const R mk_ = div_r(bs * c, q * pk);                        // T_{k+1} = T_k * colour * m_k
                 const bool next_rr = (kk + 1) >= a.min_bounces, next_cap = (kk + 1) >= a.depth_cap;
-                const bool rr_kills = next_rr && rng_draw(a.rng_stream, key, n_theta + 2) < a.rr_threshold;   // pathtracer.hpp:128
+                const bool rr_kills = next_rr && drt_rng_combine(s_ih[n_theta + 2], key) < a.rr_threshold;   // pathtracer.hpp:128
                 const bool alive = hit && has_bxdf && !next_cap && !rr_kills;
                 capped = hit && has_bxdf && next_cap && !rr_kills;
                 const int cidx = has_bxdf ? (int)cid : 0;
