@@ -632,7 +632,7 @@ def main():
             fwd_view = dict(timed_variant(backward=False), note="forward only (BASELINE config 2 when the headline is config 3)")
 
     # Two contexts on this device rendering the headline's frames alternately (no collective): the last, partly filled round of
-    # one frame's k_path grid is filled by the next frame's first -- what a render loop over several views gets
+    # one frame's k_path grid is filled by the next frame's first -- what a render loop over several views gets (HISTORY.md 1)
     two_ctx_view = None
     if extra and register_resident and not a.unbiased and world == 1:
         try:

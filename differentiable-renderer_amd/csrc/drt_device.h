@@ -115,8 +115,7 @@ struct DevBvh {
 #define DRT_BVH_NONE 0xFFFFFFFFu
 #define DRT_BVH_LEAF 0x80000000u
 #ifndef DRT_BVH_LDS_NODES
-#define DRT_BVH_LDS_NODES 16         // 1 KB of LDS per block: the very top of the tree.  (128 nodes = 8 KB measured no faster --
-                                     // 4.41 / 4.48 / 4.50 ms per step for 64 / 128 / 16 nodes -- and the room buys a fifth block per CU)
+#define DRT_BVH_LDS_NODES 16         // 1 KB of LDS per block: the very top of the tree (more measured no faster: HISTORY.md 3c)
 #endif
 #ifndef DRT_BVH_STACK
 #define DRT_BVH_STACK 30             // per-lane traversal stack in LDS, 30 KB per block (+ 1 KB of nodes: five blocks per CU).  The
@@ -124,8 +123,7 @@ struct DevBvh {
                                      // (drt_bvh.h; the 50,880-triangle test mesh needs 29)
 #endif
 #ifndef DRT_WALK_MIN_BLOCKS
-#define DRT_WALK_MIN_BLOCKS 5        // k_intersect_mesh<float> is compiled for five blocks per CU: 96 registers (20 bytes of scratch
-                                     // per lane) -- 4.44 -> 4.29 ms per step against four blocks at 116 registers
+#define DRT_WALK_MIN_BLOCKS 5        // k_intersect_mesh<float> is compiled for five blocks per CU (96 registers: HISTORY.md 3c)
 #endif
 // the walk's waves pull candidate lists from DRT_PULL_COUNTERS counters, each on a cache line of its own (one
 // address sustains only ~88 returning atomics per microsecond): counter c hands out the lists c, c + 64, c + 128, ...

@@ -6,8 +6,17 @@
 //   drt_jit.h          k_path compiled for a scene's shape kinds at run time (hiprtc)
 //   drt_render_impl.h  one shard's render enqueued: the k_path route and the queue wavefront
 //   drt_render.h       a render call in phases; group contexts; asynchronous frames; the all-reduce
-// and the kernels in drt_path.h (k_path) and drt_kernels.h (K1-K7, the BVH walk).
+// and the kernels in headers by topic too:
+//   drt_kernels.h      K1-K5 of the queue wavefront + what all kernels share (RNG, camera, analytic closest hit, BxDF sampler)
+//   drt_walk.h         K2 on triangles: the BVH walk
+//   drt_backward.h     K6 / K7: the tape's reverse sweep, gradient accumulators, the fixed-order reduction
+//   drt_chain.h        the unbiased operator's adjoint rounds on the queue wavefront
+//   drt_path.h         k_path / k_path_unbiased: the whole path in one launch (analytic scenes)
+//   drt_path_mesh.h    k_path_mesh: the same with the BVH walk inside (small frames of mesh scenes)
 #include "drt_kernels.h"
+#include "drt_walk.h"
+#include "drt_backward.h"
+#include "drt_chain.h"
 #include "drt_path.h"
 #include "drt_path_mesh.h"
 #include "drt_bvh.h"

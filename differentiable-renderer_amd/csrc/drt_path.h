@@ -201,7 +201,7 @@ struct Tangents {
     // The lane's gradient sums, NP x 3 values, live in an LDS column of the block (acc[row][thread]: conflict-free), not
     // in registers: they are touched once per SAMPLE (where the path meets a light), and twelve registers held across the
     // bounce loop cost the kernel its sixth wave per SIMD (96 -> 80 VGPRs; as scratch spills, which is what the compiler
-    // makes of them when told to fit six waves, 0.728 -> 0.704 ms on config 3; as an LDS column: see DESIGN.md 3a).
+    // makes of them when told to fit six waves, 0.728 -> 0.704 ms on config 3; as an LDS column: see HISTORY.md 3a).
     R* acc;
     __device__ inline V3<R> acc_get(int p) const { return mk<R>(acc[(p * 3) * DRT_BLOCK], acc[(p * 3 + 1) * DRT_BLOCK], acc[(p * 3 + 2) * DRT_BLOCK]); }
     __device__ inline void acc_set(int p, V3<R> v) { acc[(p * 3) * DRT_BLOCK] = v.x; acc[(p * 3 + 1) * DRT_BLOCK] = v.y; acc[(p * 3 + 2) * DRT_BLOCK] = v.z; }

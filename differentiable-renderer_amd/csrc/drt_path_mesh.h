@@ -20,6 +20,7 @@
 #pragma once
 
 #include "drt_path.h"
+#include "drt_walk.h"
 
 #ifndef DRT_MESH_LDS_STACK
 #define DRT_MESH_LDS_STACK 16

@@ -7,12 +7,7 @@
 #include "drt_device.h"
 
 // ---- the intersection program (f32) ----------------------------------------------------------------
-// (Two cheaper forms of this accept were measured on config 3 and NOT kept.  (i) One unsigned compare of the bit patterns
-// -- negative t, NaN and +inf order above every positive float; t = +0, which the eye ON the front plane produces, pushed
-// below zero by an fma with -1e-30 in place of the last multiply: 9 vector and 5 scalar instructions fewer per bounce,
-// yet 0.805 against 0.790 ms (41 interleaved rounds, twice).  (ii) The shape index in the four low mantissa bits of t and
-// the closest hit as a plain v_min3_u32 over those words: 28 vector instructions fewer, 0.827 against 0.844 ms, but the
-// hit point moves by up to 15 ulp of t and the library's routes stop agreeing to rounding.)
+// (two cheaper forms of this accept were measured on config 3 and not kept: HISTORY.md 3a)
 // (f64, the verification mode: the same formulas with a full-precision reciprocal and square root; only the compiled-in
 // form -- the reference's own scene -- exists in f64, every other scene keeps the literal loop there)
 __device__ inline float prog_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
