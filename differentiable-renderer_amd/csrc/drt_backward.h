@@ -29,6 +29,7 @@
 //        the others.  The read-add-write chains serialise on lgkmcnt, so NP > 0 is ~2x faster.
 template <typename R, int NP>
 struct GradAcc {
+    static constexpr bool kWave = false;     // (add() may be called by any subset of a wave's lanes)
     R r[NP][3];
     __device__ inline void init(R (*)[DRT_BLOCK])
     {
@@ -46,6 +47,7 @@ struct GradAcc {
             r[p][2] += sel ? v.z : R(0);
         }
     }
+    __device__ inline void add_wave(R (*a)[DRT_BLOCK], double* __restrict__ g, uint32_t id, V3<R> v) { add(a, g, id, v); }
     __device__ inline double get(R (*)[DRT_BLOCK], int row) const
     {
         double v = 0;
@@ -64,6 +66,7 @@ struct GradAcc {
 // instead of a compare + three selects + three adds per parameter.
 template <int NP>
 struct GradAccF32 {
+    static constexpr bool kWave = false;
     static_assert(NP % 2 == 0, "z components are paired");
     drt_f2 xy[NP], zz[NP / 2];
     __device__ inline void init(float (*)[DRT_BLOCK])
@@ -89,6 +92,7 @@ struct GradAccF32 {
         for (int q = 0; q < NP / 2; ++q)
             zz[q] = __builtin_elementwise_fma(drt_f2{w[2 * q], w[2 * q + 1]}, vzz, zz[q]);
     }
+    __device__ inline void add_wave(float (*a)[DRT_BLOCK], double* __restrict__ g, uint32_t id, V3<float> v) { add(a, g, id, v); }
     __device__ inline double get(float (*)[DRT_BLOCK], int row) const
     {
         double v = 0;
@@ -111,11 +115,22 @@ template <> struct GradAcc<float, 8> : GradAccF32<8> {};
 // addresses -- 117 ms instead of 0.4 for a mesh with seven per-face albedos.  Parameters beyond DRT_LDS_PARAMS (none
 // in practice: a scene has at most 64 materials and 64 emitters) still go to the gradient vector directly.
 // The pointer travels through the accumulator interface as R (*)[DRT_BLOCK]; it points at DRT_LDS_PARAMS * 3 doubles.
+// the value lane `byte_address / 4` holds (ds_bpermute)
+__device__ inline float lane_read(int byte_address, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_address, __float_as_int(v))); }
+__device__ inline double lane_read(int byte_address, double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_address, (int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_address, (int)(uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 template <typename R>
 struct GradAcc<R, 0> {
-    // The first DRT_FAST_PARAMS parameters stay in registers here too: in a room with a mesh they are the walls' colours and
-    // the light -- most vertices of most paths -- and as LDS atomics they all land on the same few words (config 4 with an
-    // albedo per face, 50,884 parameters: K6 4.1 ms that way).  One-hot accumulation like GradAcc<R, 8>; ids beyond add nothing there.
+    static constexpr bool kWave = true;      // K6 calls add_wave() with ALL lanes of the wave (ids of DRT_ID_NONE add nothing)
+    // The first DRT_FAST_PARAMS parameters stay in registers (one-hot accumulation like GradAcc<R, 8>; other ids add nothing
+    // there): in a room with a mesh they are the walls' colours and the light -- most vertices of most paths -- and as LDS
+    // atomics they all land on the same few words (config 4 with an albedo per face: K6 3.9 ms that way, 3.2 ms this way).
     GradAcc<R, DRT_FAST_PARAMS> fast;
     __device__ inline void init(R (*acc)[DRT_BLOCK])
     {
@@ -124,6 +139,7 @@ struct GradAcc<R, 0> {
         for (int r = threadIdx.x; r < DRT_LDS_PARAMS * 3; r += DRT_BLOCK)
             blk[r] = 0.0;                        // (visible to the block after stage_scene's barrier)
     }
+    // any subset of a wave's lanes (the unbiased operator's chain kernel): per-lane atomics, LDS rows or the gradient vector
     __device__ inline void add(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
     {
         fast.add(acc, grad, id, v);
@@ -132,6 +148,39 @@ struct GradAcc<R, 0> {
             atomicAdd(dst + 0, (double)v.x);
             atomicAdd(dst + 1, (double)v.y);
             atomicAdd(dst + 2, (double)v.z);
+        }
+    }
+    // The same for a whole wave at once (every lane calls; id == DRT_ID_NONE: nothing to add).  Parameters beyond the LDS rows
+    // go to the gradient vector with fp64 atomics, which execute at the memory side as 64-byte requests: three adds per lane
+    // (x, y, z) are three requests of 8 useful bytes each -- 0.16 TB/s of added bytes, an eighth of the chip's atomic rate
+    // (config 4 with an albedo per face: K6 4.1 ms).  So the lanes are TRANSPOSED first: in round r lane L carries component
+    // (64 r + L) % 3 of the vertex of lane (64 r + L) / 3 -- three neighbouring lanes add the x, y, z of one parameter's row,
+    // 24 contiguous bytes, one request (two where the row straddles a line).
+    __device__ inline void add_wave(R (*acc)[DRT_BLOCK], double* __restrict__ grad, uint32_t id, V3<R> v)
+    {
+        fast.add(acc, grad, id, v);
+        const bool none = id == DRT_ID_NONE;
+        if (!none && id >= DRT_FAST_PARAMS && id < DRT_LDS_PARAMS) {
+            // (the block's rows in LDS, addressed as LDS: the low word of a generic LDS pointer is the LDS offset)
+            typedef __attribute__((address_space(3))) double lds_double;
+            lds_double* dst = (lds_double*)(uint32_t)(uintptr_t)(reinterpret_cast<double*>(acc) + id * 3);
+            __hip_atomic_fetch_add(dst + 0, (double)v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 1, (double)v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 2, (double)v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const uint32_t fid = (!none && id >= DRT_LDS_PARAMS) ? id : DRT_ID_NONE;
+        if (__builtin_amdgcn_ballot_w64(fid != DRT_ID_NONE) == 0)
+            return;
+        const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
+#pragma unroll
+        for (uint32_t r = 0; r < 3; ++r) {
+            const uint32_t q = r * DRT_WAVE + lane, src = q / 3u, comp = q - src * 3u;
+            const int at = (int)(src << 2);                       // ds_bpermute addresses lanes in bytes
+            const uint32_t sid = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)fid);
+            const R sx = lane_read(at, v.x), sy = lane_read(at, v.y), sz = lane_read(at, v.z);
+            const R val = comp == 0 ? sx : (comp == 1 ? sy : sz);
+            if (sid != DRT_ID_NONE)
+                atomicAdd(grad + (size_t)sid * 3 + comp, (double)val);
         }
     }
     __device__ inline double get(R (*acc)[DRT_BLOCK], int row) const { return fast.get(acc, row); }
@@ -190,10 +239,22 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
                                      const TapeRec<R>* first_chunk = nullptr)
 {
     V3<R> Ln = mk<R>(R(0), R(0), R(0));
-    for (int c0 = ((K - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
+    // (an accumulator that adds a whole wave at a time -- Acc::kWave, the general one -- is called by ALL lanes at every step:
+    //  the chunk loop then runs to the longest path of the wave, each lane under its own `k < K`, and a lane without a
+    //  contribution hands over DRT_ID_NONE and zeros)
+    int Kw = K;
+    if (Acc::kWave) {
+#pragma unroll
+        for (int off = DRT_WAVE / 2; off > 0; off >>= 1) {
+            const int o2 = __shfl_xor(Kw, off);
+            Kw = o2 > Kw ? o2 : Kw;
+        }
+    }
+    for (int c0 = ((Kw - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
         // prefix throughput at the start of this chunk (only for paths longer than a chunk)
         V3<R> T = mk<R>(R(1), R(1), R(1));
-        for (int j = 0; j < c0; ++j) {
+        // (a lane whose path ends before this chunk has nothing to rebuild -- and its LAST vertex may carry no colour id)
+        for (int j = 0; j < c0 && c0 < K; ++j) {
             const TapeRec<R> tr = tape[(size_t)j * N + i];
             T = T * load_param<R, SMALL>(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
         }
@@ -225,21 +286,32 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
 #pragma unroll
         for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
             const int k = c0 + j;
+            uint32_t ide = DRT_ID_NONE, idc = DRT_ID_NONE;
+            V3<R> ve = mk<R>(R(0), R(0), R(0)), vc = ve;
             if (k < K) {
                 const uint32_t cid = ID[j] & 0xFFFFu, eid = ID[j] >> 16;
                 const R inv_pk = k >= a.min_bounces ? inv_p_rr : R(1);
                 const V3<R> adj = g * mk<R>(Tx[j], Ty[j], Tz[j]);
                 V3<R> Lk = mk<R>(R(0), R(0), R(0));
                 if (eid != DRT_ID_NONE) {
-                    acc.add(acc_lds, grad, eid, adj * inv_pk);
+                    ide = eid;
+                    ve = adj * inv_pk;
                     Lk = load_param<R, SMALL>(lds, params, (int)eid) * inv_pk;
                 }
                 if (cid != DRT_ID_NONE) {
                     const V3<R> wgt = Ln * M[j];
-                    acc.add(acc_lds, grad, cid, adj * wgt);
+                    idc = cid;
+                    vc = adj * wgt;
                     Lk = Lk + load_param<R, SMALL>(lds, params, (int)cid) * wgt;
                 }
                 Ln = Lk;
+            }
+            if (Acc::kWave) {
+                acc.add_wave(acc_lds, grad, ide, ve);
+                acc.add_wave(acc_lds, grad, idc, vc);
+            } else {
+                if (ide != DRT_ID_NONE) acc.add(acc_lds, grad, ide, ve);
+                if (idc != DRT_ID_NONE) acc.add(acc_lds, grad, idc, vc);
             }
         }
     }
@@ -287,21 +359,24 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     const size_t N = a.n_paths;
     const R inv_p_rr = (R)(1.0 / (1.0 - a.absorb));
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_paths; i += stride) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < a.n_paths; base += stride) {
+        // (the waves of a block walk the loop whole: the general accumulator adds a wave at a time; a lane beyond the batch has
+        //  no vertices)
+        const bool valid = base + threadIdx.x < a.n_paths;
+        const uint32_t i = valid ? base + threadIdx.x : a.n_paths - 1;
         // The first chunk of the tape is requested WITH the vertex count, not after it: one round trip
         // to memory per path instead of two (records beyond the path's end are read and ignored; the
-        // rows exist for every depth below the cap).  Also prefetching the NEXT path's chunk was
-        // measured slower: 174 VGPRs, 2 waves per SIMD.
-        const int K = (int)nv[i];
+        // rows exist for every depth below the cap).
+        const int K = valid ? (int)nv[i] : 0;
         TapeRec<R> first[DRT_TAPE_CHUNK];
 #pragma unroll
         for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
             if (j < a.depth_cap)
                 first[j] = tape[(size_t)j * N + i];
         V3<R> L0 = mk<R>(R(0), R(0), R(0));
-        if (K > 0)
+        if (K > 0 || GradAcc<R, NP>::kWave)
             L0 = backward_path<R, SMALL>(a, lds, params, tape, N, i, K, path_seed<R>(a, adjoint, i, radiance_in), inv_p_rr, ga, acc, grad, first);
-        if (lacc) {
+        if (lacc && valid) {
             R4 o;
             o.x = L0.x; o.y = L0.y; o.z = L0.z; o.w = R(0);
             lacc[i] = o;
@@ -360,6 +435,7 @@ k_radiance(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
 // per path instead of reduced -- written to a lacc-shaped buffer that K5 then averages per pixel.
 template <typename R>
 struct OneParamAcc {
+    static constexpr bool kWave = false;
     uint32_t param;
     V3<R> sum;
     __device__ inline void add(R (*)[DRT_BLOCK], double* __restrict__, uint32_t id, V3<R> v)
@@ -367,6 +443,7 @@ struct OneParamAcc {
         if (id == param)
             sum = sum + v;
     }
+    __device__ inline void add_wave(R (*a)[DRT_BLOCK], double* __restrict__ g, uint32_t id, V3<R> v) { add(a, g, id, v); }
 };
 
 template <typename R>

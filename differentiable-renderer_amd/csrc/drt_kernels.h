@@ -418,6 +418,10 @@ __device__ inline V3<R> load_param(const SceneLds<R>& lds, const R* __restrict__
 {
     if (ALL_LDS || id < DRT_LDS_PARAMS)
         return mk<R>(lds.params[id * 3], lds.params[id * 3 + 1], lds.params[id * 3 + 2]);
+    // (the empty asm keeps this load in a block of its own: merged with the one above into ONE load through a selected
+    //  generic pointer -- an LDS address cast to flat -- the compiler's address-space test does not assemble in K6's
+    //  wave-at-a-time form, ROCm 7.2 / gfx950: "V_CMP_NE_U32_e32 0, $src_shared_base")
+    asm volatile("");
     return mk<R>(params[id * 3], params[id * 3 + 1], params[id * 3 + 2]);
 }
 

@@ -150,7 +150,7 @@ def test_an_albedo_parameter_per_face(pkg, hip, oracle):
     _, g2, _ = hip.render(cam, rp, backward=True, f64=True)
     k = 4 + int(np.argmax(reached))
     assert not g2[k].any()
-    np.testing.assert_array_equal(np.delete(g2, k, 0), np.delete(g64, k, 0))
+    np.testing.assert_allclose(np.delete(g2, k, 0), np.delete(g64, k, 0), rtol=1e-12)      # (fp64 atomics: the order of the adds varies)
     # the gradient image of one face's albedo
     _, gi, _ = hip.render_gradient_image(cam, rp, 4 + int(np.argmax(np.abs(ref["grads"][4:]).sum(1))), f64=True)
     assert np.isfinite(gi).all() and np.abs(gi).max() > 0

@@ -6,6 +6,7 @@ restatement of the reference (oracle/), which knows the library's extensions (ma
 also run the per-sample squared-error loss and a gradient image against it.
 Usage: tools/fuzz_modes.py [n_cases] [seed]"""
 import dataclasses
+import os
 import sys
 import time
 
@@ -51,6 +52,8 @@ for case in range(n_cases):
     rp = pkg.RenderParams(**kw)
     unbiased = rs.rand() < 0.35
     adjoint = rs.uniform(0.2, 1.5, (h, w, 3)).astype(np.float32) if rs.rand() < 0.3 else None
+    if os.environ.get("FUZZ_TRACE"):
+        print(f"-- case {case}: {name} {w}x{h} {kw} shards {n_sh} unbiased {unbiased} adjoint {adjoint is not None}", flush=True)
     r.upload_scene(scene)
     t1 = time.time()
     a = r.render(cam, rp, backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
