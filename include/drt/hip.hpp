@@ -286,6 +286,25 @@ public:
     std::vector<double> grad_pool[DRT_HIP_FRAMES_IN_FLIGHT];
     bool slot_in_flight[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // the slot's buffers belong to a frame that has not been collected
     unsigned submitted = 0;
+    // The frame buffer of the SYNCHRONOUS call, kept between calls and -- on a plain context -- pinned (drt_hip_pin_host): the
+    // device's finishing kernel then writes a frame straight into it; no 3 MB allocation, staging copy or memcpy per call.
+    float* sync_frame(std::size_t n_floats, bool plain)
+    {
+        if (m_sync_frame.size() != n_floats) {
+            if (m_sync_pinned) {
+                (void)drt_hip_unpin_host(m_ctx, m_sync_frame.data());
+                m_sync_pinned = false;
+            }
+            m_sync_frame.assign(n_floats, 0.f);
+            if (plain && n_floats)
+                m_sync_pinned = drt_hip_pin_host(m_ctx, m_sync_frame.data(), n_floats * sizeof(float)) == DRT_OK;
+        }
+        return m_sync_frame.data();
+    }
+private:
+    std::vector<float> m_sync_frame;
+    bool m_sync_pinned = false;
+public:
 private:
     bool m_has_scene = false;
     std::mutex m_mutex;        // a context is not thread-safe: pooled ones are locked for the duration of a call
@@ -348,7 +367,8 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
                 adj[i * 3 + c] = float(real(adjoint[i][c]));
     }
     const std::size_t P = flat.requires_grad.size();
-    std::vector<float> frame(npix * 3, 0.f);
+    std::vector<float> own_frame;
+    const float* frame = nullptr;
     std::vector<double> grads(P * 3, 0.0);
     drt_hip_stats st{};
     {
@@ -358,6 +378,13 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
         Context& ctx = own ? *own : pooled_context(opt.devices);
         std::lock_guard<std::mutex> lock(ctx.mutex());
         ctx.set_scene(flat);
+        float* out = nullptr;
+        if (own) {
+            own_frame.assign(npix * 3, 0.f);
+            out = own_frame.data();
+        } else
+            out = ctx.sync_frame(npix * 3, n_dev == 1);      // (the pooled context's own buffer, pinned on a plain context)
+        frame = out;
         drt_render_params rp{};
         rp.spp = (int32_t)spp;
         rp.min_bounces = (int32_t)tracer.min_bounces();
@@ -373,13 +400,13 @@ inline Stats render(const Scene<T>& scene, const Camera<T>& cam, const Pathtrace
         rp.batch_paths = opt.batch_paths;
         rp.bounces_per_launch = opt.bounces_per_launch;
         // n_dev > 1: out_param_grad comes back ALREADY summed over the devices (one ncclAllReduce in the library)
-        ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, frame.data(),
+        ctx.check(drt_hip_render(ctx.get(), &cd, &rp, adjoint ? adj.data() : nullptr, out,
                                  opt.backward ? grads.data() : nullptr, &st),
                   "drt_hip_render");
+        for (std::size_t i = 0; i < npix; ++i)                 // (under the context's lock: the buffer is the context's)
+            for (int c = 0; c < 3; ++c)
+                img[i][c] = T(frame[i * 3 + c]);
     }
-    for (std::size_t i = 0; i < npix; ++i)
-        for (int c = 0; c < 3; ++c)
-            img[i][c] = T(frame[i * 3 + c]);
     Stats total;
     total.paths = st.paths;
     total.segments = st.segments;

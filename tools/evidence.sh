@@ -49,6 +49,14 @@ python3 tools/fuzz_overlap.py 300 1 2>&1 | grep -v amdgpu > "$E/fuzz_overlap.txt
 python3 tools/two_frames.py cornell 2>&1 | grep -v amdgpu > "$E/two_frames.txt"
 (python3 tools/jit_background.py random11; python3 tools/jit_background.py random5) 2>&1 | grep -v amdgpu > "$E/jit_background.txt"
 python3 tools/small_frames.py 2>&1 | grep -v amdgpu > "$E/small_frames.txt"
+# round 5: the synchronous call in its four forms; mesh scenes through both routes at small frame sizes; the roulette kernel's knobs;
+# config 4 with an albedo parameter per face; the group context's own bench mode (here: two members on the one device)
+python3 tools/sync_call.py 2>&1 | grep -v amdgpu > "$E/sync_call.txt"
+python3 tools/mesh_path_check.py small 2>&1 | grep -v amdgpu > "$E/mesh_small_frames.txt"
+python3 tools/mesh_path_check.py parity 2>&1 | grep -v amdgpu > "$E/mesh_path_parity.txt"
+python3 tools/roulette_sweep.py 2>&1 | grep -v amdgpu > "$E/roulette_sweep.txt"
+python3 bench.py --config 4 --per-face > "$E/bench_config4_per_face.json" 2>> "$E/bench.err"
+python3 bench.py --single-process --gpus 2 --same-gpu 2>> "$E/bench.err" | grep "^{" > "$E/bench_group_2members_same_gpu_plumbing.json"
 (timeout 300 python3 tools/allreduce_overlap.py; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager --context-between) 2>&1 | grep "ms per frame\|initialised" > "$E/launch_order.txt"
 (timeout 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{") > "$E/bench_1rank_under_torchrun.json"
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1

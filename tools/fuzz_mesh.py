@@ -21,7 +21,7 @@ worst64 = worst32 = 0.0
 t0 = time.time()
 for case in range(n_cases):
     lat, lon = int(rs.randint(3, 49)), int(rs.randint(3, 49))
-    pf = int(rs.choice([0, 0, 3, 5]))
+    pf = int(rs.choice([0, 0, 3, 5, -1]))          # (-1: an albedo parameter of its own per face, drt_mesh_desc::face_param)
     scene = pkg.cornell_with_mesh(lat, lon, pf, seed=int(rs.randint(1 << 20)))
     w, h = int(rs.randint(6, 49)), int(rs.randint(6, 41))
     cam = pkg.cornell_camera(w, h)
@@ -30,7 +30,8 @@ for case in range(n_cases):
     p = 1.0 if fixed else float(rs.choice([0.35, 0.5, 0.8]))
     unbiased = rs.rand() < 0.3
     rp = pkg.RenderParams(spp=int(rs.randint(1, 3 if unbiased else 5)), min_bounces=b, absorb=p, seed=int(rs.randint(1 << 30)),
-                          batch_paths=int(rs.choice([0, 0, 257, 1500])))
+                          batch_paths=int(rs.choice([0, 0, 257, 1500])),
+                          bounces_per_launch=int(rs.choice([0, 0, 1])))     # (1: the queue wavefront where k_path_mesh would run)
     adjoint = rs.uniform(0.2, 1.5, (h, w, 3)).astype(np.float32) if rs.rand() < 0.3 else None
     o = oracle.render(scene, cam, rp, backward=True, adjoint=adjoint, unbiased=unbiased, zero_dir_miss=unbiased)
     r.upload_scene(scene)
@@ -44,6 +45,6 @@ for case in range(n_cases):
     np.testing.assert_allclose(img, o["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
     assert np.isfinite(img32).all() and np.isfinite(g32).all() and abs(st32["segments"] - st["segments"]) <= 0.01 * st["segments"] + 8
     worst64, worst32 = max(worst64, e64), max(worst32, e32)
-    print(f"{case:3d} mesh{lat}x{lon}{'f%d' % pf if pf else '':3s} {2 * lon * (lat - 1):5d} triangles {w:3d}x{h:<3d} spp {rp.spp} b{b} p{p:g} {'unb' if unbiased else 'bia'} "
-          f"{'adj' if adjoint is not None else '   '} batch {rp.batch_paths:4d} rays {st['segments']:7d} (f32 {st32['segments'] - st['segments']:+d})  f64 mode {e64:.1e}  f32 mode {e32:.1e}", flush=True)
+    print(f"{case:3d} mesh{lat}x{lon}{('f%d' % pf if pf > 0 else 'fall') if pf else '':4s} {2 * lon * (lat - 1):5d} triangles {w:3d}x{h:<3d} spp {rp.spp} b{b} p{p:g} {'unb' if unbiased else 'bia'} "
+          f"{'adj' if adjoint is not None else '   '} batch {rp.batch_paths:4d} {'path ' if st['kernels']['path']['launches'] else 'queue'} rays {st['segments']:7d} (f32 {st32['segments'] - st['segments']:+d})  f64 mode {e64:.1e}  f32 mode {e32:.1e}", flush=True)
 print(f"FUZZ MESH OK: {n_cases} cases in {time.time() - t0:.0f} s; worst gradient deviation from the restatement: f64 mode {worst64:.2e}, f32 mode {worst32:.2e}")
