@@ -100,7 +100,9 @@ struct drt_hip_ctx {
     bool slot_used[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
     DevBuf fpart2, gpart2, counts2;       // k_path's partial sums of the odd frames
     DevBuf mesh_ovf[2];                   // k_path_mesh: traversal-stack entries beyond the ones in LDS, one area per k_path stream
-    DevBuf ray_a[2], ray_b[2], ray_id[2], hit, hit2, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand, cand_a, cand_b, cand_count,
+    // (scenes with a mesh: three sets of queue lanes and hit lanes -- a shade launch reads depth k and appends to k + 1 and k + 2 --
+    //  and two sets of candidate lists, by the parity of their depth)
+    DevBuf ray_a[3], ray_b[3], ray_id[3], hit, hit2, hit3, lacc, gpath, gfilm, gimg_out, tape, nv, fpart, gpix, cand[2], cand_a[2], cand_b[2], cand_count[2],
         ch_cva, ch_cvb, ch_cvh, ch_nxa, ch_nxb, ch_nxh, ch_g, ch_w, ch_ids, ch_ndraw, ch_dbase, counts, segtotal[DRT_HIP_FRAMES_IN_FLIGHT], film, gpart, grad[DRT_HIP_FRAMES_IN_FLIGHT], adjoint, out[DRT_HIP_FRAMES_IN_FLIGHT];   // one set per frame in flight (drt_hip_render_async; device frames that do not wait alternate between the first two), slot 0 otherwise
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;

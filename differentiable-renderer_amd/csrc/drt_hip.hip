@@ -128,7 +128,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->mesh_ovf[0], &ctx->mesh_ovf[1], &ctx->fpart2, &ctx->gpart2, &ctx->counts2, &ctx->fpart, &ctx->gpix, &ctx->cand, &ctx->cand_a, &ctx->cand_b, &ctx->cand_count, &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->hit, &ctx->hit2, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->mesh_ovf[0], &ctx->mesh_ovf[1], &ctx->fpart2, &ctx->gpart2, &ctx->counts2, &ctx->fpart, &ctx->gpix, &ctx->cand[0], &ctx->cand[1], &ctx->cand_a[0], &ctx->cand_a[1], &ctx->cand_b[0], &ctx->cand_b[1], &ctx->cand_count[0], &ctx->cand_count[1], &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_a[2], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_b[2], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->ray_id[2], &ctx->hit, &ctx->hit2, &ctx->hit3, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->film, &ctx->gpart, &ctx->adjoint};
     for (DevBuf* b : bufs)

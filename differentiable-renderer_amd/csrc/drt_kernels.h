@@ -594,6 +594,20 @@ __device__ inline HitRec<double> tail_closest_hit(const DevScene<double>* __rest
     return closest_hit_packed(sc, ra, rb);
 }
 
+// one queue a TAIL launch of k_shade appends to: the lanes of one depth, that depth's hit lane and candidate lists
+template <typename R>
+struct TailQueue {
+    typename Q4<R>::T* a;                       // the queue's rays ...
+    typename Q2<R>::T* b;
+    uint2* id;                                  // ... and their (path, RNG key)
+    HitRec<R>* hit;                             // hit lane of the queue's depth (the analytic hit; the walk refines it)
+    uint32_t* cand;                             // the walk's candidate lists of that depth, one per region: queue slot,
+    typename Q4<R>::T* cand_a;                  // (o.xyz, analytic t),
+    typename Q4<R>::T* cand_b;                  // (d.xyz, tie-break index)
+    uint32_t* cand_count;                       // records in region w's list
+    uint32_t* count;                            // rays in region w's queue: the counts row of that depth
+};
+
 // ---- the TAIL step, shared by the kernels that PRODUCE rays in scenes with a mesh (k_raygen, k_shade, k_adj_vertex) ------
 // The ray a lane has just written to queue slot `slot` of region w is intersected with the analytic shapes while it is still
 // in registers (the hit lane of the ray's depth gets the result) and, if it reaches the bounds of the mesh before that hit,
@@ -727,9 +741,13 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         int seg_start, const uint32_t* __restrict__ draw_base,
         typename Q4<R>::T* __restrict__ save_a, typename Q2<R>::T* __restrict__ save_b,
         HitRec<R>* __restrict__ save_hit,
-        DevBvh<R> bvh_t, HitRec<R>* __restrict__ hit_next, uint32_t* __restrict__ cand,
-        typename Q4<R>::T* __restrict__ cand_a, typename Q4<R>::T* __restrict__ cand_b, uint32_t* __restrict__ cand_count)
+        DevBvh<R> bvh_t, TailQueue<R> tq0, TailQueue<R> tq1, uint32_t* __restrict__ cont_row)
 {
+    // TAIL (scenes with a mesh; nb = 1 or 2): the launch appends to the queue of depth k + 1 (tq0) the rays that reach the
+    // bounds of the mesh -- they wait for the BVH walk -- and, nb = 2, takes the others, whose analytic hit is final, through
+    // the vertex of depth k + 1 in registers; what leaves THAT vertex goes to the queue of depth k + 2 (tq1).  A queue is
+    // appended to by two launches (k - 1: its second stage, k: its first), so a region's fill level is read when the region
+    // is begun; cont_row counts the rays that never saw a queue (they are segments too).
     // nb > 1 (FUSED only): the launch takes every ray through nb bounces -- depths k .. k+nb-1 -- in
     // registers; only the survivors of the LAST one are compacted and written back.  Lanes whose
     // path ended in between idle (a few per cent per bounce), in exchange the 64 bytes of queue
@@ -752,12 +770,18 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
     uint32_t* __restrict__ counts_next = counts_k + (size_t)nb * count_stride;
 
     if (TAIL && blockIdx.x == 0 && threadIdx.x < DRT_PULL_COUNTERS)     // the walk's list counters (it runs after this kernel)
-        pull_counters(cand_count, a.n_regions)[threadIdx.x * DRT_PULL_STRIDE] = 0;
+        pull_counters(tq0.cand_count, a.n_regions)[threadIdx.x * DRT_PULL_STRIDE] = 0;
     uint32_t cnt;
     uint32_t w = next_region<CAM>(a, counts_k, grid_wave(), n_waves, cnt);
     if (w >= a.n_regions)
         return;
-    uint32_t off = 0, running = 0, cand_running = 0;
+    uint32_t off = 0, running = 0;
+    // TAIL: fill levels of the region's queues and candidate lists (depth k + 1: what launch k - 1 left there), rays kept in registers
+    uint32_t run0 = 0, crun0 = 0, run1 = 0, crun1 = 0, n_cont = 0, nrun0 = 0, ncrun0 = 0;
+    if (TAIL) {
+        run0 = tq0.count[w];
+        crun0 = tq0.cand_count[w];
+    }
     ShadeIn<R> cur, nxt;
     bool have = lane < cnt;
     if (!CAM)
@@ -774,6 +798,10 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         const bool nhave = more && noff + lane < ncnt;
         if (!CAM)
             load_shade_in(nxt, (nw << a.region_shift) + noff + lane, nhave, !FUSED, ray_a, ray_b, ray_id, hit);
+        if (TAIL && more && nw != w) {
+            nrun0 = tq0.count[nw];
+            ncrun0 = tq0.cand_count[nw];
+        }
         if (CAM && have) {
             const uint32_t i = (w << a.region_shift) + off + lane;      // all alive at depth 0: slot == path
             cur.rid.x = i;
@@ -783,6 +811,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
         bool alive = false, live = have;
         R4 ra = cur.ra, na;
         R2 rb = cur.rb, nb2;
+        HitRec<R> hc = cur.h;                                      // (TAIL: the final hit of the ray in registers)
         const uint32_t pid = cur.rid.x, key = cur.rid.y;
         for (int it = 0;; ++it) {
             const int kk = k + it;
@@ -800,7 +829,7 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                 if (FUSED) {
                     h = closest_hit_packed(sc, ra, rb);
                 } else {
-                    h = cur.h;
+                    h = hc;
                 }
                 if (save_a && it == 0) {   // unbiased backward: this ray and its hit are the path's next chain vertex
                     save_a[pid] = ra;
@@ -867,6 +896,57 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
                 if (lane == 0 && n_cap)
                     atomicAdd(counts_k + (size_t)(it + 1) * count_stride + w, n_cap);
             }
+            if (TAIL) {
+                // the ray this vertex produced: its analytic hit while it is in registers; does it reach the bounds of the mesh?
+                bool reach = false;
+                HitRec<R> hn;
+                hn.t = (R)INFINITY;
+                hn.prim = -1;
+                if (alive) {
+                    hn = tail_closest_hit(sc, recs, na, nb2);
+                    const V3<R> o2 = mk<R>(na.x, na.y, na.z), d2 = mk<R>(na.w, nb2.x, nb2.y);
+                    const V3<R> inv2 = mk<R>(div_r(R(1), d2.x), div_r(R(1), d2.y), div_r(R(1), d2.z));   // (f32: v_rcp; the bounds are padded)
+                    R tn;
+                    reach = box_hit(mk<R>(bvh_t.lo[0], bvh_t.lo[1], bvh_t.lo[2]), mk<R>(bvh_t.hi[0], bvh_t.hi[1], bvh_t.hi[2]), o2, inv2, hn.t, tn);
+                }
+                const bool last = it + 1 >= nb;
+                const bool enq = alive && (reach || last);             // queued: waits for the walk, or the launch ends here
+                const TailQueue<R>& q = it == 0 ? tq0 : tq1;
+                const uint32_t qrun = it == 0 ? run0 : run1, qcrun = it == 0 ? crun0 : crun1;
+                uint32_t n_enq, n_reach;
+                const uint32_t ns = (w << a.region_shift) + qrun + wave_rank(enq, n_enq);
+                const uint32_t rk = wave_rank(reach, n_reach);
+                if (enq) {
+                    q.a[ns] = na;
+                    q.b[ns] = nb2;
+                    q.id[ns] = cur.rid;
+                    q.hit[ns] = hn;
+                }
+                if (reach) {
+                    const size_t at = ((size_t)w << a.region_shift) + qcrun + rk;
+                    const uint32_t flat = hn.prim >= 0 ? (uint32_t)sc->flat[hn.prim] : 0xFFFFFFFFu;
+                    R4 ca, cb;
+                    ca.x = na.x; ca.y = na.y; ca.z = na.z; ca.w = hn.t;
+                    cb.x = na.w; cb.y = nb2.x; cb.z = nb2.y; cb.w = pid_pack(R(0), flat);
+                    q.cand[at] = ns;
+                    q.cand_a[at] = ca;
+                    q.cand_b[at] = cb;
+                }
+                if (it == 0) { run0 += n_enq; crun0 += n_reach; }
+                else { run1 += n_enq; crun1 += n_reach; }
+                if (last)
+                    break;
+                const bool go = alive && !reach;
+                const uint32_t n_go = (uint32_t)__popcll(__ballot(go));
+                if (n_go == 0)
+                    break;
+                n_cont += n_go;
+                ra = na;
+                rb = nb2;
+                hc = hn;
+                live = go;
+                continue;
+            }
             if (it + 1 >= nb)
                 break;
             // survivors go straight into the next bounce; the row of the depth in between only counts them
@@ -879,27 +959,41 @@ k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R*
             rb = nb2;
             live = alive;
         }
-        uint32_t n_alive;
-        const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
-        if (alive) {
-            next_a[ns] = na;
-            next_b[ns] = nb2;
-            next_id[ns] = cur.rid;
+        if (!TAIL) {
+            uint32_t n_alive;
+            const uint32_t ns = (w << a.region_shift) + running + wave_rank(alive, n_alive);
+            if (alive) {
+                next_a[ns] = na;
+                next_b[ns] = nb2;
+                next_id[ns] = cur.rid;
+            }
+            running += n_alive;
         }
-        if (TAIL)
-            tail_emit<R>(a, sc, recs, bvh_t, alive, ns, na, nb2, w, cand_running, hit_next, cand, cand_a, cand_b);
-        running += n_alive;
         if (nw != w) {                                         // region finished
             if (lane == 0) {
-                if (k + nb < a.depth_cap)                      // (row depth_cap counts capped paths, see above)
+                if (!TAIL && k + nb < a.depth_cap)             // (row depth_cap counts capped paths, see above)
                     counts_next[w] = running;
                 if (CAM)
                     counts_k[w] = cnt;                         // depth 0: every path of the region
-                if (TAIL)
-                    cand_count[w] = cand_running;
+                if (TAIL) {
+                    if (k + 1 < a.depth_cap)
+                        tq0.count[w] = run0;
+                    tq0.cand_count[w] = crun0;
+                    if (nb > 1) {
+                        if (k + 2 < a.depth_cap)
+                            tq1.count[w] = run1;
+                        tq1.cand_count[w] = crun1;
+                        if (n_cont)
+                            cont_row[w] += n_cont;
+                    }
+                }
             }
             running = 0;
-            cand_running = 0;
+            run0 = nrun0;
+            crun0 = ncrun0;
+            run1 = 0;
+            crun1 = 0;
+            n_cont = 0;
         }
         if (!more)
             break;

@@ -174,10 +174,23 @@ struct Shard {
     BatchArgs a;
     int n_fast, g_rows, g_stride;   // gradient partials: gpart[block][g_stride], rows [0, g_rows) reduced over the blocks by K7
     // typed views of the queue buffers
-    R4* ra[2];
-    R2* rb[2];
-    uint2* rid[2];
+    int tail_nb = 1, tail_ring = 2; // shade_tail: stages of a shade launch (2: rays that miss the mesh bounds stay in registers through one more
+                                    // vertex, DRT_HIP_TAIL_BOUNCES) and sets of queue / hit lanes that takes (3: a launch reads depth k, appends to k + 1, k + 2)
+    R4* ra[3];                      // queue lanes: by depth parity, by depth mod tail_ring where the scene has a mesh (shade_tail)
+    R2* rb[3];
+    uint2* rid[3];
     HitRec<R>* hit;
+    HitRec<R>* hitr[3];             // shade_tail: the hit lanes of depth d mod tail_ring
+    TailQueue<R> tailq(int d) const  // shade_tail: what a launch that appends to the queue of depth d gets
+    {
+        TailQueue<R> q;
+        const int m = tail_ring;
+        q.a = ra[d % m]; q.b = rb[d % m]; q.id = rid[d % m]; q.hit = hitr[d % m];
+        q.cand = (uint32_t*)ctx->cand[d & 1].p; q.cand_a = (R4*)ctx->cand_a[d & 1].p; q.cand_b = (R4*)ctx->cand_b[d & 1].p;
+        q.cand_count = (uint32_t*)ctx->cand_count[d & 1].p;
+        q.count = counts + (size_t)d * max_regions;
+        return q;
+    }
     R4* lacc;
     TapeRec<R>* tape;
     uint32_t* nv;
@@ -304,7 +317,7 @@ void shard_plan(Shard<R>& s)
     uint64_t cap_default;
     {
         const uint64_t f = sizeof(R) / 4;
-        const uint64_t per_path = f * (112u + 8u * (uint64_t)(D > 0 ? D : 1) + (ctx->has_mesh ? 36u : 0u) + (s.unbiased ? 110u : 0u)) + 24u;
+        const uint64_t per_path = f * (112u + 8u * (uint64_t)(D > 0 ? D : 1) + (ctx->has_mesh ? 80u : 0u) + (s.unbiased ? (ctx->has_mesh ? 150u : 110u) : 0u)) + 24u;
         const uint64_t budget = std::min<uint64_t>(ctx->device_mem / 8, (uint64_t)32 << 30);
         cap_default = (uint64_t)1 << 22;
         while (cap_default < ((uint64_t)1 << 28) && 2 * cap_default * per_path <= budget)
@@ -356,13 +369,17 @@ void shard_plan(Shard<R>& s)
     s.path_ranges = (s.Sb + s.path_spr - 1) / s.path_spr;
     s.path_waves = (size_t)path_groups * s.path_ranges;
     s.shade_tail = ctx->has_mesh;
+    // two-stage shade launches (measured, same process, alternating): config 4's share 5.90 -> 6.15 ms of shade launches (20 % fewer
+    // bytes, 18 % more instructions, the second stage at two lanes in three), the unbiased operator's rounds 14.05 -> 13.25: on for those
+    s.tail_nb = s.shade_tail && (tuning().tail_bounces > 1 || (tuning().tail_bounces == 0 && s.unbiased)) ? 2 : 1;
+    s.tail_ring = s.tail_nb > 1 ? 3 : 2;
     s.overlap_ok = ctx->overlap_next && s.use_path && !s.timing && s.gimg_param < 0 && ctx->path_stream[0] && ctx->ev_copied[0];
     const bool odd = s.overlap_ok && (ctx->slot & 1);
     s.fpart_buf = odd ? &ctx->fpart2 : &ctx->fpart;
     s.gpart_buf = odd ? &ctx->gpart2 : &ctx->gpart;
     s.counts_buf = odd ? &ctx->counts2 : &ctx->counts;
     s.cw = s.use_path ? (s.mesh_path ? 3 : 2) * s.path_waves      // [segments | capped paths (| rays the BVH walk took)] per wave
-                      : (size_t)(D + 1) * s.max_regions;          // counts[depth][region] of one batch
+                      : (size_t)(D + 2) * s.max_regions;          // counts[depth][region] of one batch (row D: capped paths, D + 1: rays kept in registers)
     // a k_path launch that covers the whole frame is followed by ONE finishing launch that WRITES image, gradients and
     // totals (k_path_finish); every other route accumulates into zeroed buffers
     s.path_finish = s.use_path && s.Pb == s.n_local_pixels && s.Sb == (uint32_t)s.spp && (!s.film || s.d_out_rgb);
@@ -393,7 +410,7 @@ int shard_buffers(Shard<R>& s)
                              threads * (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) * sizeof(uint32_t))) != DRT_OK) return rc;
         }
     } else {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < (s.shade_tail ? s.tail_ring : 2); ++i) {
             if ((rc = ensure(ctx, ctx->ray_a[i], N * sizeof(R4))) != DRT_OK) return rc;
             if ((rc = ensure(ctx, ctx->ray_b[i], N * sizeof(R2))) != DRT_OK) return rc;
             if ((rc = ensure(ctx, ctx->ray_id[i], N * sizeof(uint2))) != DRT_OK) return rc;
@@ -404,10 +421,14 @@ int shard_buffers(Shard<R>& s)
             // per queue region (the region's own span of the candidate arrays) + the walk's list counters
             const size_t cand_words = (size_t)s.max_regions * s.region_size;
             if ((rc = ensure(ctx, ctx->hit2, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
-            if ((rc = ensure(ctx, ctx->cand, cand_words * sizeof(uint32_t))) != DRT_OK) return rc;
-            if ((rc = ensure(ctx, ctx->cand_a, cand_words * sizeof(R4))) != DRT_OK) return rc;
-            if ((rc = ensure(ctx, ctx->cand_b, cand_words * sizeof(R4))) != DRT_OK) return rc;
-            if ((rc = ensure(ctx, ctx->cand_count, ((size_t)s.max_regions + DRT_PULL_WORDS) * sizeof(uint32_t))) != DRT_OK) return rc;
+            if (s.tail_ring > 2)
+                if ((rc = ensure(ctx, ctx->hit3, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
+            for (int i = 0; i < 2; ++i) {
+                if ((rc = ensure(ctx, ctx->cand[i], cand_words * sizeof(uint32_t))) != DRT_OK) return rc;
+                if ((rc = ensure(ctx, ctx->cand_a[i], cand_words * sizeof(R4))) != DRT_OK) return rc;
+                if ((rc = ensure(ctx, ctx->cand_b[i], cand_words * sizeof(R4))) != DRT_OK) return rc;
+                if ((rc = ensure(ctx, ctx->cand_count[i], ((size_t)s.max_regions + DRT_PULL_WORDS) * sizeof(uint32_t))) != DRT_OK) return rc;
+            }
         }
         if ((rc = ensure(ctx, ctx->lacc, N * sizeof(R4))) != DRT_OK) return rc;
         if (s.gimg_param >= 0)
@@ -445,10 +466,13 @@ int shard_buffers(Shard<R>& s)
                                                              : (size_t)std::min(ctx->n_params, DRT_LDS_PARAMS) * 3;
         if ((rc = ensure(ctx, *s.gpart_buf, blocks * rows * sizeof(double))) != DRT_OK) return rc;
     }
-    s.ra[0] = (R4*)ctx->ray_a[0].p; s.ra[1] = (R4*)ctx->ray_a[1].p;
-    s.rb[0] = (R2*)ctx->ray_b[0].p; s.rb[1] = (R2*)ctx->ray_b[1].p;
-    s.rid[0] = (uint2*)ctx->ray_id[0].p; s.rid[1] = (uint2*)ctx->ray_id[1].p;
+    for (int i = 0; i < 3; ++i) {
+        s.ra[i] = (R4*)ctx->ray_a[i].p;
+        s.rb[i] = (R2*)ctx->ray_b[i].p;
+        s.rid[i] = (uint2*)ctx->ray_id[i].p;
+    }
     s.hit = (HitRec<R>*)ctx->hit.p;
+    s.hitr[0] = s.hit; s.hitr[1] = (HitRec<R>*)ctx->hit2.p; s.hitr[2] = (HitRec<R>*)ctx->hit3.p;
     s.lacc = (R4*)ctx->lacc.p;
     s.tape = (TapeRec<R>*)ctx->tape.p;
     s.nv = (uint32_t*)ctx->nv.p;
@@ -697,7 +721,9 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
     const int gk2 = grid_for(ctx, a.n_paths);
     int rc;
     for (int k = first, lc = 0, nbk = 1, next_poll = first + DRT_POLL_EVERY; k < D; k += nbk, ++lc) {
-        const int cur = (parity0 + lc) & 1, nxt = cur ^ 1;
+        // (queue lanes: by the launch's parity; scenes with a mesh: by the depth mod s.tail_ring -- a two-stage launch appends to two queues)
+        const int ringm = s.tail_ring;
+        const int cur = shade_tail ? k % ringm : (parity0 + lc) & 1, nxt = shade_tail ? (k + 1) % ringm : cur ^ 1;
         nbk = s.bounces_from(k);
         if (!(camera_fused && k == 0)) *read |= 1ull << (k - base);         // (the camera launch generates its rays)
         if (k + nbk < D) *written |= 1ull << (k + nbk - base);
@@ -706,7 +732,8 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
             // (deep caps = roulette-terminated renders: ask every few bounces whether any path is still alive)
             next_poll = k + DRT_POLL_EVERY;
             unsigned long long live = 0;
-            if ((rc = queue_length(ctx, ck, s.max_regions, &live)) != DRT_OK) return rc;
+            // (scenes with a mesh: a ray kept in registers through depth k - 1 waits in the queue of depth k + 1)
+            if ((rc = queue_length(ctx, ck, (shade_tail && k + 1 < D ? 2u : 1u) * s.max_regions, &live)) != DRT_OK) return rc;
             if (live == 0)
                 break;        // every path has ended: deeper queues stay empty
         }
@@ -715,8 +742,7 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
         R2* sv_b = k == first ? sv_b0 : (R2*)nullptr;
         HitRec<R>* sv_hit = k == first ? sv_hit0 : (HitRec<R>*)nullptr;
         // hit lane of this depth (double-buffered where the shade launch fills the next depth's itself: mesh scenes)
-        HitRec<R>* hit_k = shade_tail && (lc & 1) ? (HitRec<R>*)ctx->hit2.p : s.hit;
-        HitRec<R>* hit_n = shade_tail ? ((lc & 1) ? s.hit : (HitRec<R>*)ctx->hit2.p) : (HitRec<R>*)nullptr;
+        HitRec<R>* hit_k = shade_tail ? s.hitr[k % ringm] : s.hit;
         if (!fused && !shade_tail) {
             // K2 as a kernel of its own (DRT_RENDER_UNFUSED: the textbook wavefront)
             DRT_TIMED(s, DRT_K_INTERSECT,
@@ -730,18 +756,30 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
             const uint32_t walk_group = (uint32_t)tuning().shade_list_group;
             DRT_TIMED(s, DRT_K_INTERSECT_MESH,
                       hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, s.d_scene, s.bvh, hit_k,
-                                         (const uint32_t*)ctx->cand.p, (const R4*)ctx->cand_a.p, (const R4*)ctx->cand_b.p,
-                                         (uint32_t*)ctx->cand_count.p, s.region_size, a.n_regions, walk_group,
+                                         (const uint32_t*)ctx->cand[k & 1].p, (const R4*)ctx->cand_a[k & 1].p, (const R4*)ctx->cand_b[k & 1].p,
+                                         (uint32_t*)ctx->cand_count[k & 1].p, s.region_size, a.n_regions, walk_group,
                                          coprime_multiplier((a.n_regions + walk_group - 1) / walk_group), s.totals));
         }
         TapeRec<R>* tape_k = s.tape + (size_t)k * a.n_paths;
         const bool tail_here = shade_tail && k + nbk < D;
-        if (tail_here)       // (the region lists of regions no wave visits stay empty)
-            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+        // the launch's two stages: the vertex of depth k, and -- for the rays that miss the bounds of the mesh, whose analytic
+        // hit is final -- the vertex of depth k + 1 in registers.  The lists of depth k + 1 hold what launch k - 1's second
+        // stage left there; the lists of depth k + 2 (= the ones the walk of depth k has just consumed) start empty.
+        const int tail_nb = tail_here ? s.tail_nb : 1;
+        if (tail_here) {     // (the region lists of regions no wave visits stay empty)
+            if (tail_nb == 1 || lc == 0)
+                HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[(k + 1) & 1].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+            if (tail_nb > 1)
+                HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[k & 1].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+        }
+        const TailQueue<R> tq0 = s.tailq(k + 1), tq1 = s.tailq(k + 2);
+        uint32_t* cont_row = s.counts + (size_t)(D + 1) * s.max_regions;
 #define DRT_SHADE_ARGS a, k, nbk, s.d_scene, s.d_params, s.ra[cur], s.rb[cur], s.rid[cur], hit_k, s.ra[nxt], s.rb[nxt], s.rid[nxt], tape_k, \
                        s.nv, ck, (uint32_t)s.max_regions, s.bvh.tri_shade
-#define DRT_SHADE_NO_TAIL s.bvh, (HitRec<R>*)nullptr, (uint32_t*)nullptr, (R4*)nullptr, (R4*)nullptr, (uint32_t*)nullptr
-#define DRT_SHADE_TAIL s.bvh, hit_n, (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p
+#define DRT_SHADE_ARGS_TAIL a, k, tail_nb, s.d_scene, s.d_params, s.ra[cur], s.rb[cur], s.rid[cur], hit_k, s.ra[nxt], s.rb[nxt], s.rid[nxt], tape_k, \
+                            s.nv, ck, (uint32_t)s.max_regions, s.bvh.tri_shade
+#define DRT_SHADE_NO_TAIL s.bvh, tq0, tq1, (uint32_t*)nullptr
+#define DRT_SHADE_TAIL s.bvh, tq0, tq1, cont_row
 #define DRT_LAUNCH_SHADE(SPEC)                                                                                                       \
     do {                                                                                                                            \
         if (fused && camera_fused && k == 0)                                                                                        \
@@ -751,7 +789,7 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
             hipLaunchKernelGGL((k_shade<R, SPEC, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, DRT_SHADE_ARGS, seg, dbase,       \
                                sv_a, sv_b, sv_hit, DRT_SHADE_NO_TAIL);                                                              \
         else if (tail_here)                                                                                                         \
-            hipLaunchKernelGGL((k_shade<R, SPEC, false, false, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, DRT_SHADE_ARGS,     \
+            hipLaunchKernelGGL((k_shade<R, SPEC, false, false, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, DRT_SHADE_ARGS_TAIL, \
                                seg, dbase, sv_a, sv_b, sv_hit, DRT_SHADE_TAIL);                                                     \
         else                                                                                                                        \
             hipLaunchKernelGGL((k_shade<R, SPEC, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, DRT_SHADE_ARGS, seg, dbase,      \
@@ -764,6 +802,7 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
 #undef DRT_LAUNCH_SHADE
 #undef DRT_SHADE_TAIL
 #undef DRT_SHADE_NO_TAIL
+#undef DRT_SHADE_ARGS_TAIL
 #undef DRT_SHADE_ARGS
     }
     return DRT_OK;
@@ -791,15 +830,16 @@ int adjoint_rounds(Shard<R>& s)
     s.st->launches[DRT_K_BACKWARD]++;
     for (int r = 0; r < D; ++r) {
         const int sd = r + 1;                                    // depth of the suffix's first ray
-        HIPCHK(ctx, hipMemsetAsync(s.counts + (size_t)sd * s.max_regions, 0, (size_t)(D + 1 - sd) * s.max_regions * sizeof(uint32_t), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(s.counts + (size_t)sd * s.max_regions, 0, (size_t)(D + 2 - sd) * s.max_regions * sizeof(uint32_t), ctx->stream));
         // (scenes with a mesh: the kernel also intersects the rays it queues with the analytic shapes and builds the BVH walk's
         //  candidate lists -- hit lane `hit`, the one the suffix loop starts on.  Timed with the backward pass.)
         if (s.shade_tail)
-            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[sd & 1].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+        const int sq = s.shade_tail ? sd % s.tail_ring : sd & 1;   // the queue lanes of depth sd
 #define DRT_LAUNCH_ADJ_VERTEX(SPEC, TAILV)                                                                                  \
     hipLaunchKernelGGL((k_adj_vertex<R, SPEC, TAILV>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, s.d_scene, s.d_params, s.cs, \
-                       s.bvh.tri_shade, s.ra[sd & 1], s.rb[sd & 1], s.rid[sd & 1], s.nv, s.counts + (size_t)sd * s.max_regions, s.bvh, \
-                       s.hit, (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p, (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p)
+                       s.bvh.tri_shade, s.ra[sq], s.rb[sq], s.rid[sq], s.nv, s.counts + (size_t)sd * s.max_regions, s.bvh, \
+                       s.shade_tail ? s.hitr[sq] : s.hit, (uint32_t*)ctx->cand[sd & 1].p, (R4*)ctx->cand_a[sd & 1].p, (R4*)ctx->cand_b[sd & 1].p, (uint32_t*)ctx->cand_count[sd & 1].p)
         if (s.shade_tail) {
             if (ctx->has_specular) DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_VERTEX(true, true));
             else DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_VERTEX(false, true));
@@ -826,7 +866,7 @@ int adjoint_rounds(Shard<R>& s)
         //  the cap ended, the camera paths' and the suffixes', like the one-launch kernel does)
         if (sd < D)
             hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, s.counts + (size_t)sd * s.max_regions,
-                               (uint32_t)((size_t)(D + 1 - sd) * s.max_regions), s.totals, (uint32_t)s.max_regions, sfx_read, sfx_written,
+                               (uint32_t)((size_t)(D + 2 - sd) * s.max_regions), s.totals, (uint32_t)s.max_regions, sfx_read, sfx_written,
                                (uint32_t)(D - sd));
 #define DRT_LAUNCH_ADJ_ACC(NP)                                                                                           \
     hipLaunchKernelGGL((k_adj_accumulate<R, NP>), dim3(gp), dim3(DRT_BLOCK), 0, ctx->stream, a, r, s.d_scene, s.d_params, \
@@ -889,11 +929,11 @@ int queue_batch(Shard<R>& s)
         // (scenes with a mesh: K1 also intersects its rays with the analytic shapes and builds the BVH walk's candidate lists --
         //  hit lane `hit`, the one the bounce loop starts on)
         if (s.shade_tail) {
-            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count.p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[0].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
             DRT_TIMED(s, DRT_K_RAYGEN,
                       hipLaunchKernelGGL((k_raygen<R, true>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, s.d_scene, s.ra[0], s.rb[0],
-                                         s.rid[0], s.nv, s.counts, s.bvh, s.hit, (uint32_t*)ctx->cand.p, (R4*)ctx->cand_a.p,
-                                         (R4*)ctx->cand_b.p, (uint32_t*)ctx->cand_count.p));
+                                         s.rid[0], s.nv, s.counts, s.bvh, s.hit, (uint32_t*)ctx->cand[0].p, (R4*)ctx->cand_a[0].p,
+                                         (R4*)ctx->cand_b[0].p, (uint32_t*)ctx->cand_count[0].p));
         } else
             DRT_TIMED(s, DRT_K_RAYGEN,
                       hipLaunchKernelGGL((k_raygen<R, false>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, s.d_scene, s.ra[0], s.rb[0],
@@ -906,7 +946,7 @@ int queue_batch(Shard<R>& s)
     if ((rc = bounce_loop<R>(s, 0, 0, camera_fused, s.unbiased ? s.cs.cv_a : (R4*)nullptr,
                              s.unbiased ? s.cs.cv_b : (typename Shard<R>::R2*)nullptr, s.unbiased ? s.cs.cv_hit : (HitRec<R>*)nullptr, 0,
                              (const uint32_t*)nullptr, 0, &read_rows, &written_rows)) != DRT_OK) return rc;
-    hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, s.counts, (uint32_t)((size_t)(D + 1) * s.max_regions),
+    hipLaunchKernelGGL(k_sum_counts, dim3(64), dim3(DRT_BLOCK), 0, ctx->stream, s.counts, (uint32_t)((size_t)(D + 2) * s.max_regions),
                        s.totals, (uint32_t)s.max_regions, read_rows, written_rows, (uint32_t)D);
     if (s.backward && D > 0 && s.gimg_param >= 0) {
         // gradient image: per-path gradient of one parameter, averaged per pixel by K5

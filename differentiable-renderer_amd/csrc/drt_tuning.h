@@ -25,6 +25,7 @@ struct Tuning {
     int shade_bounces = 0;         // DRT_HIP_SHADE_BOUNCES    overrides drt_render_params.bounces_per_launch
     // ---- triangle meshes
     int mesh_blocks_per_cu = 0;    // DRT_HIP_MESH_BLOCKS_PER_CU   blocks of the BVH walk's persistent grid per CU; 0 = what the occupancy query says (5)
+    int tail_bounces = 0;          // DRT_HIP_TAIL_BOUNCES         mesh scenes: 2 = a shade launch keeps the rays that miss the mesh bounds in registers through one more vertex, 1 = every ray is queued, 0 = 2 for the unbiased operator's rounds, else 1
     int shade_list_group = 4;      // DRT_HIP_SHADE_LIST_GROUP     region lists the walk pulls at a time
     int bvh_refill = -1;           // DRT_HIP_BVH_REFILL           idle lanes before the walk's waves refill; -1 = DRT_BVH_REFILL (16)
     int bvh_descend_min = -1;      // DRT_HIP_BVH_DESCEND_MIN      lanes that keep the interior-node loop going; -1 = DRT_BVH_DESCEND_MIN (32)
@@ -59,6 +60,8 @@ inline const Tuning& tuning()
         v.shade_bounces = (int)num("DRT_HIP_SHADE_BOUNCES", 0);
         v.mesh_blocks_per_cu = (int)num("DRT_HIP_MESH_BLOCKS_PER_CU", 0);
         v.shade_list_group = (int)num("DRT_HIP_SHADE_LIST_GROUP", 4);
+        v.tail_bounces = (int)num("DRT_HIP_TAIL_BOUNCES", 0);
+        if (v.tail_bounces < 0 || v.tail_bounces > 2) v.tail_bounces = 0;
         v.bvh_refill = (int)num("DRT_HIP_BVH_REFILL", -1);
         v.bvh_descend_min = (int)num("DRT_HIP_BVH_DESCEND_MIN", -1);
         v.mesh_path_max = num("DRT_HIP_MESH_PATH_MAX", 1 << 20);

@@ -2,6 +2,7 @@
 shape): the BVH traversal of K2 against the brute-force oracle, whose triangle semantics are
 pinned by a Triangle plugin running inside the unmodified reference (tests/golden/g9..g11)."""
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -192,3 +193,17 @@ def test_mesh_errors(pkg, hip):
     with pytest.raises(pkg.DrtHipError, match="DRT_ERR_INVALID"):
         hip.upload_scene(scene)
     hip.upload_scene(pkg.cornell_box())          # the context is still usable
+
+
+@pytest.mark.gpu
+def test_two_stage_shade_launches_change_no_bit():
+    """DRT_HIP_TAIL_BOUNCES=2 (a shade launch keeps the rays that miss the bounds of the mesh in registers through one more vertex;
+    the unbiased operator's rounds run that way) against =1: same image, gradients, segment / capped / walked counts on ten
+    renders x f64 and f32 x whole frame, shard, small batches; f64 against the oracle.  The knob is read once per process:
+    tools/tail_check.py renders each setting in a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "tail_check.py"), "parity"], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "parity ok" in out.stdout and out.stdout.count("\nok ") + out.stdout.startswith("ok ") == 60

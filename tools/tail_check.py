@@ -1,0 +1,130 @@
+"""The queue wavefront's shade launches on mesh scenes with their second stage (DRT_HIP_TAIL_BOUNCES=2: rays that miss the bounds of
+the mesh stay in registers through one more vertex) against one vertex per launch (=1): results bit for bit, and the times.
+
+  python tools/tail_check.py parity     a dump per setting (subprocesses), compared byte by byte; f64 against the oracle
+  python tools/tail_check.py time       kernel ms per frame, config 4's share / 512^2 x 64 / per-face albedos / the unbiased operator
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CASES = [("mesh10x12", 24, 24, 3, dict(min_bounces=4, absorb=1.0), False),
+         ("mesh40x40", 48, 48, 4, dict(min_bounces=5, absorb=1.0), False),
+         ("mesh10x12", 29, 28, 3, dict(min_bounces=1, absorb=0.5), False),
+         ("mesh10x12f5", 31, 27, 5, dict(min_bounces=3, absorb=1.0), False),
+         ("mesh40x40", 40, 30, 4, dict(min_bounces=2, absorb=0.3, max_depth=6), False),
+         ("mesh40x40", 70, 66, 40, dict(min_bounces=3, absorb=0.4, max_depth=9), False),
+         ("mesh160x160", 200, 160, 16, dict(min_bounces=8, absorb=1.0), False),
+         ("mesh10x12", 24, 24, 3, dict(min_bounces=4, absorb=1.0), True),
+         ("mesh40x40", 40, 30, 4, dict(min_bounces=2, absorb=0.3, max_depth=6), True),
+         ("mesh10x12f5", 31, 27, 5, dict(min_bounces=3, absorb=0.2), True)]
+
+
+def dump():
+    import numpy as np
+    import __graft_entry__ as e
+    pkg = e.load_package()
+    oracle = e.load_oracle()
+    r = pkg.HipRenderer(0)
+    out = []
+    for name, W, H, spp, kw, unbiased in CASES:
+        scene = pkg.scene_by_name(name)
+        cam = pkg.cornell_camera(W, H)
+        r.upload_scene(scene)
+        for f64 in (True, False):
+            for extra in (dict(), dict(shard=1, n_shards=3, band_rows=5), dict(batch_paths=1000)):
+                rp = pkg.RenderParams(spp=spp, seed=3, bounces_per_launch=1, **kw, **extra)
+                img, grads, st = r.render(cam, rp, backward=True, f64=f64, unbiased=unbiased)
+                # (more than 8 parameters: K6 sums with atomics, the last bit of a gradient depends on their order)
+                exact = scene.n_params <= 8
+                h = hashlib.sha256(img.tobytes() + (grads.tobytes() if exact else b"")).hexdigest()[:16]
+                rec = dict(case=[name, W, H, spp, kw, unbiased, f64, extra], hash=h, grads=grads.tolist(), segments=st["segments"], capped=st["capped_paths"],
+                           walked=st["kernels"]["intersect_mesh"]["units"], shade_launches=st["kernels"]["shade"]["launches"],
+                           walk_launches=st["kernels"]["intersect_mesh"]["launches"])
+                if f64 and not extra and W * H * spp < 30000:
+                    ref = oracle.render(scene, cam, rp, backward=True, unbiased=unbiased)
+                    rec["oracle_segments"] = int(ref["stats"]["segments"])
+                    rec["grad_err"] = float(np.abs(grads - ref["grads"]).max() / np.abs(ref["grads"]).max())
+                out.append(rec)
+    print(json.dumps(out))
+
+
+def parity():
+    res = {}
+    for tb in ("1", "2"):
+        o = subprocess.run([sys.executable, __file__, "dump"], env=dict(os.environ, DRT_HIP_TAIL_BOUNCES=tb, DRT_HIP_MESH_PATH_MAX="0"),
+                           capture_output=True, text=True, timeout=900)
+        if o.returncode != 0:
+            print(o.stderr[-3000:])
+            raise SystemExit(1)
+        res[tb] = json.loads(o.stdout.strip().splitlines()[-1])
+    bad = 0
+    for a, b in zip(res["1"], res["2"]):
+        import numpy as np
+        same = all(a[k] == b[k] for k in ("hash", "segments", "capped", "walked")) and np.allclose(a["grads"], b["grads"], rtol=1e-12, atol=0)
+        ok = same and ("grad_err" not in b or (b["grad_err"] < 1e-9 and b["segments"] == b["oracle_segments"]))
+        bad += not ok
+        print(("ok   " if ok else "FAIL ") + json.dumps(b["case"]) + f"  segments {a['segments']} / {b['segments']}" +
+              (f" / oracle {b['oracle_segments']}  grad err {b['grad_err']:.2e}" if "grad_err" in b else "") +
+              f"  walked {a['walked']} / {b['walked']}  capped {a['capped']} / {b['capped']}  hash {a['hash']} / {b['hash']}", flush=True)
+    print("parity", "ok" if not bad else f"FAILED ({bad})")
+    raise SystemExit(1 if bad else 0)
+
+
+def time_one(which):
+    import time
+    import __graft_entry__ as e
+    pkg = e.load_package()
+    r = pkg.HipRenderer(0, lib_path=os.environ.get("CHECK_LIB"))
+    unbiased = which == "unbiased"
+    share = which in ("share", "perface")
+    scene = "mesh160x160fall" if which == "perface" else "mesh160x160"
+    W, spp = (1024, 256) if share else (512, 64)
+    r.upload_scene(pkg.scene_by_name(scene))
+    cam = pkg.cornell_camera(W, W)
+    rp = pkg.RenderParams(spp=spp, min_bounces=8, absorb=1.0, seed=1, **(dict(shard=0, n_shards=8, band_rows=4) if share else {}))
+    for _ in range(2):
+        r.render(cam, rp, backward=True, unbiased=unbiased)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        r.render(cam, rp, backward=True, unbiased=unbiased)
+    wall = (time.perf_counter() - t0) / 5 * 1e3
+    best = None
+    for _ in range(4):
+        _, _, st = r.render(cam, rp, backward=True, timing=True, unbiased=unbiased)
+        ms = sum(v["ms"] for v in st["kernels"].values())
+        if best is None or ms < best[0]:
+            best = (ms, st)
+    ms, st = best
+    print(json.dumps({"wall_ms": round(wall, 3), "kernels_ms": round(ms, 3), "segments": st["segments"],
+                      "per_kernel": {k: round(v["ms"], 3) for k, v in st["kernels"].items() if v["ms"] > 0},
+                      "walked": st["kernels"]["intersect_mesh"]["units"]}))
+
+
+def time_all():
+    variants = [("one vertex per launch", {"DRT_HIP_TAIL_BOUNCES": "1"}), ("two stages", {"DRT_HIP_TAIL_BOUNCES": "2"})]
+    extra = os.environ.get("CHECK_VARIANTS")
+    if extra:
+        variants = [(v, dict(kv.split("=") for kv in v.split(",") if kv)) for v in extra.split(";")]
+    for which in os.environ.get("CHECK_WHICH", "share,frame,perface,unbiased").split(","):
+        for name, env in variants:
+            out = subprocess.run([sys.executable, __file__, "time_one", which], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-600:]
+            print(f"{which:9s} {name:24s} {line}", flush=True)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "parity"
+    if mode == "dump":
+        dump()
+    elif mode == "parity":
+        parity()
+    elif mode == "time_one":
+        time_one(sys.argv[2])
+    else:
+        time_all()
