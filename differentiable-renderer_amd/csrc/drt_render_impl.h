@@ -181,13 +181,15 @@ struct Shard {
     uint2* rid[3];
     HitRec<R>* hit;
     HitRec<R>* hitr[3];             // shade_tail: the hit lanes of depth d mod tail_ring
+    int cset(int d) const { return tail_ring > 2 ? d & 1 : 0; }   // which set of candidate lists holds depth d (two sets only where launches have two stages)
     TailQueue<R> tailq(int d) const  // shade_tail: what a launch that appends to the queue of depth d gets
     {
         TailQueue<R> q;
         const int m = tail_ring;
         q.a = ra[d % m]; q.b = rb[d % m]; q.id = rid[d % m]; q.hit = hitr[d % m];
-        q.cand = (uint32_t*)ctx->cand[d & 1].p; q.cand_a = (R4*)ctx->cand_a[d & 1].p; q.cand_b = (R4*)ctx->cand_b[d & 1].p;
-        q.cand_count = (uint32_t*)ctx->cand_count[d & 1].p;
+        const int c = cset(d);
+        q.cand = (uint32_t*)ctx->cand[c].p; q.cand_a = (R4*)ctx->cand_a[c].p; q.cand_b = (R4*)ctx->cand_b[c].p;
+        q.cand_count = (uint32_t*)ctx->cand_count[c].p;
         q.count = counts + (size_t)d * max_regions;
         return q;
     }
@@ -317,7 +319,9 @@ void shard_plan(Shard<R>& s)
     uint64_t cap_default;
     {
         const uint64_t f = sizeof(R) / 4;
-        const uint64_t per_path = f * (112u + 8u * (uint64_t)(D > 0 ? D : 1) + (ctx->has_mesh ? 80u : 0u) + (s.unbiased ? (ctx->has_mesh ? 150u : 110u) : 0u)) + 24u;
+        // (mesh scenes: one set of candidate records, 36 B; the unbiased operator's two-stage shade launches: a third set of queue
+        //  and hit lanes and a second set of candidate records, + 76 B)
+        const uint64_t per_path = f * (112u + 8u * (uint64_t)(D > 0 ? D : 1) + (ctx->has_mesh ? 36u : 0u) + (s.unbiased ? (ctx->has_mesh ? 186u : 110u) : 0u)) + 24u;
         const uint64_t budget = std::min<uint64_t>(ctx->device_mem / 8, (uint64_t)32 << 30);
         cap_default = (uint64_t)1 << 22;
         while (cap_default < ((uint64_t)1 << 28) && 2 * cap_default * per_path <= budget)
@@ -423,7 +427,7 @@ int shard_buffers(Shard<R>& s)
             if ((rc = ensure(ctx, ctx->hit2, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
             if (s.tail_ring > 2)
                 if ((rc = ensure(ctx, ctx->hit3, N * sizeof(HitRec<R>))) != DRT_OK) return rc;
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < (s.tail_ring > 2 ? 2 : 1); ++i) {
                 if ((rc = ensure(ctx, ctx->cand[i], cand_words * sizeof(uint32_t))) != DRT_OK) return rc;
                 if ((rc = ensure(ctx, ctx->cand_a[i], cand_words * sizeof(R4))) != DRT_OK) return rc;
                 if ((rc = ensure(ctx, ctx->cand_b[i], cand_words * sizeof(R4))) != DRT_OK) return rc;
@@ -756,8 +760,8 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
             const uint32_t walk_group = (uint32_t)tuning().shade_list_group;
             DRT_TIMED(s, DRT_K_INTERSECT_MESH,
                       hipLaunchKernelGGL(k_intersect_mesh<R>, dim3(gm), dim3(DRT_BLOCK), 0, ctx->stream, a, s.d_scene, s.bvh, hit_k,
-                                         (const uint32_t*)ctx->cand[k & 1].p, (const R4*)ctx->cand_a[k & 1].p, (const R4*)ctx->cand_b[k & 1].p,
-                                         (uint32_t*)ctx->cand_count[k & 1].p, s.region_size, a.n_regions, walk_group,
+                                         (const uint32_t*)ctx->cand[s.cset(k)].p, (const R4*)ctx->cand_a[s.cset(k)].p, (const R4*)ctx->cand_b[s.cset(k)].p,
+                                         (uint32_t*)ctx->cand_count[s.cset(k)].p, s.region_size, a.n_regions, walk_group,
                                          coprime_multiplier((a.n_regions + walk_group - 1) / walk_group), s.totals));
         }
         TapeRec<R>* tape_k = s.tape + (size_t)k * a.n_paths;
@@ -768,9 +772,9 @@ int bounce_loop(Shard<R>& s, int first, int parity0, bool camera_fused, typename
         const int tail_nb = tail_here ? s.tail_nb : 1;
         if (tail_here) {     // (the region lists of regions no wave visits stay empty)
             if (tail_nb == 1 || lc == 0)
-                HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[(k + 1) & 1].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[s.cset(k + 1)].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
             if (tail_nb > 1)
-                HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[k & 1].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[s.cset(k)].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
         }
         const TailQueue<R> tq0 = s.tailq(k + 1), tq1 = s.tailq(k + 2);
         uint32_t* cont_row = s.counts + (size_t)(D + 1) * s.max_regions;
@@ -834,12 +838,12 @@ int adjoint_rounds(Shard<R>& s)
         // (scenes with a mesh: the kernel also intersects the rays it queues with the analytic shapes and builds the BVH walk's
         //  candidate lists -- hit lane `hit`, the one the suffix loop starts on.  Timed with the backward pass.)
         if (s.shade_tail)
-            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[sd & 1].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->cand_count[s.cset(sd)].p, 0, (size_t)a.n_regions * sizeof(uint32_t), ctx->stream));
         const int sq = s.shade_tail ? sd % s.tail_ring : sd & 1;   // the queue lanes of depth sd
 #define DRT_LAUNCH_ADJ_VERTEX(SPEC, TAILV)                                                                                  \
     hipLaunchKernelGGL((k_adj_vertex<R, SPEC, TAILV>), dim3(g), dim3(DRT_BLOCK), 0, ctx->stream, a, r, s.d_scene, s.d_params, s.cs, \
                        s.bvh.tri_shade, s.ra[sq], s.rb[sq], s.rid[sq], s.nv, s.counts + (size_t)sd * s.max_regions, s.bvh, \
-                       s.shade_tail ? s.hitr[sq] : s.hit, (uint32_t*)ctx->cand[sd & 1].p, (R4*)ctx->cand_a[sd & 1].p, (R4*)ctx->cand_b[sd & 1].p, (uint32_t*)ctx->cand_count[sd & 1].p)
+                       s.shade_tail ? s.hitr[sq] : s.hit, (uint32_t*)ctx->cand[s.cset(sd)].p, (R4*)ctx->cand_a[s.cset(sd)].p, (R4*)ctx->cand_b[s.cset(sd)].p, (uint32_t*)ctx->cand_count[s.cset(sd)].p)
         if (s.shade_tail) {
             if (ctx->has_specular) DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_VERTEX(true, true));
             else DRT_TIMED(s, DRT_K_BACKWARD, DRT_LAUNCH_ADJ_VERTEX(false, true));
