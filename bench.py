@@ -513,7 +513,9 @@ def main():
     #  needs none, is what the top level carries then)
     top = valu_view if (issue_bound and valu_view) else hbm_view
     roofline = {"bound": ("valu-issue (paths are register-resident: the kernel moves almost no bytes)" if register_resident
-                          else ("latency (divergent BVH walk out of L2): far from both the HBM and the vector-issue roof" if dominant == "intersect_mesh" else "hbm")),
+                          else ("valu-issue at partial lanes (divergent BVH walk out of L2: 37 of 64 lanes per vector instruction, the vector pipes 75 % busy by "
+                                "SQ_ACTIVE_INST_VALU, 0.37 of the nominal issue rate by instruction count -- profiles/r05_walk_counters.txt; "
+                                "far from the HBM roof)" if dominant == "intersect_mesh" else "hbm")),
                 "kernel": "k_" + dominant, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                 "frac": top["frac"],
                 "traffic": traffic,
