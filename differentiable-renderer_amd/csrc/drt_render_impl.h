@@ -375,7 +375,10 @@ void shard_plan(Shard<R>& s)
     s.shade_tail = ctx->has_mesh;
     // two-stage shade launches (measured, same process, alternating): config 4's share 5.90 -> 6.15 ms of shade launches (20 % fewer
     // bytes, 18 % more instructions, the second stage at two lanes in three), the unbiased operator's rounds 14.05 -> 13.25: on for those
-    s.tail_nb = s.shade_tail && (tuning().tail_bounces > 1 || (tuning().tail_bounces == 0 && s.unbiased)) ? 2 : 1;
+    // (this knob alone is read at every render: the two settings differ by a few per cent, less than one process differs from the
+    //  next on a box that warms up -- tools/tail_check.py alternates them inside one process)
+    const int tail_bounces = tail_bounces_now();
+    s.tail_nb = s.shade_tail && (tail_bounces > 1 || (tail_bounces == 0 && s.unbiased)) ? 2 : 1;
     s.tail_ring = s.tail_nb > 1 ? 3 : 2;
     s.overlap_ok = ctx->overlap_next && s.use_path && !s.timing && s.gimg_param < 0 && ctx->path_stream[0] && ctx->ev_copied[0];
     const bool odd = s.overlap_ok && (ctx->slot & 1);

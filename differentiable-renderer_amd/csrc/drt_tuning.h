@@ -82,4 +82,13 @@ inline const Tuning& tuning()
     return t;
 }
 
+// DRT_HIP_TAIL_BOUNCES as it stands NOW: the one knob read at every render (the two settings differ by a few per cent, less than
+// one process differs from the next on a box that warms up: tools/tail_check.py alternates them inside one process)
+inline int tail_bounces_now()
+{
+    if (const char* e = getenv("DRT_HIP_TAIL_BOUNCES"))
+        return ((e[0] == '1' || e[0] == '2') && !e[1]) ? e[0] - '0' : 0;
+    return tuning().tail_bounces;
+}
+
 } // namespace

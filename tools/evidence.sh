@@ -55,6 +55,7 @@ python3 tools/sync_call.py 2>&1 | grep -v amdgpu > "$E/sync_call.txt"
 python3 tools/mesh_path_check.py small 2>&1 | grep -v amdgpu > "$E/mesh_small_frames.txt"
 python3 tools/mesh_path_check.py parity 2>&1 | grep -v amdgpu > "$E/mesh_path_parity.txt"
 python3 tools/roulette_sweep.py 2>&1 | grep -v amdgpu > "$E/roulette_sweep.txt"
+python3 tools/tail_check.py time 2>&1 | grep -v amdgpu > "$E/two_stage_shade_times.txt"
 python3 bench.py --config 4 --per-face > "$E/bench_config4_per_face.json" 2>> "$E/bench.err"
 python3 bench.py --single-process --gpus 2 --same-gpu 2>> "$E/bench.err" | grep "^{" > "$E/bench_group_2members_same_gpu_plumbing.json"
 (timeout 300 python3 tools/allreduce_overlap.py; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager --context-between) 2>&1 | grep "ms per frame\|initialised" > "$E/launch_order.txt"

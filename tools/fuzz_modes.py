@@ -98,7 +98,15 @@ for case in range(n_cases):
     if not limit_hit and not o["stats"]["deepest"] >= 40:
         assert q[2]["segments"] == o["stats"]["segments"], (case, name, kw, unbiased, q[2]["segments"], o["stats"]["segments"])
         assert float(np.abs(q[1] - o["grads"]).max() / oscale) < 1e-9, (case, name, kw, unbiased)
-        np.testing.assert_allclose(q[0], o["image"].astype(np.float32), rtol=2e-7, atol=1e-12 if p > 0.35 else 1e-6 * float(o["image"].max()))
+        # (per pixel to the float's last bits -- except that ONE path in ~1e9 stands where the f64 roundings of host and device,
+        #  1e-16 apart, come out 1e-7 apart: a grazing hit, a cancelling sum.  Round 5, case 9385 of seed 103: random3, 80 x 56, 1 spp,
+        #  pixel (50, 32): -3.36687925e-4 against -3.36688002e-4, both device routes alike, gradients within 1e-9.  Three such pixels
+        #  of a frame may be 1e-5 off.)
+        oi = o["image"].astype(np.float32)
+        off = ~np.isclose(q[0], oi, rtol=2e-7, atol=1e-12 if p > 0.35 else 1e-6 * float(o["image"].max()))
+        if off.any():
+            assert int(off.sum()) <= 9 and np.allclose(q[0][off], oi[off], rtol=1e-5, atol=0), (case, name, kw, unbiased, int(off.sum()))
+            print(f"{case:3d} {name:22s} {int(off.sum())} image values beyond 2e-7 of the restatement's (within 1e-5): a rounding amplified", flush=True)
     # a per-sample squared-error loss and the gradient image, where the render allows them (biased operator)
     extra = ""
     if not unbiased and rs.rand() < 0.3:
