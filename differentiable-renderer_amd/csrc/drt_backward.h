@@ -19,6 +19,12 @@
 // Parameter ids < DRT_FAST_PARAMS accumulate in registers (compare-select, no atomics, fixed
 // order => bitwise reproducible); other ids use fp64 atomics on the gradient vector.
 #define DRT_TAPE_CHUNK 8
+// (the general accumulator -- any number of parameters, a wave adds at once: GradAcc<R, 0> -- walks chunks of 4: its adds hold
+//  ~60 registers of their own, and at 8 vertices per chunk the kernel runs two waves per SIMD instead of three: config 4 with an
+//  albedo per face 3.13 -> 3.01 ms; the register accumulators lose 20 % at 4: their kernel stays at 8)
+#ifndef DRT_TAPE_CHUNK_WAVE
+#define DRT_TAPE_CHUNK_WAVE 4
+#endif
 
 // Gradient accumulators of one thread.
 //   NP = 4 or 8 (the scene has at most NP parameters): NP x 3 registers, conditional adds with a
@@ -238,6 +244,7 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
                                      R inv_p_rr, Acc& acc, R (*acc_lds)[DRT_BLOCK], double* __restrict__ grad,
                                      const TapeRec<R>* first_chunk = nullptr)
 {
+    constexpr int CH = Acc::kWave ? DRT_TAPE_CHUNK_WAVE : DRT_TAPE_CHUNK;      // vertices per chunk
     V3<R> Ln = mk<R>(R(0), R(0), R(0));
     // (an accumulator that adds a whole wave at a time -- Acc::kWave, the general one -- is called by ALL lanes at every step:
     //  the chunk loop then runs to the longest path of the wave, each lane under its own `k < K`, and a lane without a
@@ -250,7 +257,7 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
             Kw = o2 > Kw ? o2 : Kw;
         }
     }
-    for (int c0 = ((Kw - 1) / DRT_TAPE_CHUNK) * DRT_TAPE_CHUNK; c0 >= 0; c0 -= DRT_TAPE_CHUNK) {
+    for (int c0 = ((Kw - 1) / CH) * CH; c0 >= 0; c0 -= CH) {
         // prefix throughput at the start of this chunk (only for paths longer than a chunk)
         V3<R> T = mk<R>(R(1), R(1), R(1));
         // (a lane whose path ends before this chunk has nothing to rebuild -- and its LAST vertex may carry no colour id)
@@ -258,22 +265,22 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
             const TapeRec<R> tr = tape[(size_t)j * N + i];
             T = T * load_param<R, SMALL>(lds, params, (int)(tr.ids & 0xFFFFu)) * tr.m;
         }
-        R Tx[DRT_TAPE_CHUNK], Ty[DRT_TAPE_CHUNK], Tz[DRT_TAPE_CHUNK], M[DRT_TAPE_CHUNK];
-        uint32_t ID[DRT_TAPE_CHUNK];
-        TapeRec<R> trs[DRT_TAPE_CHUNK];
+        R Tx[CH], Ty[CH], Tz[CH], M[CH];
+        uint32_t ID[CH];
+        TapeRec<R> trs[CH];
         if (first_chunk && c0 == 0) {
-            // vertices 0..7 were requested together with the path's vertex count (k_backward)
+            // vertices 0 .. CH - 1 were requested together with the path's vertex count (k_backward)
 #pragma unroll
-            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+            for (int j = 0; j < CH; ++j)
                 trs[j] = first_chunk[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+            for (int j = 0; j < CH; ++j)
                 if (c0 + j < K)
                     trs[j] = tape[(size_t)(c0 + j) * N + i];   // independent loads, all in flight
         }
 #pragma unroll
-        for (int j = 0; j < DRT_TAPE_CHUNK; ++j) {
+        for (int j = 0; j < CH; ++j) {
             if (c0 + j < K) {
                 ID[j] = trs[j].ids;
                 M[j] = trs[j].m;
@@ -284,7 +291,7 @@ __device__ inline V3<R> backward_path(const BatchArgs& a, const SceneLds<R>& lds
             }
         }
 #pragma unroll
-        for (int j = DRT_TAPE_CHUNK - 1; j >= 0; --j) {
+        for (int j = CH - 1; j >= 0; --j) {
             const int k = c0 + j;
             uint32_t ide = DRT_ID_NONE, idc = DRT_ID_NONE;
             V3<R> ve = mk<R>(R(0), R(0), R(0)), vc = ve;
@@ -368,9 +375,10 @@ k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
         // to memory per path instead of two (records beyond the path's end are read and ignored; the
         // rows exist for every depth below the cap).
         const int K = valid ? (int)nv[i] : 0;
-        TapeRec<R> first[DRT_TAPE_CHUNK];
+        constexpr int CH = GradAcc<R, NP>::kWave ? DRT_TAPE_CHUNK_WAVE : DRT_TAPE_CHUNK;
+        TapeRec<R> first[CH];
 #pragma unroll
-        for (int j = 0; j < DRT_TAPE_CHUNK; ++j)
+        for (int j = 0; j < CH; ++j)
             if (j < a.depth_cap)
                 first[j] = tape[(size_t)j * N + i];
         V3<R> L0 = mk<R>(R(0), R(0), R(0));
