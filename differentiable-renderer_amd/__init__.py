@@ -245,7 +245,7 @@ class Scene:
 
 
 def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front_mirror: bool = False,
-                mirror_wall: bool = False, per_wall: bool = False) -> Scene:
+                mirror_wall: bool = False, per_wall: bool = False, per_shape: bool = False) -> Scene:
     """The hard-coded scene of /root/reference/src/render.cpp:26-59 (same order, same values).
 
     front_specular: sphere_front uses SpecularBxDF(white, 30) (render.cpp:35 creates it, the
@@ -255,7 +255,10 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front
     front_mirror / mirror_wall: sphere_front / the back plane use MirrorBxDF (unit normals only: a
     mirror off the non-unit right wall would hand the spheres a non-unit direction).
     per_wall: the back, front, ground and ceiling planes get albedo parameters of their own (8 parameters in all: what
-    an inverse-rendering loop over "every wall's colour" optimises)."""
+    an inverse-rendering loop over "every wall's colour" optimises).
+    per_shape: EVERY shape with a BxDF gets an albedo of its own: the two spheres and the four white planes take new parameters,
+    red / green keep the side walls, `white` stays declared as render.cpp:28 declares it and is no shape's colour any more --
+    10 parameters, the smallest scene past the eight the register form of the one-launch kernels covers."""
     s = Scene()
     red = s.parameter((0.5, 0, 0), True, "red")                 # render.cpp:26
     green = s.parameter((0, 0.5, 0), True, "green")             # :27
@@ -284,7 +287,56 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front
                                                      ("ground", (0.5, 0.55, 0.45)), ("ceiling", (0.45, 0.5, 0.55)))):
             t, _, e, p4 = s.shapes[shape]
             s.shapes[shape] = (t, s.diffuse(s.parameter(col, True, name)), e, p4)
+    if per_shape:
+        for shape, (name, col) in zip((0, 1, 4, 5, 6, 7), (("sphere_front", (0.55, 0.5, 0.45)), ("sphere_back", (0.45, 0.5, 0.6)),
+                                                           ("back", (0.6, 0.5, 0.4)), ("front", (0.4, 0.4, 0.5)),
+                                                           ("ground", (0.5, 0.55, 0.45)), ("ceiling", (0.45, 0.5, 0.55)))):
+            t, m, e, p4 = s.shapes[shape]
+            ty, _, ex = s.materials[m]
+            s.materials.append((ty, s.parameter(col, True, name), ex))
+            s.shapes[shape] = (t, len(s.materials) - 1, e, p4)
     s.sphere((0., 3., 3.), 1., -1, emitter)                     # :47 light (no BxDF)
+    return s
+
+
+def many_param_scene(n_params: int, n_geometry: int = 0, seed: int = 77, zero_channels: bool = True) -> Scene:
+    """A closed box of six walls and small spheres, every shape a diffuse albedo parameter: `n_params` parameters in all
+    (two emissions, n_params - 2 albedos handed to the shapes round-robin).  The GEOMETRY is that of the scene with
+    `n_geometry` parameters (default: n_params, at most 64) -- `many_param_scene(4, 64)` is the 64-parameter scene's room with three
+    albedos and one light colour: what the parameter count alone costs.  A few albedos have zero channels (like the
+    reference's red and green, render.cpp:26-27).  Test / bench input, deterministic in `seed`."""
+    n_geometry = n_geometry or min(n_params, 64)
+    assert 3 <= n_params <= 126 and min(n_params, 64) <= n_geometry <= 64
+    rng = np.random.RandomState(seed)
+    s = Scene()
+    # (at most 64 materials and 63 shapes: beyond 64 parameters the extra ones are emissions of their own for the spheres)
+    n_em = (2 if n_params >= 6 else 1) if n_params <= 64 else n_params - 62
+    n_alb = n_params - n_em
+    mats = []
+    for i in range(n_alb):
+        col = rng.uniform(0.25, 0.85, 3)
+        if zero_channels and i % 7 == 3:
+            col[rng.randint(3)] = 0.0
+        mats.append(s.diffuse(s.parameter(col, True, f"albedo{i}")))
+    dim = 1.0 if n_em <= 2 else 0.08
+    lights = [s.area_emitter(s.parameter(rng.uniform(0.8, 3.0, 3) * (dim if i + 1 < n_em else 1.0), True, f"emission{i}")) for i in range(n_em)]
+    n_bxdf_shapes = n_geometry - (2 if n_geometry >= 6 else 1)
+    k = 0
+    def mat():
+        nonlocal k
+        k += 1
+        return mats[(k - 1) % n_alb]
+    s.plane((-1., 0., 0.), -3., mat())
+    s.plane((1., 0., 0.1), -3., mat())            # (not unit, like render.cpp:42)
+    s.plane((0., 0., -1.), -6., mat())
+    s.plane((0., 0., 1.), 0., mat())
+    s.plane((0., 1., 0.), -3., mat())
+    s.plane((0., -1., 0.), -3., mat())
+    geo = np.random.RandomState(seed + 1)         # (the geometry's own stream: the same room whatever n_params)
+    for i in range(max(0, n_bxdf_shapes - 6)):
+        c = (geo.uniform(-2.4, 2.4), geo.uniform(-2.4, 1.6), geo.uniform(1.5, 5.4))
+        s.sphere(c, geo.uniform(0.15, 0.45), mat(), lights[i] if i < n_em - 1 else -1)
+    s.sphere((0., 3., 3.), 1., -1, lights[-1])
     return s
 
 
@@ -388,6 +440,11 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box(front_specular=True)
     if name == "cornell_walls":
         return cornell_box(per_wall=True)
+    if name == "cornell_shapes":
+        return cornell_box(per_shape=True)
+    if name.startswith("params"):        # params<n>[of<m>]: n parameters in the room of the m-parameter scene
+        n, _, m = name[len("params"):].partition("of")
+        return many_param_scene(int(n), int(m) if m else 0)
     if name == "cornell_emissive_wall":
         return cornell_box(emissive_wall=True)
     if name == "cornell_mirror":

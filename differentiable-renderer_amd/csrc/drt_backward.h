@@ -489,15 +489,23 @@ k_backward_image(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __res
 // ---- K7 ---------------------------------------------------------------------------------------
 // grad[p] += sum over blocks of gpart[block][p] in a fixed order (deterministic); one block per row p
 __global__ void __launch_bounds__(DRT_BLOCK)
-k_gradreduce(const double* __restrict__ gpart, int n_blocks, int n_rows, double* __restrict__ grad, int row_stride)
+k_gradreduce(const double* __restrict__ gpart, int n_blocks, int n_rows, double* __restrict__ grad, int row_stride,
+             const unsigned short* __restrict__ slot_map = nullptr)
 {
+    // (slot_map, the one-launch kernels' general form: gpart's rows are table rows -- word p of the gradient vector, channel
+    //  p % 3 of parameter p / 3, comes from row slot_map[p / 3] * 3 + p % 3, or from nowhere)
     __shared__ double red[DRT_BLOCK];
     const int p = blockIdx.x;
-    if (p >= n_rows)
+    int src = p;
+    if (slot_map) {
+        const int slot = slot_map[p / 3];
+        src = slot == (int)DRT_SLOT_NONE ? n_rows : slot * 3 + p % 3;
+    }
+    if (src >= n_rows)
         return;
     double v = 0;
     for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
-        v += gpart[(size_t)b * row_stride + p];
+        v += gpart[(size_t)b * row_stride + src];
     red[threadIdx.x] = v;
     __syncthreads();
     for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {

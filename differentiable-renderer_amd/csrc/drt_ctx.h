@@ -70,6 +70,7 @@ struct drt_hip_ctx {
     double jit_ms = 0;                    // compile + load time spent by this context
     int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)
     int n_user_params = 0;            // what the caller uploaded and gets gradients for
+    int n_grad_slots = 0;             // how many of the first DRT_PATH_LDS_PARAMS parameters require a gradient (DevScene::grad_slot)
     std::vector<uint8_t> requires_grad;
     std::vector<drt_material_desc> materials;
     DevScene<float>* d_scene_f = nullptr;
@@ -96,9 +97,14 @@ struct drt_hip_ctx {
     // stream of its own, waits for it before it writes the lane again.
     hipEvent_t ev_lane_free[2] = {nullptr, nullptr};
     bool lane_used[2] = {false, false};
+    // drt_hip_update_params installs the new values with a launch on the context's stream and returns: ev_params marks the end of
+    // that launch, params_pending[lane] says that lane's stream has not waited for it yet
+    hipEvent_t ev_params = nullptr;
+    bool params_pending[2] = {false, false};
     bool overlap_next = false;            // set around render_launch by the callers whose renders do not wait
     bool slot_used[DRT_HIP_FRAMES_IN_FLIGHT] = {};   // ev_copied[slot] has been recorded (the slot's buffers have a previous user)
     DevBuf fpart2, gpart2, counts2;       // k_path's partial sums of the odd frames
+    DevBuf hist_ovf[2];                   // the one-launch kernels' general form: vertex-history words beyond the ones in LDS, one area per k_path stream
     DevBuf mesh_ovf[2];                   // k_path_mesh: traversal-stack entries beyond the ones in LDS, one area per k_path stream
     // (scenes with a mesh: three sets of queue lanes and hit lanes -- a shade launch reads depth k and appends to k + 1 and k + 2 --
     //  and two sets of candidate lists, by the parity of their depth)
@@ -127,6 +133,7 @@ struct drt_hip_ctx {
     const void* adj_src_dev = nullptr;    // ... as the device addresses it; render_impl either hands this to the kernels or copies it
     size_t adj_bytes = 0;
     bool adj_pending = false;
+    bool stage_adjoint_next = false;      // set around the render_launch of an asynchronous host-buffer frame: its adjoint image is copied before the call returns, pinned by the caller or not
     bool zero_copy_next = false;          // set around the render_launch of a host-buffer render whose finishing kernels store the image into the pinned block
     struct PinnedRange { uint8_t* host; size_t bytes; uint8_t* dev; };
     std::vector<PinnedRange> pinned;      // drt_hip_pin_host: caller buffers the finishing kernels may write directly

@@ -18,6 +18,8 @@
 #define DRT_MAX_EMITTERS 64
 #define DRT_LDS_PARAMS 256       // parameters staged in LDS by K3/K6 (more: read from L2)
 #define DRT_FAST_PARAMS 8        // parameter ids accumulated in registers by K6
+#define DRT_PATH_LDS_PARAMS 136  // parameters the one-launch kernels stage in LDS: every analytic scene's (<= 64 materials + 64 emitters + the mirrors' constant)
+#define DRT_SLOT_NONE 0xFFFFu    // DevScene::grad_slot of a parameter nobody wants a gradient for
 #define DRT_ID_NONE 0xFFFFu
 #define DRT_BLOCK 256
 #define DRT_WAVE 64
@@ -64,6 +66,10 @@ struct DevScene {
     DevShape<R> shapes[DRT_MAX_SHAPES];
     DevMaterial<R> materials[DRT_MAX_MATERIALS];
     int emitter_param[DRT_MAX_EMITTERS];
+    // the one-launch kernels' gradient tables (drt_path.h, NP = DRT_NP_ANY) have a row per parameter that REQUIRES a gradient
+    // (Vector<T,3,true>(value, requires_grad), vector.hpp:228-234): grad_slot[p] = its row, DRT_SLOT_NONE = none
+    int n_grad_slots;
+    unsigned short grad_slot[DRT_PATH_LDS_PARAMS];
 };
 
 // ---- 16-byte (f32) / 32-byte (f64) queue lanes ----------------------------------------------

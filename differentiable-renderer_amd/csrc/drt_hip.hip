@@ -95,6 +95,8 @@ int drt_hip_create(int device_id, drt_hip_ctx** out)
         for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&ctx->ev_lane_free[i], hipEventDisableTiming) != hipSuccess)
                 ctx->ev_lane_free[i] = nullptr;
+        if (hipEventCreateWithFlags(&ctx->ev_params, hipEventDisableTiming) != hipSuccess)
+            ctx->ev_params = nullptr;
     }
     {   // the BVH walk is a persistent kernel whose waves own strided streams of rays: its grid must be exactly what
         // is resident at once (more blocks would run as a second round behind the first, at half the occupancy)
@@ -128,7 +130,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         (void)ncclCommDestroy(ctx->comm);
     if (ctx->ev_done)
         (void)hipEventDestroy(ctx->ev_done);
-    DevBuf* bufs[] = {&ctx->mesh_ovf[0], &ctx->mesh_ovf[1], &ctx->fpart2, &ctx->gpart2, &ctx->counts2, &ctx->fpart, &ctx->gpix, &ctx->cand[0], &ctx->cand[1], &ctx->cand_a[0], &ctx->cand_a[1], &ctx->cand_b[0], &ctx->cand_b[1], &ctx->cand_count[0], &ctx->cand_count[1], &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_a[2], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_b[2], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->ray_id[2], &ctx->hit, &ctx->hit2, &ctx->hit3, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
+    DevBuf* bufs[] = {&ctx->hist_ovf[0], &ctx->hist_ovf[1], &ctx->mesh_ovf[0], &ctx->mesh_ovf[1], &ctx->fpart2, &ctx->gpart2, &ctx->counts2, &ctx->fpart, &ctx->gpix, &ctx->cand[0], &ctx->cand[1], &ctx->cand_a[0], &ctx->cand_a[1], &ctx->cand_b[0], &ctx->cand_b[1], &ctx->cand_count[0], &ctx->cand_count[1], &ctx->ray_a[0], &ctx->ray_a[1], &ctx->ray_a[2], &ctx->ray_b[0], &ctx->ray_b[1], &ctx->ray_b[2], &ctx->ray_id[0], &ctx->ray_id[1], &ctx->ray_id[2], &ctx->hit, &ctx->hit2, &ctx->hit3, &ctx->lacc, &ctx->gpath, &ctx->gfilm, &ctx->gimg_out, &ctx->tape, &ctx->nv,
                       &ctx->ch_cva, &ctx->ch_cvb, &ctx->ch_cvh, &ctx->ch_nxa, &ctx->ch_nxb, &ctx->ch_nxh, &ctx->ch_g,
                       &ctx->ch_w, &ctx->ch_ids, &ctx->ch_ndraw, &ctx->ch_dbase, &ctx->counts, &ctx->film, &ctx->gpart, &ctx->adjoint};
     for (DevBuf* b : bufs)
@@ -166,6 +168,7 @@ void drt_hip_destroy(drt_hip_ctx* ctx)
         if (ctx->ev_path[i]) (void)hipEventDestroy(ctx->ev_path[i]);
         if (ctx->ev_lane_free[i]) (void)hipEventDestroy(ctx->ev_lane_free[i]);
     }
+    if (ctx->ev_params) (void)hipEventDestroy(ctx->ev_params);
     release(ctx->probe);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
@@ -284,7 +287,9 @@ int drt_hip_render_async(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
     // (the k_path grids of consecutive frames overlap -- render_impl: path_stream --: frame t shares its stream and its set of
     //  partial sums with frame t - 2, whose finishing launch, on the context's stream, must have read them)
     ctx->overlap_next = two_streams && !(rp && (rp->flags & DRT_RENDER_SERIAL));
+    ctx->stage_adjoint_next = true;
     int rc = render_launch(ctx, cam, rp, adjoint_rgb, out_rgb, out_param_grad, &sink, -1, nullptr);
+    ctx->stage_adjoint_next = false;
     ctx->zero_copy_next = false;
     ctx->overlap_next = false;
     if (rc != DRT_OK)

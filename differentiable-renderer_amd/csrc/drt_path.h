@@ -50,6 +50,8 @@ struct PathArgs {
     uint32_t regen_min;             // regenerating form: idle lanes it takes to run the camera code (see k_path)
     uint32_t shade_min, descend_min;   // k_path_mesh (drt_path_mesh.h): lanes it takes to run the vertex step / to keep the node loop going
     int32_t gimg_param;             // >= 0: the lanes' gradient sums of this parameter also leave per pixel (gradient image)
+    uint32_t gen_rows, gen_clog2;   // NP = DRT_NP_ANY: rows of the gradient tables (3 per parameter that requires a gradient), log2 of the copies a wave keeps of each
+    uint32_t hist_lds, hist_stride; // ... full history words a thread keeps in LDS (the rest: global memory), threads of the grid
     double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
     // camera
     double eye[3], fwd[3], right[3], up[3];
@@ -92,7 +94,7 @@ __device__ inline HitRec<double> path_closest_hit(const DevScene<double>* __rest
 #define DRT_NSIG_CORNELL 9
 typedef KindSig<DRT_SIG_CORNELL, 0ull, 0ull, 0ull, DRT_NSIG_CORNELL> SigCornell;
 
-#define DRT_PATH_LDS_PARAMS 136      // parameters staged in LDS: every analytic scene's (<= 64 materials + 64 emitters + the mirrors' constant); more: read from L2
+// (DRT_PATH_LDS_PARAMS, drt_device.h: parameters staged in LDS; more: read from L2)
 
 // the part of the scene a vertex of the one-launch kernels needs, compact (SceneLds carries the whole DevScene and 256
 // parameters: 10.4 KB; this is 5.2 KB in f32 -- a block per CU more for the regenerating k_path)
@@ -208,6 +210,186 @@ struct Tangents {
     __device__ inline void new_path() { cnt[0] = 0; if (NC > 4) cnt[NC > 4 ? 1 : 0] = 0; zc = 0; }
 };
 
+// ---- ANY number of parameters (NP = DRT_NP_ANY) -------------------------------------------------------------------------
+// The reference differentiates with respect to every Vector<T,3,true> of the scene, however many (vector.hpp:185-191;
+// render.cpp:26-29 has four because its scene is small).  Counters and an LDS column per parameter (above) stop at eight.
+// The general form keeps the same closed form -- dT/dc_p = T n_p / c_p, i.e. every vertex j that scattered on a colour adds
+// g T E / (p_k c_{id_j}) to the row of ITS colour once the path meets a light -- and remembers WHICH colour every vertex
+// scattered on instead of counting per colour:
+//   history   8 bits per vertex (parameter ids < DRT_PATH_LDS_PARAMS = 136; 0xFF = no vertex): the last <= 4 in a register,
+//             full words in an LDS column of the thread (dynamic shared memory: as many words as fit without costing the
+//             kernel a block per CU -- four in the lockstep kernel: paths of 16 vertices; none in the regenerating ones),
+//             deeper ones in a column of global memory (written once per four vertices, read where the path meets a light);
+//   tables    per WAVE, in LDS: a row per channel of every parameter that requires a gradient (DevScene::grad_slot), in
+//             2^clog2 copies (lane & (copies - 1): same-address atomics serialise), added to with ds_add -- one wave's adds
+//             reach its own table in program order, so the sums do not depend on how the waves of the chip were scheduled;
+//   per id    GenLds: the colour with zero channels replaced by 1 + its zero-count increments, 1 / c + row and zero-channel bits
+//             (one ds_read_b128 each).
+// A zero channel (red = (0.5, 0, 0), render.cpp:26): vertex j's own factor is the only zero of the channel iff zc_ch == 1, and
+// then d/dc of that channel is T_ch (the product WITHOUT the zero factor, which is what the lane's T holds) -- else 0.
+#define DRT_NP_ANY (-1)
+#ifndef DRT_GEN_TABLE
+#define DRT_GEN_TABLE 408            // elements of a wave's gradient table (rows x copies; 408 = 3 x DRT_PATH_LDS_PARAMS: one copy of every row at least)
+#endif
+template <bool B, typename X, typename Y> struct PickT { typedef X T; };
+template <typename X, typename Y> struct PickT<false, X, Y> { typedef Y T; };
+struct NoLds { int unused; };
+// The tables are fp64 in the f32 kernels too (ds_add_f64): a table sums what 64 lanes x their samples add, and ONE heavy sample
+// (the unbiased operator's L' g / pdf; a roulette-boosted path) in an f32 sum costs every later add its low bits -- measured
+// with f32 tables: 3.4e-3 of the largest component on the 12-parameter unbiased fixture, where per-lane f32 sums give 3e-6.
+template <typename R> struct GenAcc { typedef double T; };
+#ifdef DRT_GEN_F32
+template <> struct GenAcc<float> { typedef float T; };
+#endif
+
+template <typename R>
+struct GenLds {
+    R colnz[DRT_PATH_LDS_PARAMS][4];   // colour, zero channels replaced by 1 | [3]: zero-count increments, 8 bits per channel (pid_pack)
+    R invc[DRT_PATH_LDS_PARAMS][4];    // 1 / c per channel, 0 where the channel is zero | [3]: table row | zero-channel bits << 16 (pid_pack)
+};
+
+template <typename R, typename SL>
+__device__ inline void stage_gen(GenLds<R>& gl, const SL& lds, const DevScene<R>* __restrict__ sc)
+{
+    // (after stage_path_scene's barrier; ids beyond the scene's own read as (1, 1, 1) without a row)
+    for (int p = threadIdx.x; p < DRT_PATH_LDS_PARAMS; p += blockDim.x) {
+        const bool in = p < lds.sc.n_params;
+        uint32_t zinc = 0, zbits = 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const R c = in ? lds.params[p * 3 + ch] : R(1);
+            const bool zero = abs_r(c) < R(1e-18);
+            gl.colnz[p][ch] = zero ? R(1) : c;
+            gl.invc[p][ch] = zero ? R(0) : R(1) / c;
+            zinc |= zero ? 1u << (8 * ch) : 0u;
+            zbits |= zero ? 1u << ch : 0u;
+        }
+        const uint32_t slot = in ? (uint32_t)sc->grad_slot[p] : DRT_SLOT_NONE;
+        gl.colnz[p][3] = pid_pack(R(0), zinc);
+        gl.invc[p][3] = pid_pack(R(0), slot | zbits << 16);
+    }
+    __syncthreads();
+}
+
+template <typename R, int NC>
+struct Tangents<R, DRT_NP_ANY, NC> {
+    typedef typename GenAcc<R>::T GT;
+    uint32_t cur;                   // the colours of the last <= 4 vertices, shifted in from the top (0xFF: none)
+    uint32_t zc;                    // zero factors met per channel, 8 bits each
+    uint32_t nv;                    // history entries of the current path (wave-uniform in the lockstep kernel)
+    uint32_t* hist;                 // the thread's column of full history words: word w < hist_lds at hist[w * DRT_BLOCK] (LDS),
+    uint32_t* hist_ovf;             // ... the others at hist_ovf[(w - hist_lds) * hist_stride] (global)
+    uint32_t hist_lds, hist_stride;
+    const GenLds<R>* gl;
+    GT* table;                      // the wave's table, at the lane's copy: element (row, copy) at table[(row << clog2)]
+    uint32_t clog2;
+    R* acc;                         // (unused: the register / column forms' sums)
+    __device__ inline void new_path() { cur = 0xFFFFFFFFu; zc = 0; nv = 0; }
+    __device__ inline void store_word(uint32_t w, uint32_t v)
+    {
+        if (w < hist_lds) hist[w * DRT_BLOCK] = v;
+        else hist_ovf[(size_t)(w - hist_lds) * hist_stride] = v;
+    }
+    __device__ inline uint32_t load_word(uint32_t w) const
+    {
+        return w < hist_lds ? hist[w * DRT_BLOCK] : hist_ovf[(size_t)(w - hist_lds) * hist_stride];
+    }
+    // one more vertex: `id` = the colour it scattered on, 0xFF = none (the path ended there).  UNIFORM: every lane of the wave
+    // pushes at every bounce (the lockstep kernel: nv stays a scalar); else only lanes with `live`.
+    template <bool UNIFORM>
+    __device__ inline void push(bool live, uint32_t id)
+    {
+        const uint32_t shifted = (cur >> 8) | (id << 24);
+        if (UNIFORM) {
+            cur = shifted;
+            ++nv;
+            if ((nv & 3u) == 0u) {
+                store_word((nv >> 2) - 1u, cur);
+                cur = 0xFFFFFFFFu;
+            }
+        } else {
+            cur = live ? shifted : cur;
+            nv += live ? 1u : 0u;
+            if (live && (nv & 3u) == 0u) {
+                store_word((nv >> 2) - 1u, cur);
+                cur = 0xFFFFFFFFu;
+            }
+        }
+    }
+    __device__ inline void add(uint32_t row, V3<R> v)
+    {
+        GT* t = table + ((row * 3u) << clog2);
+        atomicAdd(t, (GT)v.x);
+        atomicAdd(t + (1u << clog2), (GT)v.y);
+        atomicAdd(t + (2u << clog2), (GT)v.z);
+    }
+    // the four vertices of one history word: each adds  TgE / c  (U where its own channel is the zero one) to its colour's row
+    __device__ inline void add_word(uint32_t wd, V3<R> TgE, V3<R> U)
+    {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t id = (wd >> (8 * b)) & 0xFFu;
+            const bool valid = id != 0xFFu;
+            if (wave_any(valid)) {
+                if (valid) {
+                    const R* rec = gl->invc[id];
+                    const R ix = rec[0], iy = rec[1], iz = rec[2];
+                    const uint32_t bits = pid_unpack(rec[3]);
+                    const uint32_t row = bits & 0xFFFFu;
+                    if (row != DRT_SLOT_NONE)
+                        add(row, mk<R>((bits & 0x10000u) ? U.x : TgE.x * ix, (bits & 0x20000u) ? U.y : TgE.y * iy,
+                                       (bits & 0x40000u) ? U.z : TgE.z * iz));
+                }
+            }
+        }
+    }
+};
+
+// what a block of a general-form kernel keeps in LDS, and the two ends of its life
+template <typename R>
+struct GenBlock {
+    GenLds<R> gl;
+    typename GenAcc<R>::T table[DRT_BLOCK / DRT_WAVE][DRT_GEN_TABLE];
+};
+// (before stage_path_scene's barrier: the tables start at zero)
+template <typename R>
+__device__ inline void gen_zero(GenBlock<R>& gb)
+{
+    typedef typename GenAcc<R>::T GT;
+    for (uint32_t i = threadIdx.x; i < (DRT_BLOCK / DRT_WAVE) * DRT_GEN_TABLE; i += DRT_BLOCK)
+        (&gb.table[0][0])[i] = GT(0);
+}
+// (after it: the per-id records; the thread's view of its wave's table)
+template <typename R, int NC, typename SL>
+__device__ inline void gen_begin(GenBlock<R>& gb, const SL& lds, const DevScene<R>* __restrict__ sc, const PathArgs& a, uint32_t* hist,
+                                 uint32_t* hist_ovf, Tangents<R, DRT_NP_ANY, NC>& tg)
+{
+    stage_gen(gb.gl, lds, sc);
+    tg.gl = &gb.gl;
+    tg.hist = hist + threadIdx.x;
+    tg.hist_ovf = hist_ovf + (size_t)blockIdx.x * DRT_BLOCK + threadIdx.x;
+    tg.hist_lds = a.hist_lds;
+    tg.hist_stride = a.hist_stride;
+    tg.clog2 = a.gen_clog2;
+    tg.table = &gb.table[threadIdx.x / DRT_WAVE][threadIdx.x & ((1u << a.gen_clog2) - 1u)];
+    tg.acc = nullptr;
+    tg.new_path();
+}
+// the waves' tables -> the block's row sums in fp64: copies, then waves, in a fixed order; K7 / the finishing launch adds the blocks
+template <typename R>
+__device__ inline void gen_finish(const GenBlock<R>& gb, const PathArgs& a, double* __restrict__ gpart)
+{
+    __syncthreads();
+    const uint32_t copies = 1u << a.gen_clog2;
+    for (uint32_t r = threadIdx.x; r < a.gen_rows; r += DRT_BLOCK) {
+        double v = 0;
+        for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
+            for (uint32_t c = 0; c < copies; ++c)
+                v += (double)gb.table[ww][(r << a.gen_clog2) + c];
+        gpart[(size_t)blockIdx.x * a.gen_rows + r] = v;
+    }
+}
+
 // an emissive vertex reached with prefix throughput T: radiance and gradients
 //   L     += T E / p_k                                   (pathtracer.hpp:113-114, 133)
 //   d/dc_p += g dT_p E / p_k      d/dE += g T / p_k       (vector.hpp:418-484 in closed form)
@@ -218,12 +400,28 @@ template <typename R, int NP, int NC, bool LOSS = false, typename SL = PathScene
 __device__ inline void add_emission(const SL& lds, const TangentLds<R>& tl, const R* __restrict__ params, uint32_t eid, R inv_pk,
                                     V3<R> T, V3<R> g, V3<R>& L, Tangents<R, NP, NC>& tg)
 {
-    const V3<R> E = load_param<R, (NP > 0)>(lds, params, (int)eid) * inv_pk;
+    const V3<R> E = load_param<R, (NP != 0)>(lds, params, (int)eid) * inv_pk;
     V3<R> Tr = T;
-    if (NC > 0)                     // a channel that met a zero colour is dark
+    if (NC > 0 || NP == DRT_NP_ANY)  // a channel that met a zero colour is dark
         Tr = mk<R>((tg.zc & 0xFFu) ? R(0) : T.x, (tg.zc & 0xFF00u) ? R(0) : T.y, (tg.zc & 0xFF0000u) ? R(0) : T.z);
     L = L + Tr * E;
-    if (NP > 0) {
+    if constexpr (NP == DRT_NP_ANY) {
+        // any number of parameters: the light's own row, then every vertex of the path's history adds to its colour's row
+        if (LOSS)
+            g = mk<R>(R(2) * (L.x - g.x), R(2) * (L.y - g.y), R(2) * (L.z - g.z));
+        const V3<R> gE = g * E;
+        const uint32_t ebits = pid_unpack(tg.gl->invc[eid < DRT_PATH_LDS_PARAMS ? eid : 0][3]);
+        if ((ebits & 0xFFFFu) != DRT_SLOT_NONE && eid < DRT_PATH_LDS_PARAMS)
+            tg.add(ebits & 0xFFFFu, g * Tr * inv_pk);
+        const V3<R> TgE = Tr * gE;
+        const V3<R> U = mk<R>((tg.zc & 0xFFu) == 0x1u ? T.x * gE.x : R(0), (tg.zc & 0xFF00u) == 0x100u ? T.y * gE.y : R(0),
+                              (tg.zc & 0xFF0000u) == 0x10000u ? T.z * gE.z : R(0));
+        const uint32_t nw = tg.nv >> 2;
+        for (uint32_t w = 0; wave_any(w < nw); ++w)
+            tg.add_word(w < nw ? tg.load_word(w) : 0xFFFFFFFFu, TgE, U);
+        tg.add_word(tg.cur, TgE, U);
+    } else
+    if constexpr (NP > 0) {
         if (NC > 0)
             asm volatile("" ::: "memory");    // (keeps the reads of `tl` below where they are: see there)
         if (LOSS)
@@ -308,7 +506,7 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
     if (last && !vo) {
         if (wave_any(emits && has_bxdf)) {
             if (emits && has_bxdf) {
-                if (NP > 0 && seed_px)
+                if (NP != 0 && seed_px)
                     g = mk<R>((R)seed_px[0], (R)seed_px[1], (R)seed_px[2]);
                 add_emission<R, NP, NC>(lds, tl, params, eid, inv_pk, T, g, L, tg);
             }
@@ -336,7 +534,7 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
     }
     if (wave_any(emits && has_bxdf)) {
         if (emits && has_bxdf) {
-            if (NP > 0 && seed_px)
+            if (NP != 0 && seed_px)
                 g = mk<R>((R)seed_px[0], (R)seed_px[1], (R)seed_px[2]);
             add_emission<R, NP, NC>(lds, tl, params, eid, inv_pk, T, g, L, tg);
         }
@@ -355,10 +553,20 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
     // the throughput moves on only in lanes whose path goes on (the others stay frozen for the light's turn); with
     // gradients it leaves zero colour channels out and counts them, and counts the bounce for its colour (see Tangents)
     const int cidx = has_bxdf ? (int)cid : 0;
-    const V3<R> col = NC > 0 ? mk<R>(tl.colnz[cidx][0], tl.colnz[cidx][1], tl.colnz[cidx][2]) : load_param<R, (NP > 0)>(lds, params, cidx);
+    V3<R> col;
+    if constexpr (NP == DRT_NP_ANY) {
+        const R* rec = tg.gl->colnz[cidx < DRT_PATH_LDS_PARAMS ? cidx : 0];
+        col = mk<R>(rec[0], rec[1], rec[2]);
+        tg.zc += alive ? pid_unpack(rec[3]) : 0u;
+        if (ih)
+            tg.template push<false>(alive, cid);      // (a lane on its own: only vertices the path goes on from)
+        else
+            tg.template push<true>(live, alive ? cid : 0xFFu);
+    } else
+        col = NC > 0 ? mk<R>(tl.colnz[cidx][0], tl.colnz[cidx][1], tl.colnz[cidx][2]) : load_param<R, (NP > 0)>(lds, params, cidx);
     const V3<R> cmv = col * mk_;
     const V3<R> cm = mk<R>(alive ? cmv.x : R(1), alive ? cmv.y : R(1), alive ? cmv.z : R(1));
-    if (NC > 0) {
+    if constexpr (NC > 0 && NP != DRT_NP_ANY) {
         tg.cnt[0] += alive ? tl.inc[cidx][0] : 0u;
         if (NC > 4)
             tg.cnt[NC > 4 ? 1 : 0] += alive ? tl.inc[cidx][1] : 0u;
@@ -442,9 +650,14 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     __shared__ PathSceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
     __shared__ TangentLds<R> s_tl;
+    constexpr bool GEN = NP == DRT_NP_ANY;                // any number of parameters: history + per-wave tables (see Tangents<R, DRT_NP_ANY>)
+    __shared__ typename PickT<GEN, GenBlock<R>, NoLds>::T s_gen;
+    extern __shared__ uint32_t s_hist[];                  // GEN: [a.hist_lds][DRT_BLOCK] history words
+    if constexpr (GEN)
+        gen_zero(s_gen);
     stage_path_scene(lds, sc, params);
     const TangentLds<R>& tl = s_tl;
-    if (NC > 0)
+    if (NC > 0 && !GEN)
         stage_tangents(s_tl, lds);
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
@@ -458,9 +671,13 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     Tangents<R, NP, NC> tg;
     __shared__ R s_acc[NP > 0 ? NP * 3 : 1][DRT_BLOCK];
     tg.acc = &s_acc[0][threadIdx.x];
+    if constexpr (GEN)
+        gen_begin(s_gen, lds, sc, a, s_hist, reinterpret_cast<uint32_t*>(gimg_part), tg);   // (no gradient image in this form: the pointer carries the history's global part)
+    else {
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-        tg.acc_set(p, mk<R>(R(0), R(0), R(0)));
+        for (int p = 0; p < NP; ++p)
+            tg.acc_set(p, mk<R>(R(0), R(0), R(0)));
+    }
     double fx = 0, fy = 0, fz = 0;                        // radiance sum of this lane's pixel over the range
     uint32_t n_seg = 0, n_capped = 0;                     // wave-uniform counters
 
@@ -470,7 +687,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         gpix = path_global_pixel(a, a.p0 + lp);
         py = gpix / (uint32_t)a.W;
         px = gpix - py * (uint32_t)a.W;
-        if (NP > 0 && adjoint)
+        if (NP != 0 && adjoint)
             g = mk<R>((R)adjoint[(size_t)gpix * 3], (R)adjoint[(size_t)gpix * 3 + 1], (R)adjoint[(size_t)gpix * 3 + 2]);
     }
     // f32: the pixel's corner in double ONCE per lane; a sample then only adds its jitter (camera.hpp:53-58 in the form
@@ -506,7 +723,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
         uint32_t end_ids = DRT_ID_NONE;                   // emission parameter of the light the path ended on
         R end_inv_pk = R(1);
-        if (NC > 0)
+        if (NC > 0 || GEN)
             tg.new_path();
         for (int kk = 0; kk < a.depth_cap; ++kk) {
             const uint32_t n_live = (uint32_t)__popcll(wave_ballot(live));
@@ -571,7 +788,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         ra.x = ra.y = ra.z = ra.w = R(0);
         rb.x = rb.y = R(0);
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
-        if (NC > 0)
+        if (NC > 0 || GEN)
             tg.new_path();
         const int first_rr = a.min_bounces > 1 ? a.min_bounces : 1;
         for (;;) {
@@ -594,7 +811,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
                         live = a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
                         T = mk<R>(R(1), R(1), R(1));
                         L = mk<R>(R(0), R(0), R(0));
-                        if (NC > 0)
+                        if (NC > 0 || GEN)
                             tg.new_path();
                     }
                 }
@@ -619,7 +836,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             uint32_t light;
             // the seed of the path's pixel (render.cpp:80: all ones; else the caller's image): read where a path meets a light
             V3<R> gp3 = mk<R>(R(1), R(1), R(1));
-            const float* seed_px = (NP > 0 && adjoint) ? adjoint + (size_t)pgpix * 3 : (const float*)nullptr;
+            const float* seed_px = (NP != 0 && adjoint) ? adjoint + (size_t)pgpix * 3 : (const float*)nullptr;
             path_bounce<R, SPEC, NP, NC, SG>(a, lds, tl, sc, params, recs, key, pk, inv_pk, n_theta, next_rr, next_cap, live, gp3,
                                                     ra, rb, T, L, tg, alive, capped, on_light, light, nullptr, false, seed_px, s_ih);
             if (!a.cap_is_roulette)
@@ -654,7 +871,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             double* f = fpart + ((size_t)range * 3) * a.Pb + lp;       // [range][channel][pixel]: coalesced
             f[0] = fx; f[(size_t)a.Pb] = fy; f[(size_t)a.Pb * 2] = fz;
         }
-        if (NP > 0 && gimg_part && have) {
+        if constexpr (NP > 0) if (gimg_part && have) {
             // gradient image (README.md:142-145): a lane IS a pixel, its gradient sum of one parameter over the samples of
             // this range is that pixel's share -- same layout as the radiance partials, same finishing kernels
             const V3<R> v = tg.acc_get(a.gimg_param > 0 && a.gimg_param < NP ? a.gimg_param : 0);
@@ -666,6 +883,9 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             counts[(size_t)a.n_groups * a.n_ranges + w] = n_capped;
         }
     }
+    if constexpr (GEN)
+        gen_finish(s_gen, a, gpart);
+    else
     if (NP > 0) {
         // block reduction in fp64: thread -> wave (shuffles) -> block (LDS), fixed order; K7 adds the blocks
         const int wv = threadIdx.x / DRT_WAVE;
@@ -757,8 +977,17 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     typedef typename Q2<R>::T R2;
     __shared__ PathSceneLds<R> lds;
     __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+    // NP = DRT_NP_ANY: any number of parameters -- the chain's two adds per vertex (the light's colour, the BxDF's colour) go
+    // to the wave's gradient table in LDS (Tangents<R, DRT_NP_ANY>; no vertex history: the chain IS the reverse sweep)
+    constexpr bool GEN = NP == DRT_NP_ANY;
+    __shared__ typename PickT<GEN, GenBlock<R>, NoLds>::T s_gen;
+    if constexpr (GEN)
+        gen_zero(s_gen);
     stage_path_scene(lds, sc, params);
     const TangentLds<R>& tl = *reinterpret_cast<const TangentLds<R>*>(&lds);   // (forward-only walks never touch it)
+    Tangents<R, GEN ? DRT_NP_ANY : 0, 0> gt;
+    if constexpr (GEN)
+        gen_begin(s_gen, lds, sc, a, (uint32_t*)nullptr, (uint32_t*)nullptr, gt);
 
     const uint32_t lane = threadIdx.x & (DRT_WAVE - 1);
     const uint32_t w = grid_wave();
@@ -768,7 +997,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     const uint32_t s_begin = range * a.spr;
     const uint32_t s_end = s_begin + a.spr < a.Sb ? s_begin + a.spr : a.Sb;
 
-    V3<R> acc[NP];
+    V3<R> acc[NP > 0 ? NP : 1];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
         acc[p] = mk<R>(R(0), R(0), R(0));
@@ -838,6 +1067,13 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
                     const V3<R> g1 = g * inv_pk;                  // "/ p" of trace()
                     const uint32_t eid = cur.ids >> 16;
                     cid = cur.ids & 0xFFFFu;
+                    if constexpr (GEN) {
+                        if (eid < DRT_PATH_LDS_PARAMS) {
+                            const uint32_t row = pid_unpack(gt.gl->invc[eid][3]) & 0xFFFFu;
+                            if (row != DRT_SLOT_NONE)
+                                gt.add(row, g1);
+                        }
+                    }
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         const bool own = eid == (uint32_t)p;
@@ -873,6 +1109,13 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
                 // ---- gradients of this vertex; the chain moves on to the suffix's first vertex
                 if (in_chain) {
                     const V3<R> df = Ls * gq * bs;                // MulBackward, brdf side
+                    if constexpr (GEN) {
+                        if (cid < DRT_PATH_LDS_PARAMS) {
+                            const uint32_t row = pid_unpack(gt.gl->invc[cid][3]) & 0xFFFFu;
+                            if (row != DRT_SLOT_NONE)
+                                gt.add(row, df);
+                        }
+                    }
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         const bool own = cid == (uint32_t)p;
@@ -897,6 +1140,9 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
             counts[(size_t)a.n_groups * a.n_ranges + w] = n_capped;
         }
     }
+    if constexpr (GEN)
+        gen_finish(s_gen, a, gpart);
+    else
     {   // block reduction in fp64 (as in k_path)
         const int wv = threadIdx.x / DRT_WAVE;
 #pragma unroll
@@ -946,8 +1192,10 @@ k_film_parts(const double* __restrict__ fpart, uint32_t n_ranges, uint32_t Pb, u
 __global__ void __launch_bounds__(DRT_BLOCK)
 k_path_finish(PathArgs a, const double* __restrict__ fpart, float* __restrict__ out, uint32_t film_blocks,
               const double* __restrict__ gpart, int n_blocks, int n_rows, int row_stride, double* __restrict__ grad, uint32_t grad_words,
-              const uint32_t* __restrict__ counts, uint32_t n_waves, unsigned long long* __restrict__ total, uint32_t count_rows = 2)
+              const uint32_t* __restrict__ counts, uint32_t n_waves, unsigned long long* __restrict__ total, uint32_t count_rows = 2,
+              const unsigned short* __restrict__ slot_map = nullptr)
 {
+    // (slot_map, the general form of the path kernels: gpart's rows are table rows, DevScene::grad_slot maps parameters to them)
     // (count_rows = 3, k_path_mesh: a third word per wave, the rays its BVH walk took -> total[5])
     __shared__ double red[DRT_BLOCK];
     if (blockIdx.x < film_blocks) {
@@ -970,10 +1218,15 @@ k_path_finish(PathArgs a, const double* __restrict__ fpart, float* __restrict__ 
     }
     if (blockIdx.x < film_blocks + grad_words) {
         const int p = (int)(blockIdx.x - film_blocks);
+        int src = p;
+        if (slot_map) {
+            const int slot = slot_map[p / 3];
+            src = slot == (int)DRT_SLOT_NONE ? n_rows : slot * 3 + p % 3;
+        }
         double v = 0;
-        if (p < n_rows)
+        if (src < n_rows)
             for (int b = threadIdx.x; b < n_blocks; b += DRT_BLOCK)
-                v += gpart[(size_t)b * row_stride + p];
+                v += gpart[(size_t)b * row_stride + src];
         red[threadIdx.x] = v;
         __syncthreads();
         for (int off = DRT_BLOCK / 2; off > 0; off >>= 1) {

@@ -49,12 +49,17 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     __shared__ uint32_t s_stack[DRT_MESH_LDS_STACK][DRT_BLOCK];
     __shared__ R s_acc[NP > 0 ? NP * 3 : 1][DRT_BLOCK];
     __shared__ uint32_t s_ih[DRT_DRAW_TABLE];             // h(n) of every draw index (lanes stand at their own depths: drt_path.h)
+    constexpr bool GEN = NP == DRT_NP_ANY;                // any number of parameters: vertex history + per-wave tables (drt_path.h)
+    __shared__ typename PickT<GEN, GenBlock<R>, NoLds>::T s_gen;
+    extern __shared__ uint32_t s_hist[];                  // GEN: [a.hist_lds][DRT_BLOCK] history words
     for (uint32_t n = threadIdx.x; n < DRT_DRAW_TABLE; n += DRT_BLOCK)
         s_ih[n] = drt_rng_index_hash(a.rng_stream, n);
+    if constexpr (GEN)
+        gen_zero(s_gen);
     stage_tail_program(s_prog, sc);
     stage_path_scene(lds, sc, params);                    // (ends with a barrier)
     const TangentLds<R>& tl = s_tl;
-    if (NC > 0)
+    if (NC > 0 && !GEN)
         stage_tangents(s_tl, lds);
     ProgRecs<0> recs;
     recs.lds = &s_prog;
@@ -70,9 +75,13 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
 
     Tangents<R, NP, NC> tg;
     tg.acc = &s_acc[0][threadIdx.x];
+    if constexpr (GEN)
+        gen_begin(s_gen, lds, sc, a, s_hist, ovf + (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) * ovf_stride, tg);   // (behind the traversal stacks' global part)
+    else {
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
-        tg.acc_set(p, mk<R>(R(0), R(0), R(0)));
+        for (int p = 0; p < NP; ++p)
+            tg.acc_set(p, mk<R>(R(0), R(0), R(0)));
+    }
     double fx = 0, fy = 0, fz = 0;                        // radiance sum of this lane's pixel over the range
     uint32_t n_seg = 0, n_capped = 0, n_walked = 0;       // wave-uniform counters
 
@@ -82,7 +91,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
         gpix = path_global_pixel(a, a.p0 + lp);
         py = gpix / (uint32_t)a.W;
         px = gpix - py * (uint32_t)a.W;
-        if (NP > 0 && adjoint)
+        if (NP != 0 && adjoint)
             g = mk<R>((R)adjoint[(size_t)gpix * 3], (R)adjoint[(size_t)gpix * 3 + 1], (R)adjoint[(size_t)gpix * 3 + 2]);
     }
     CameraLane<R> cl;                                     // (see k_path)
@@ -102,7 +111,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     R tmin = (R)INFINITY;
     int prim = -1, sp = 0;
     uint32_t best_flat = 0xFFFFFFFFu, cur = DRT_BVH_NONE;
-    if (NC > 0)
+    if (NC > 0 || GEN)
         tg.new_path();
 
 #define DRT_MESH_PUSH(v)                                                                      \
@@ -183,9 +192,16 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                 const bool alive = hit && has_bxdf && !next_cap && !rr_kills;
                 capped = hit && has_bxdf && next_cap && !rr_kills;
                 const int cidx = has_bxdf ? (int)cid : 0;
-                const V3<R> col = NC > 0 ? mk<R>(tl.colnz[cidx][0], tl.colnz[cidx][1], tl.colnz[cidx][2]) : load_param<R, (NP > 0)>(lds, params, cidx);
+                V3<R> col;
+                if constexpr (GEN) {
+                    const R* rec = tg.gl->colnz[cidx < DRT_PATH_LDS_PARAMS ? cidx : 0];
+                    col = mk<R>(rec[0], rec[1], rec[2]);
+                    tg.zc += pid_unpack(rec[3]);
+                    tg.template push<false>(alive, cid);
+                } else
+                    col = NC > 0 ? mk<R>(tl.colnz[cidx][0], tl.colnz[cidx][1], tl.colnz[cidx][2]) : load_param<R, (NP > 0)>(lds, params, cidx);
                 T = T * col * mk_;                                          // (only read again if the path goes on)
-                if (NC > 0) {
+                if constexpr (NC > 0 && !GEN) {
                     tg.cnt[0] += tl.inc[cidx][0];
                     if (NC > 4)
                         tg.cnt[NC > 4 ? 1 : 0] += tl.inc[cidx][1];
@@ -216,7 +232,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                         o = mk<R>(ra.x, ra.y, ra.z);
                         d = mk<R>(ra.w, rb.x, rb.y);
                         T = mk<R>(R(1), R(1), R(1));
-                        if (NC > 0)
+                        if (NC > 0 || GEN)
                             tg.new_path();
                         // pathtracer.hpp:128 at depth 0
                         fresh = a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
@@ -296,7 +312,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
             double* f = fpart + ((size_t)range * 3) * a.Pb + lp;       // [range][channel][pixel]: coalesced
             f[0] = fx; f[(size_t)a.Pb] = fy; f[(size_t)a.Pb * 2] = fz;
         }
-        if (NP > 0 && gimg_part && have) {                             // gradient image (README.md:142-145): see k_path
+        if constexpr (NP > 0) if (gimg_part && have) {                 // gradient image (README.md:142-145): see k_path
             const V3<R> v = tg.acc_get(a.gimg_param > 0 && a.gimg_param < NP ? a.gimg_param : 0);
             double* f = gimg_part + ((size_t)range * 3) * a.Pb + lp;
             f[0] = (double)v.x; f[(size_t)a.Pb] = (double)v.y; f[(size_t)a.Pb * 2] = (double)v.z;
@@ -308,6 +324,9 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
             counts[2 * nw + w] = n_walked;
         }
     }
+    if constexpr (GEN)
+        gen_finish(s_gen, a, gpart);
+    else
     if (NP > 0) {
         // block reduction in fp64: thread -> wave (shuffles) -> block (LDS), fixed order; the finishing launch adds the blocks
         const int wv = threadIdx.x / DRT_WAVE;

@@ -2,6 +2,7 @@
 // phase on all members before the next) and asynchronous frames; the ONE collective of the path (ncclAllReduce of the P x 3
 // gradient accumulator, VariableNode::backward's `m_grad += grad`, vector.hpp:185-188) is enqueued in `reduce`.
 #pragma once
+#include <thread>
 
 // rows [y0, y1) of the bands that `shard` owns
 template <typename F>
@@ -127,7 +128,9 @@ static int render_launch(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt
                 // small frame --, everything else gets it copied into device memory (the tape route reads it per PATH).
                 if ((rc = ensure(ctx, ctx->adjoint, npix_all * 3 * sizeof(float))) != DRT_OK) return rc;
                 ctx->adj_src_host = adjoint_rgb;
-                ctx->adj_src_dev = pinned_alias(ctx, adjoint_rgb, npix_all * 3 * sizeof(float));
+                // (an ASYNCHRONOUS frame always takes its copy: drt_hip_render_async promises that adjoint_rgb is consumed when it
+                //  returns -- a loop rewrites its one pinned adjoint image for the next frame while this one is in flight)
+                ctx->adj_src_dev = ctx->stage_adjoint_next ? nullptr : pinned_alias(ctx, adjoint_rgb, npix_all * 3 * sizeof(float));
                 if (!ctx->adj_src_dev) {
                     if ((rc = ensure_stage(ctx, j)) != DRT_OK) return rc;
                     memcpy(ctx->h_stage[ctx->slot] + j.off_adj, adjoint_rgb, npix_all * 3 * sizeof(float));
@@ -239,6 +242,7 @@ static int ensure_stage(drt_hip_ctx* ctx, RenderJob& j)
         ctx->h_stage_cap[ctx->slot] = 0;
         HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stage[ctx->slot], need));
         ctx->h_stage_cap[ctx->slot] = need;
+        memset(ctx->h_stage[ctx->slot], 0, 128);        // (totals and the completion word of a fresh block: never a stale sequence number)
     }
     return DRT_OK;
 }
@@ -389,7 +393,13 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true, hipEvent_t don
             const auto t_spin = std::chrono::steady_clock::now();
             for (uint32_t it = 0;; ++it) {
                 if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == (unsigned long long)j.done_seq) { seen = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#elif defined(__aarch64__)
+                __asm__ __volatile__("isb" ::: "memory");
+#else
+                std::this_thread::yield();
+#endif
                 if ((it & 255u) == 255u &&
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_spin).count() > (double)tuning().sync_spin_us)
                     break;
@@ -397,6 +407,15 @@ static int render_finish(drt_hip_ctx* ctx, bool with_grad = true, hipEvent_t don
         }
         if (!seen)
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        else {
+            // (the word was written by the frame's LAST launch, so the stream is through -- a query costs a microsecond and
+            //  surfaces a fault of this frame here instead of at some later call)
+            const hipError_t eq = hipStreamQuery(ctx->stream);
+            if (eq != hipSuccess && eq != hipErrorNotReady) {
+                ctx->err = std::string("render: ") + hipGetErrorString(eq);
+                return DRT_ERR_HIP;
+            }
+        }
     }
     unsigned long long h_tot[DRT_TOTAL_WORDS] = {0};
     if (j.want_segments)

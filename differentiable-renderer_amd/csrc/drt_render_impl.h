@@ -158,6 +158,8 @@ struct Shard {
     hipFunction_t loss_kernel = nullptr;   // ... on k_path: the LOSS instantiation, made at run time only (drt_jit.h)
     bool can_fuse;                  // K2 folded into K3: analytic scenes, unless DRT_RENDER_UNFUSED asks for the textbook pipeline
     bool use_path, path_regen;      // the whole path in one launch (k_path); its regenerating form
+    bool path_gen = false;          // ... its gradients in the general form: any number of parameters (DRT_NP_ANY)
+    uint32_t gen_rows = 0, gen_clog2 = 0;
     bool mesh_path;                 // ... in a scene with a mesh: k_path_mesh (drt_path_mesh.h), the BVH walk inside the launch
     bool shade_tail;                // mesh scenes: the launch that produces a ray also intersects it with the analytic shapes and
                                     // builds the BVH walk's candidate lists (k_raygen / k_shade / k_adj_vertex <TAIL>)
@@ -227,17 +229,18 @@ struct Shard {
 
 // "k_path<float, SPEC, NP, NC, KindSig<...>, REGEN[, LOSS]>" / "k_path_unbiased<float, SPEC, NP, KindSig<...>>": the name expression
 // of the f32 instantiation a render would launch, for the scene's own signature
-inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss)
+inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss, bool gen)
 {
     const std::string sg = drt_jit::sig_type(ctx->prog_sig, ctx->n_shapes);
     const char* sp = ctx->has_specular ? "true" : "false";
     const bool three = ctx->max_colour_param < 3;      // tangent state only for parameters that ARE some BxDF's colour
     char name[400];
+    // (gen: the general form, any number of parameters: DRT_NP_ANY = -1)
     if (unbiased)
-        snprintf(name, sizeof name, "k_path_unbiased<float, %s, %d, %s>", sp, ctx->n_params > 4 ? 8 : 4, sg.c_str());
+        snprintf(name, sizeof name, "k_path_unbiased<float, %s, %d, %s>", sp, gen ? -1 : (ctx->n_params > 4 ? 8 : 4), sg.c_str());
     else {
-        const int np = tangents ? (ctx->n_params > 4 ? 8 : 4) : 0;
-        const int nc = tangents ? (ctx->n_params > 4 ? 8 : (three ? 3 : 4)) : 0;
+        const int np = tangents ? (gen ? -1 : (ctx->n_params > 4 ? 8 : 4)) : 0;
+        const int nc = tangents ? (gen ? 0 : (ctx->n_params > 4 ? 8 : (three ? 3 : 4))) : 0;
         snprintf(name, sizeof name, "k_path<float, %s, %d, %d, %s, %s%s>", sp, np, nc, sg.c_str(), regen ? "true" : "false", loss ? ", true" : "");
     }
     return name;
@@ -270,7 +273,12 @@ void shard_plan(Shard<R>& s)
     // (decided by the size of the FRAME, not of this shard's part of it: the shards of a frame take one route and tile it bit for bit)
     const bool mesh_ok = ctx->has_mesh && (long long)s.cam->width * s.cam->height * s.spp <= tuning().mesh_path_max && ctx->prog_sorted && !(rp->flags & DRT_RENDER_UNFUSED) && !s.unbiased &&
                          !s.loss_l2;
-    s.use_path = ((s.can_fuse && ctx->prog_ok) || mesh_ok) && D > 0 && (!(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS) &&
+    // gradients: <= 8 parameters in registers / LDS columns; any number the kernels can stage (136: every analytic scene) through
+    // the general form -- vertex history + per-wave tables (drt_path.h, DRT_NP_ANY) -- except the gradient IMAGE, which is
+    // the lanes' own sums
+    const bool grads_ok = !(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS ||
+                          (ctx->n_params <= DRT_PATH_LDS_PARAMS && s.gimg_param < 0 && tuning().path_general);
+    s.use_path = ((s.can_fuse && ctx->prog_ok) || mesh_ok) && D > 0 && grads_ok &&
                  rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path == -1;
     s.mesh_path = s.use_path && ctx->has_mesh;
     s.path_regen = tuning().path_regen > 0 || s.mesh_path;    // (k_path_mesh: every lane on its own, always)
@@ -306,10 +314,15 @@ void shard_plan(Shard<R>& s)
         // (DRT_SPECIALISE_AUTO: no frame waits for the compiler -- the compile runs on the library's own thread from the first
         //  such frame on, and the tape route renders until it has delivered; DRT_SPECIALISE_NOW waits)
         if (sizeof(R) == 4 && !ctx->emissive_bxdf && ctx->jit_mode >= DRT_SPECIALISE_AUTO) {
-            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true), ctx->jit_mode > DRT_SPECIALISE_AUTO);
+            const bool gen_loss = ctx->n_params > tuning().gen_above && ctx->n_params <= DRT_PATH_LDS_PARAMS && (tuning().path_general || ctx->n_params <= DRT_FAST_PARAMS);
+            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true, gen_loss), ctx->jit_mode > DRT_SPECIALISE_AUTO);
             s.use_path = s.loss_kernel != nullptr;
         }
     }
+    // (the general form also where the register form would do but is slower: its 5 ... 8-parameter instantiation keeps 24 LDS
+    //  columns per thread -- 0.78 ms against the general form's 0.75 on config 3's frame with an albedo per wall)
+    s.path_gen = s.use_path && s.backward && s.gimg_param < 0 && ctx->n_params > tuning().gen_above && ctx->n_params <= DRT_PATH_LDS_PARAMS &&
+                 (tuning().path_general || ctx->n_params <= DRT_FAST_PARAMS);
     // Batch = the paths that are in flight at once on the queue route.  The BVH walk wants it LARGE: its launches end in a
     // tail of ~0.1 ms whatever their size (the list counters run dry, every wave finishes what it holds), so config 4 at full
     // size (1024^2 x 256 spp) takes 115 / 101 / 98 / 96 ms with 2^24 / 2^26 / 2^27 / 2^28 paths per batch and one GPU's
@@ -390,6 +403,16 @@ void shard_plan(Shard<R>& s)
     // a k_path launch that covers the whole frame is followed by ONE finishing launch that WRITES image, gradients and
     // totals (k_path_finish); every other route accumulates into zeroed buffers
     s.path_finish = s.use_path && s.Pb == s.n_local_pixels && s.Sb == (uint32_t)s.spp && (!s.film || s.d_out_rgb);
+    if (s.path_gen) {
+        // a wave's table holds DRT_GEN_TABLE elements: as many copies of every row as fit, at most 16 (same-address LDS atomics
+        // of one instruction serialise; with 16 copies the ~12 lanes of a wave that end a sample on a light rarely meet)
+        s.gen_rows = (uint32_t)std::max(1, ctx->n_grad_slots) * 3u;
+        s.gen_clog2 = 0;
+        while (s.gen_clog2 < 4 && (s.gen_rows << (s.gen_clog2 + 1)) <= DRT_GEN_TABLE)
+            ++s.gen_clog2;
+        if (tuning().gen_copies_log2 >= 0 && (s.gen_rows << tuning().gen_copies_log2) <= DRT_GEN_TABLE)
+            s.gen_clog2 = (uint32_t)tuning().gen_copies_log2;
+    }
     s.n_fast = ctx->n_params < DRT_FAST_PARAMS ? ctx->n_params : DRT_FAST_PARAMS;
     const bool g_general = ctx->n_params > DRT_FAST_PARAMS;
     s.g_rows = g_general ? std::min(ctx->n_params, DRT_LDS_PARAMS) * 3 : s.n_fast * 3;
@@ -469,8 +492,9 @@ int shard_buffers(Shard<R>& s)
         if (s.use_path && path_blocks > blocks)
             blocks = path_blocks;
         // rows per block: 24 for the register paths (<= 8 parameters), else one per parameter channel (LDS accumulators)
-        const size_t rows = ctx->n_params <= DRT_FAST_PARAMS ? (size_t)DRT_FAST_PARAMS * 3
-                                                             : (size_t)std::min(ctx->n_params, DRT_LDS_PARAMS) * 3;
+        const size_t rows = s.path_gen ? (size_t)s.gen_rows
+                                       : (ctx->n_params <= DRT_FAST_PARAMS ? (size_t)DRT_FAST_PARAMS * 3
+                                                                           : (size_t)std::min(ctx->n_params, DRT_LDS_PARAMS) * 3);
         if ((rc = ensure(ctx, *s.gpart_buf, blocks * rows * sizeof(double))) != DRT_OK) return rc;
     }
     for (int i = 0; i < 3; ++i) {
@@ -559,6 +583,19 @@ int path_batch(Shard<R>& s)
     pa.tan_half = a.tan_half; pa.aspect = a.aspect;
     pa.inv_W = 1.0 / (double)a.W; pa.inv_H = 1.0 / (double)a.H;
     pa.gimg_param = s.gimg_param;
+    pa.gen_rows = s.gen_rows; pa.gen_clog2 = s.gen_clog2;
+    // the general form's vertex history: a word per four vertices and thread, in dynamic shared memory
+    const bool gen = s.path_gen;
+    // (the first words in LDS, as many as leave the kernel's blocks per CU alone: four in the lockstep k_path -- 16 vertices --,
+    //  none in the regenerating forms, whose static LDS sits right under a block's share; the others in global memory)
+    const uint32_t hist_words = gen ? (uint32_t)(a.depth_cap / 4) : 0u;
+    pa.hist_lds = std::min<uint32_t>(hist_words, (path_regen || s.mesh_path) ? 0u : 4u);
+    if (tuning().gen_hist_lds >= 0)
+        pa.hist_lds = std::min<uint32_t>(hist_words, (uint32_t)tuning().gen_hist_lds);
+    const unsigned hist_bytes = pa.hist_lds * DRT_BLOCK * (unsigned)sizeof(uint32_t);
+    const uint32_t hist_ovf_words = hist_words - pa.hist_lds;
+    const unsigned short* slot_map = gen ? (const unsigned short*)((const char*)s.d_scene + offsetof(DevScene<R>, grad_slot)) : (const unsigned short*)nullptr;
+    const int g_rows = gen ? (int)s.gen_rows : s.n_fast * 3, g_stride = gen ? (int)s.gen_rows : DRT_FAST_PARAMS * 3;
     const size_t n_waves = (size_t)pa.n_groups * pa.n_ranges;
     const int gpath = (int)((n_waves + DRT_BLOCK / DRT_WAVE - 1) / (DRT_BLOCK / DRT_WAVE));
     const DevScene<R>* d_scene = s.d_scene;
@@ -568,6 +605,7 @@ int path_batch(Shard<R>& s)
     uint32_t* counts = s.counts;
     double* fpart = s.film ? (double*)s.fpart_buf->p : (double*)nullptr;
     double* gpix = s.gimg_param >= 0 ? (double*)ctx->gpix.p : (double*)nullptr;   // gradient image partials
+    double* hist_global = nullptr;   // the general form (never with a gradient image): the kernel's gradient-image argument carries its history's global part
     // The closest-hit program.  The kinds of the reference's own scene are compiled in, in the instantiation the library
     // carries (f64 too: the verification mode runs the same program with full-precision reciprocals and square roots); any
     // other analytic scene reads its kinds at run time (the kind-sorted program) until it has rendered enough for a kernel
@@ -576,9 +614,10 @@ int path_batch(Shard<R>& s)
                          ctx->prog_sig[0] == DRT_SIG_CORNELL && !s.loss_kernel && !s.mesh_path;
     unsigned long long* ptotal = s.path_finish ? s.totals : (unsigned long long*)nullptr;
     // (frames that overlap: this frame's grid goes to the lane's own stream, behind whoever still uses the lane's buffers, and
-    //  the finishing launch on the context's stream waits for it.  Scene and parameter uploads block until they are done, so
-    //  the grid needs nothing from the context's stream -- unless the call brings an adjoint image, which the caller may have
-    //  produced in that stream's order: then the frame keeps its place in it.)
+    //  the finishing launch on the context's stream waits for it.  Scene uploads block until they are done; a parameter update
+    //  is a launch in the context's stream that nobody waits for on the host -- the first frame of either lane behind it waits
+    //  for its event --; an adjoint image the caller may have produced in the context's stream's order: then the frame keeps
+    //  its place in it.)
     hipStream_t ks = ctx->stream;
     const bool overlap = s.overlap_ok && s.path_finish;
     const int lane2 = ctx->slot & 1;                // which of the two k_path streams / sets of partial sums
@@ -592,24 +631,28 @@ int path_batch(Shard<R>& s)
         //  stream -- has enqueued its last reader on the context's stream by the time its event is recorded)
         if (ctx->lane_used[lane2] && ctx->ev_lane_free[lane2])
             HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_lane_free[lane2], 0));
+        if (ctx->params_pending[lane2] && ctx->ev_params) {
+            HIPCHK(ctx, hipStreamWaitEvent(ks, ctx->ev_params, 0));
+            ctx->params_pending[lane2] = false;
+        }
     }
     const bool three = ctx->max_colour_param < 3;
     const bool tangents = backward || s.gimg_param >= 0;
     hipFunction_t jit = s.loss_kernel;
     ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(s.D > 0 ? s.D : 1);
     if (!jit && !builtin && !s.mesh_path && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
-        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false), ctx->jit_mode > 1);
+        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen), ctx->jit_mode > 1);
     st->path_program = builtin ? DRT_PROGRAM_BUILTIN : (jit ? DRT_PROGRAM_SPECIALISED : DRT_PROGRAM_SORTED);
     int rc;
     if ((rc = timing_begin(ctx, s.timing, DRT_K_PATH)) != DRT_OK) return rc;
 #define DRT_LAUNCH_PATH(SPEC, NP, NC, SG)                                                                                 \
     do {                                                                                                                 \
         if (path_regen)                                                                                                  \
-            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, true>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,                 \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, true>), dim3(gpath), dim3(DRT_BLOCK), hist_bytes, ks,        \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gen ? hist_global : gpix); \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, false>), dim3(gpath), dim3(DRT_BLOCK), 0, ks,                \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
+            hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, false>), dim3(gpath), dim3(DRT_BLOCK), hist_bytes, ks,       \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gen ? hist_global : gpix); \
     } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
     do {                                                                                   \
@@ -627,24 +670,43 @@ int path_batch(Shard<R>& s)
     } while (0)
     uint32_t* ovf = s.mesh_path ? (uint32_t*)ctx->mesh_ovf[(s.overlap_ok && lane2) ? 1 : 0].p : (uint32_t*)nullptr;
     const uint32_t ovf_stride = (uint32_t)gpath * DRT_BLOCK;
+    pa.hist_stride = ovf_stride;
+    if (gen && hist_ovf_words > 0) {
+        // the general form's history beyond its LDS words: a column per thread of the grid (one area per k_path stream); the
+        // mesh kernel keeps it behind its traversal stacks' global part
+        DevBuf& hb = s.mesh_path ? ctx->mesh_ovf[(s.overlap_ok && lane2) ? 1 : 0] : ctx->hist_ovf[(s.overlap_ok && lane2) ? 1 : 0];
+        const size_t words = (size_t)hist_ovf_words + (s.mesh_path ? (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) : 0);
+        int rce;
+        if ((rce = ensure(ctx, hb, words * ovf_stride * sizeof(uint32_t))) != DRT_OK) return rce;
+        if (s.mesh_path)
+            ovf = (uint32_t*)hb.p;
+        else
+            hist_global = (double*)hb.p;
+    }
     const DevBvh<R> bvh = s.bvh;
 #define DRT_LAUNCH_MESH(SPEC, NP, NC)                                                                              \
-    hipLaunchKernelGGL((k_path_mesh<R, SPEC, NP, NC>), dim3(gpath), dim3(DRT_BLOCK), 0, ks, pa, d_scene, d_params, \
+    hipLaunchKernelGGL((k_path_mesh<R, SPEC, NP, NC>), dim3(gpath), dim3(DRT_BLOCK), hist_bytes, ks, pa, d_scene, d_params, \
                        d_adjoint, bvh, ovf, ovf_stride, gpart, fpart, counts, ptotal, gpix)
     if (s.mesh_path) {
-        if (tangents && ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 8, 8); else DRT_LAUNCH_MESH(false, 8, 8); }
+        if (tangents && gen) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, DRT_NP_ANY, 0); else DRT_LAUNCH_MESH(false, DRT_NP_ANY, 0); }
+        else if (tangents && ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 8, 8); else DRT_LAUNCH_MESH(false, 8, 8); }
         else if (tangents && three) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 4, 3); else DRT_LAUNCH_MESH(false, 4, 3); }
         else if (tangents) { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 4, 4); else DRT_LAUNCH_MESH(false, 4, 4); }
         else { if (ctx->has_specular) DRT_LAUNCH_MESH(true, 0, 0); else DRT_LAUNCH_MESH(false, 0, 0); }
     } else
 #undef DRT_LAUNCH_MESH
     if (jit) {
-        void* args_path[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal, &gpix};
+        double* aux = gen ? hist_global : gpix;
+        void* args_path[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal, &aux};
         void* args_unb[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal};
-        HIPCHK(ctx, hipModuleLaunchKernel(jit, (unsigned)gpath, 1, 1, DRT_BLOCK, 1, 1, 0, ks, unbiased ? args_unb : args_path, nullptr));
+        HIPCHK(ctx, hipModuleLaunchKernel(jit, (unsigned)gpath, 1, 1, DRT_BLOCK, 1, 1, unbiased ? 0u : hist_bytes, ks, unbiased ? args_unb : args_path, nullptr));
     } else if (unbiased) {                      // the unbiased operator: fresh suffix paths per vertex, in registers
-        if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }
+        if (gen) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, DRT_NP_ANY); else DRT_LAUNCH_UNB(false, DRT_NP_ANY); }
+        else if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }
         else { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 4); else DRT_LAUNCH_UNB(false, 4); }
+    } else if (tangents && gen) {                      // any number of parameters
+        if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, DRT_NP_ANY, 0);
+        else DRT_LAUNCH_PATH_SIG(false, DRT_NP_ANY, 0);
     } else if (tangents && ctx->n_params > 4) {        // 5 .. 8 parameters
         if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, 8, 8);
         else DRT_LAUNCH_PATH_SIG(false, 8, 8);
@@ -665,7 +727,7 @@ int path_batch(Shard<R>& s)
     }
     st->launches[DRT_K_PATH]++;
     st->path_bytes += (s.film ? (uint64_t)pa.n_ranges * a.Pb * 3 * sizeof(double) : 0) +
-                      (backward ? (uint64_t)gpath * DRT_FAST_PARAMS * 3 * sizeof(double) : 0) + (s.mesh_path ? 3 : 2) * n_waves * sizeof(uint32_t);
+                      (backward ? (uint64_t)gpath * (uint64_t)g_stride * sizeof(double) : 0) + (s.mesh_path ? 3 : 2) * n_waves * sizeof(uint32_t);
     if (s.path_finish) {
         // image, gradients and totals of the frame in one launch (timed in the film slot)
         const uint32_t film_blocks = s.film ? (uint32_t)grid_for(ctx, a.Pb) : 0u;
@@ -673,9 +735,9 @@ int path_batch(Shard<R>& s)
         const uint32_t count_blocks = (uint32_t)std::min<size_t>(64, (n_waves + DRT_BLOCK - 1) / DRT_BLOCK);
         DRT_TIMED(s, DRT_K_FILM,
                   hipLaunchKernelGGL(k_path_finish, dim3(film_blocks + grad_words + count_blocks), dim3(DRT_BLOCK), 0, ctx->stream, pa,
-                                     (const double*)fpart, s.d_out_rgb, film_blocks, (const double*)gpart, gpath, s.n_fast * 3,
-                                     DRT_FAST_PARAMS * 3, s.grad, grad_words, (const uint32_t*)counts, (uint32_t)n_waves, s.totals,
-                                     s.mesh_path ? 3u : 2u));
+                                     (const double*)fpart, s.d_out_rgb, film_blocks, (const double*)gpart, gpath, g_rows,
+                                     g_stride, s.grad, grad_words, (const uint32_t*)counts, (uint32_t)n_waves, s.totals,
+                                     s.mesh_path ? 3u : 2u, slot_map));
         st->units[DRT_K_FILM] += a.n_paths;
         if (gpix && s.d_out_gimg) {   // the gradient image: the same sums over the sample ranges, its own output
             const uint32_t gb = (uint32_t)grid_for(ctx, a.Pb);
@@ -690,8 +752,8 @@ int path_batch(Shard<R>& s)
                        s.totals, (uint32_t)n_waves, 0ull, 0ull, 1u);
     if (backward) {
         DRT_TIMED(s, DRT_K_GRADREDUCE,
-                  hipLaunchKernelGGL(k_gradreduce, dim3(s.n_fast > 0 ? s.n_fast * 3 : 1), dim3(DRT_BLOCK), 0, ctx->stream, gpart,
-                                     gpath, s.n_fast * 3, s.grad, DRT_FAST_PARAMS * 3));
+                  hipLaunchKernelGGL(k_gradreduce, dim3(gen ? ctx->n_params * 3 : (s.n_fast > 0 ? s.n_fast * 3 : 1)), dim3(DRT_BLOCK), 0, ctx->stream, gpart,
+                                     gpath, g_rows, s.grad, g_stride, slot_map));
         st->units[DRT_K_GRADREDUCE] += (uint64_t)gpath;
     }
     if (s.film) {

@@ -134,6 +134,11 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     }
     for (int i = 0; i < s->n_emitters; ++i)
         ds.emitter_param[i] = s->emitters[i].param;
+    // rows of the one-launch kernels' gradient tables: the parameters that require a gradient, in order (the mirrors' constant never)
+    for (int i = 0; i < DRT_PATH_LDS_PARAMS; ++i) {
+        const bool wants = i < s->n_params && (!s->requires_grad || s->requires_grad[i]);
+        ds.grad_slot[i] = wants ? (unsigned short)ds.n_grad_slots++ : (unsigned short)DRT_SLOT_NONE;
+    }
     // k_path (drt_path.h): the parameter ids of every shape in one word, and the intersection program
     ds.prog_ok = 1;
     bool has_mesh_shape = false;
@@ -272,6 +277,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_f, pf.data(), pf.size() * sizeof(float));
     if (rc == DRT_OK) rc = up((void**)&ctx->d_params_d, pd.data(), pd.size() * sizeof(double));
     const int n_dev_params = hf->n_params;   // user parameters + internal constants
+    ctx->n_grad_slots = hf->n_grad_slots;
     ctx->prog_ok = hf->prog_ok != 0;
     ctx->prog_sorted = hf->prog_sorted != 0;
     // The kernels hiprtc made for the PREVIOUS scene's shape kinds are of no use to a scene with other kinds: unload them (a
@@ -400,10 +406,12 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     return DRT_OK;
 }
 
-// new parameter values -> both compute types' vectors, in stream order (one launch that reads the context's pinned copy)
+// new parameter values -> both compute types' vectors, in stream order (one launch that reads the context's pinned copy;
+// grid-stride, coalesced: with an albedo per face -- 152,652 doubles -- a single block spent a millisecond on round trips over
+// the link)
 __global__ void __launch_bounds__(DRT_BLOCK) k_set_params(const double* __restrict__ h_params, int n, float* __restrict__ pf, double* __restrict__ pd)
 {
-    for (int i = threadIdx.x; i < n; i += DRT_BLOCK) {
+    for (int i = blockIdx.x * DRT_BLOCK + threadIdx.x; i < n; i += gridDim.x * DRT_BLOCK) {
         const double v = h_params[i];
         pf[i] = (float)v;
         pd[i] = v;
@@ -437,8 +445,17 @@ int update_params_one(drt_hip_ctx* ctx, const double* params)
         ctx->h_params_cap = n;
     }
     memcpy(ctx->h_params, params, n * sizeof(double));
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(DRT_BLOCK), 0, ctx->stream, (const double*)ctx->h_params, (int)n, ctx->d_params_f, ctx->d_params_d);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + DRT_BLOCK - 1) / DRT_BLOCK, (size_t)ctx->n_cu * 2);
+    hipLaunchKernelGGL(k_set_params, dim3(blocks ? blocks : 1), dim3(DRT_BLOCK), 0, ctx->stream, (const double*)ctx->h_params, (int)n, ctx->d_params_f, ctx->d_params_d);
     HIPCHK(ctx, hipGetLastError());
+    // The install runs in the CONTEXT's stream and the call does not wait for it.  Frames that overlap launch their path kernels
+    // on streams of their own (path_stream[lane]); those must not start before the new values are in place: the next frame of
+    // either lane waits for this event first (path_batch).
+    if (ctx->ev_params) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_params, ctx->stream));
+        ctx->params_pending[0] = ctx->params_pending[1] = true;
+    } else
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // (a context without the overlap machinery: the old, blocking form)
     return DRT_OK;
 }
 

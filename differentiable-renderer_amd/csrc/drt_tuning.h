@@ -19,6 +19,10 @@ struct Tuning {
     int path_spr = 0;              // DRT_HIP_PATH_SPR         samples per wave range of k_path; 0 = automatic (~112 waves per CU)
     int path_regen = -1;           // DRT_HIP_PATH_REGEN       1 / 0: force the regenerating / lockstep form of k_path; -1 = the cheaper by the library's estimate
     int path_regen_min = 8;        // DRT_HIP_PATH_REGEN_MIN   idle lanes it takes for the regenerating form to run the camera code
+    bool path_general = true;      // DRT_HIP_PATH_GENERAL     0: gradients of more than 8 parameters take the queue wavefront (tape + K6) instead of the one-launch kernels' general form
+    int gen_above = 4;             // DRT_HIP_GEN_ABOVE        scenes with more parameters than this take the general form (history + tables); up to 8 the register / column form exists too
+    int gen_hist_lds = -1;         // DRT_HIP_GEN_HIST_LDS     history words (four vertices each) per thread the general form keeps in LDS; -1 = 4 in the lockstep kernel, 0 in the regenerating ones
+    int gen_copies_log2 = -1;      // DRT_HIP_GEN_COPIES_LOG2  log2 of the copies a wave keeps of every row of its gradient table (general form); -1 = as many as fit, at most 16
     // ---- the queue wavefront
     long long batch_paths = 0;     // DRT_HIP_BATCH_PATHS      paths per batch; 0 = drt_render_params.batch_paths, else sized by the device's memory
     int region_size = 0;           // DRT_HIP_REGION_SIZE      slots per queue region (a wave's share of a queue); 0 = 256
@@ -55,6 +59,14 @@ inline const Tuning& tuning()
         v.path_spr = (int)num("DRT_HIP_PATH_SPR", 0);
         v.path_regen = (int)num("DRT_HIP_PATH_REGEN", -1);
         v.path_regen_min = (int)num("DRT_HIP_PATH_REGEN_MIN", 8);
+        v.path_general = !off("DRT_HIP_PATH_GENERAL");
+        v.gen_copies_log2 = (int)num("DRT_HIP_GEN_COPIES_LOG2", -1);
+        v.gen_above = (int)num("DRT_HIP_GEN_ABOVE", 4);
+        if (v.gen_above < 0) v.gen_above = 0;
+        if (v.gen_above > DRT_FAST_PARAMS) v.gen_above = DRT_FAST_PARAMS;
+        v.gen_hist_lds = (int)num("DRT_HIP_GEN_HIST_LDS", -1);
+        if (v.gen_hist_lds > 16) v.gen_hist_lds = 16;
+        if (v.gen_copies_log2 > 4) v.gen_copies_log2 = 4;
         v.batch_paths = num("DRT_HIP_BATCH_PATHS", 0);
         v.region_size = (int)num("DRT_HIP_REGION_SIZE", 0);
         v.shade_bounces = (int)num("DRT_HIP_SHADE_BOUNCES", 0);

@@ -151,6 +151,21 @@ SMALL = [
          absorb=0.17, seed=289, unbiased=True),
     dict(name="u9_unbiased_mesh10x12f5_29x28x3_depth64", scene="mesh10x12f5", width=29, height=28, spp=3, min_bounces=4,
          absorb=0.2, seed=66973654, unbiased=True),
+    # more parameters than the register form of the one-launch kernels holds (8): an albedo per shape of the reference's own
+    # scene (10 parameters), and rooms of 12 / 20 / 40 parameters, some albedos with zero channels (render.cpp:26-27 has such);
+    # the reference differentiates with respect to ANY number of Vector<T,3,true> (vector.hpp:185-191)
+    dict(name="p1_cornell_shapes_48x48x8_d8", scene="cornell_shapes", width=48, height=48, spp=8, min_bounces=8,
+         absorb=1.0, seed=23),
+    dict(name="p2_params12_40x40x6_rr_adj", scene="params12", width=40, height=40, spp=6, min_bounces=2,
+         absorb=0.3, seed=24, adjoint_seed=8, requires_grad=[True, True, False, True, True, True, True, False, True, True, True, True]),
+    dict(name="p3_params20_36x36x6_d12", scene="params20", width=36, height=36, spp=6, min_bounces=12,
+         absorb=1.0, seed=25),
+    dict(name="p4_params40_32x32x4_d6", scene="params40", width=32, height=32, spp=4, min_bounces=6,
+         absorb=1.0, seed=26, adjoint_seed=9),
+    dict(name="p5_unbiased_params12_28x28x4_rr", scene="params12", width=28, height=28, spp=4, min_bounces=2,
+         absorb=0.35, seed=27, unbiased=True),
+    dict(name="p6_cornell_shapes_default_roulette_40x40x8", scene="cornell_shapes", width=40, height=40, spp=8, min_bounces=1,
+         absorb=0.5, seed=28, adjoint_seed=10),
     # the reference's uniform() returns exactly 1.0 for path 2133's roulette draw at depth 5 (rand() == RAND_MAX): with absorb == 1
     # the path survives, p = 1 - absorb = 0, and the reference divides by it -- a NaN pixel and NaN gradients IN THE FIXTURE.
     # The restatement reproduces that; the device ends the path (the one deliberate deviation)

@@ -62,11 +62,18 @@ SMALL_GOLDENS = ["g2_cornell_32x32x4_d4", "g3_cornell_64x64x8_d8", "g3b_cornell_
                  "g4_specular_64x64x8_d8", "g4b_emissive_wall_48x32x8_adj", "g7_random3_40x30x6",
                  "g8_random8_36x36x6_d5", "g9_mesh6x8_40x30x4", "g10_mesh10x12f5_32x32x4_d4",
                  "g11_mesh40x40_48x48x4_d5", "g14_mesh10x12fall_36x30x4_rr", "m1_mirror_48x48x6_d6", "m2_mirror_wall_40x32x6_rr_adj"]
+# more parameters than the register form of the one-launch kernels holds (10, 12, 20, 40; vector.hpp:185-191 knows no limit)
+MANY_PARAM_GOLDENS = ["p1_cornell_shapes_48x48x8_d8", "p2_params12_40x40x6_rr_adj", "p3_params20_36x36x6_d12",
+                      "p4_params40_32x32x4_d6", "p6_cornell_shapes_default_roulette_40x40x8"]
+SMALL_GOLDENS += MANY_PARAM_GOLDENS
 
 
 UNBIASED_GOLDENS = ["u1_unbiased_cornell_40x30x4_rr", "u2_unbiased_cornell_48x48x4_d4",
                     "u3_unbiased_specular_32x32x4_adj", "u4_unbiased_emissive_wall_32x24x4",
                     "u5_unbiased_mesh10x12_24x24x3", "u6_unbiased_mirror_32x24x4_rr"]
+# ... of a 12-parameter room (the general form of the one-launch kernels).  In f32 ONE path of this frame takes another surface
+# (20 of its 33,892 segments differ, on the one-launch route and the queue route alike): pinned in f64, f32 route against route
+MANY_PARAM_UNBIASED_GOLDENS = ["p5_unbiased_params12_28x28x4_rr"]
 # the reference's own NaN: a roulette draw of exactly 1.0 at absorb == 1
 QUIRK_GOLDENS = ["q1_nan_mirror_wall_15x36x10_d5"]
 # long roulette chains under the unbiased operator: the deepest trace() stands exactly at depth 64, the library's limit

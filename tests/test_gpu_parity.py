@@ -811,7 +811,9 @@ def test_path_kernel_corner_cases(pkg, hip, oracle):
     np.testing.assert_array_equal(both, fwd)
     check_f32_heavy_tailed(hip, rcam, rrp, None, rscene.n_params, rref["image"], rref["grads"], rref["stats"]["segments"],
                            lambda p: oracle.render(rscene, rcam, rrp, backward=True, grad_image_param=p)["grad_image"])
-    # more than 8 parameters: forward-only still goes through k_path (no tangents), backward through the tape
+    # more than 8 parameters: forward-only goes through k_path without tangents, backward through its general form (vertex
+    # history + per-wave tables, tests/test_gpu_many_params.py) -- and through the tape where a launch per bounce is asked for
+    import dataclasses
     bscene = pkg.random_scene(3, specular=False, n_lights=6)
     assert bscene.n_params > 8
     bref = oracle.render(bscene, rcam, rrp, backward=True)
@@ -819,7 +821,11 @@ def test_path_kernel_corner_cases(pkg, hip, oracle):
     fwd, _, fst = hip.render(rcam, rrp, backward=False, f64=True)
     assert fst["kernels"]["path"]["launches"] == 1 and fst["segments"] == bref["stats"]["segments"]
     both, g, bst = hip.render(rcam, rrp, backward=True, f64=True)
-    assert bst["kernels"]["path"]["launches"] == 0 and grad_rel_err(g, bref["grads"]) < 1e-9
+    assert bst["kernels"]["path"]["launches"] == 1 and bst["kernels"]["backward"]["launches"] == 0
+    assert grad_rel_err(g, bref["grads"]) < 1e-9
+    np.testing.assert_array_equal(both, fwd)
+    _, gq, qst = hip.render(rcam, dataclasses.replace(rrp, bounces_per_launch=1), backward=True, f64=True)
+    assert qst["kernels"]["path"]["launches"] == 0 and qst["kernels"]["backward"]["launches"] > 0 and grad_rel_err(gq, bref["grads"]) < 1e-9
 
 
 def test_path_kernel_scene_with_many_shapes(pkg, hip, oracle):
