@@ -460,3 +460,70 @@ def test_pinned_caller_buffers_get_the_same_bits(pkg):
         np.testing.assert_array_equal(img, ref)
     finally:
         r.close()
+
+
+def test_update_params_is_ordered_before_overlapped_frames(pkg):
+    """drt_hip_update_params installs the new values with a launch in the context's stream and returns; frames that do not wait
+    (device pointers, asynchronous host frames) run their path kernels on streams of their own.  They must see the NEW values:
+    a scene with an albedo per face -- 19,804 parameters, an install launch of some tens of microseconds -- rendered right
+    behind every update, forward only and without an adjoint (nothing else orders the frame behind the context's stream),
+    against the synchronous call bit for bit.  And an asynchronous frame keeps its own copy of a PINNED adjoint image."""
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    scene = pkg.scene_by_name("mesh100x100fall")
+    assert scene.n_params == 4 + 19800
+    cam = pkg.cornell_camera(96, 64)
+    rp = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=5)
+    rs = np.random.RandomState(11)
+    base = np.asarray(scene.params, dtype=np.float64)
+    sets = []
+    for k in range(2):
+        p = base.copy()
+        p[4:] = rs.uniform(0.05 if k else 0.6, 0.35 if k else 0.95, (len(base) - 4, 3))      # (dark faces / bright faces: any stale value shows)
+        sets.append(p)
+    r = pkg.HipRenderer(0)
+    try:
+        r.upload_scene(scene)
+        want = []
+        for p in sets:
+            r.update_params(p)
+            img, _, st = r.render(cam, rp, backward=False)
+            assert st["kernels"]["path"]["launches"] == 1          # (k_path_mesh: the route whose frames overlap)
+            want.append(img.copy())
+        assert np.abs(want[0] - want[1]).max() > 1e-2
+        out = [torch.zeros((64, 96, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        for it in range(24):
+            k = it & 1
+            r.update_params(sets[k])
+            r.render_device(cam, rp, out[k].data_ptr(), 0, backward=False)             # returns after enqueueing
+            if it % 5 == 4:
+                r.update_params(sets[k ^ 1])                                            # (two updates in a row, two frames behind them)
+                r.render_device(cam, rp, out[k ^ 1].data_ptr(), 0, backward=False)
+                r.render_device(cam, rp, out[k ^ 1].data_ptr(), 0, backward=False)
+                r.synchronize()
+                torch.cuda.synchronize(dev)
+                np.testing.assert_array_equal(out[k ^ 1].cpu().numpy(), want[k ^ 1])
+            r.synchronize()
+            torch.cuda.synchronize(dev)
+            np.testing.assert_array_equal(out[k].cpu().numpy(), want[k])
+        # asynchronous host frames: the same, and a pinned adjoint image may be rewritten as soon as render_async has returned
+        scene2 = pkg.cornell_box()
+        r.upload_scene(scene2)
+        cam2 = pkg.cornell_camera(64, 48)
+        rp2 = pkg.RenderParams(spp=4, min_bounces=3, absorb=1.0, seed=2)
+        adj = np.ascontiguousarray(rs.uniform(-1, 2, (48, 64, 3)).astype(np.float32))
+        r.pin_host(adj)
+        a0 = adj.copy()
+        _, g_want, _ = r.render(cam2, rp2, backward=True, adjoint=a0)
+        handles = []
+        for i in range(3):
+            adj[...] = a0
+            handles.append(r.render_async(cam2, rp2, backward=True, adjoint=adj))
+            adj[...] = 1e6                                                              # the caller's next frame overwrites it
+        for h in handles:
+            _, g, _ = r.wait(h)
+            np.testing.assert_array_equal(g, g_want)
+        r.unpin_host(adj)
+    finally:
+        r.close()
