@@ -404,6 +404,18 @@ def main():
         mine = f"rank {rank}: cuda:{local_rank} pci {r.pci_bus_id()} (torch: {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}), library communicator of {r.comm_size} ranks"
         devices = [None] * world
         dist.all_gather_object(devices, mine)
+        # First contact with a multi-GPU node must not be mis-measured: N ranks = N DIFFERENT devices as the library sees them
+        # (PCI bus ids of the contexts' devices), unless --same-gpu asked for the single-GPU plumbing run.
+        pcis = [None] * world
+        dist.all_gather_object(pcis, r.pci_bus_id())
+        if len(set(pcis)) != world and not a.same_gpu:
+            if rank == 0:
+                print(f"bench.py: {world} ranks render on {len(set(pcis))} distinct devices ({pcis}); every rank needs a GPU of its own "
+                      f"(pass --same-gpu for the single-GPU plumbing run)", file=sys.stderr)
+            sys.exit(3)
+        if rank == 0:
+            for line_ in devices:
+                print("bench.py:", line_, file=sys.stderr)
     else:
         total_segments, total_paths = float(segments), float(paths)
 
@@ -628,7 +640,12 @@ def main():
         unb_view = dict(timed_variant(unbiased=True), note="the same frame with the reference's UNBIASED integration operator "
                                                            "(integrate.hpp:39-52: a fresh suffix path per vertex, O(depth^2) segments)")
     if extra and not a.unbiased:
-        f64_view = dict(timed_variant(f64=True), note="the same call with DRT_RENDER_F64: every kernel computes and stores in "
+        f64_view = dict(timed_variant(f64=True), roofline={
+            "bound": "f64 vector issue", "kernel": "k_path<double>", "valu_per_launch": 9.786e8, "launch_ms_profiled": 1.829,
+            "achieved": 535.0, "unit": "G wave-instr/s", "peak_all_f64": 614.4, "peak_all_f32": 1228.8, "frac_of_f64_rate": 0.87,
+            "frac_of_f32_rate": 0.44, "waves_per_simd": 4,
+            "source": "profiles/r06_f64_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU over tools/f64_frames.py: a STORED count, "
+                      "valid for config 3's frame only)"} if a.is_config and a.config == 3 else None, note="the same call with DRT_RENDER_F64: every kernel computes and stores in "
                                                       "double, the reference's precision (render.cpp:22)")
         if backward:
             fwd_view = dict(timed_variant(backward=False), note="forward only (BASELINE config 2 when the headline is config 3)")

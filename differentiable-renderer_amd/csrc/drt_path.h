@@ -228,6 +228,10 @@ struct Tangents {
 // A zero channel (red = (0.5, 0, 0), render.cpp:26): vertex j's own factor is the only zero of the channel iff zc_ch == 1, and
 // then d/dc of that channel is T_ch (the product WITHOUT the zero factor, which is what the lane's T holds) -- else 0.
 #define DRT_NP_ANY (-1)
+#ifndef DRT_F64_MIN_BLOCKS
+#define DRT_F64_MIN_BLOCKS 4         // blocks per CU the f64 lockstep diffuse k_path is compiled for: 128 registers instead of 142-145, four waves per
+                                     // SIMD instead of three (config 3 in f64: 1.938 -> 1.890 ms, an albedo per shape 2.19 -> 1.97; 3 and 5: no gain)
+#endif
 #ifndef DRT_GEN_TABLE
 #define DRT_GEN_TABLE 408            // elements of a wave's gradient table (rows x copies; 408 = 3 x DRT_PATH_LDS_PARAMS: one copy of every row at least)
 #endif
@@ -638,7 +642,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
 // (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
 template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false, bool LOSS = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? 5 : 1))
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? 5 : ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)

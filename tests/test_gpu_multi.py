@@ -527,3 +527,37 @@ def test_update_params_is_ordered_before_overlapped_frames(pkg):
         r.unpin_host(adj)
     finally:
         r.close()
+
+
+def test_group_over_all_visible_devices_equals_one_context(pkg, hip):
+    """First contact with a multi-GPU box: drt_hip_create_group over ALL visible devices (distinct devices: ONE grouped
+    ncclAllReduce over xGMI inside the library) against the single-context render -- image bit for bit (disjoint 16-row bands),
+    gradients to fp64 summation order.  Skipped where one device is visible (every box so far)."""
+    n = pkg.load_library().drt_hip_device_count()
+    if n < 2:
+        pytest.skip("one visible device")
+    scene = pkg.cornell_box()
+    cam = pkg.cornell_camera(256, 192)
+    rp = pkg.RenderParams(spp=8, min_bounces=6, absorb=1.0, seed=4, band_rows=16)
+    hip.upload_scene(scene)
+    want_img, want_g, want_st = hip.render(cam, rp, backward=True)
+    g = pkg.HipRenderer(list(range(n)))
+    try:
+        assert g.group_size == n and len({g.pci_bus_id(i) for i in range(n)}) == n
+        g.upload_scene(scene)
+        for _ in range(3):
+            img, grads, st = g.render(cam, rp, backward=True)
+            np.testing.assert_array_equal(img, want_img)
+            assert st["segments"] == want_st["segments"]
+            assert np.abs(grads - want_g).max() <= 1e-6 * np.abs(want_g).max()
+        # ... and a per-face scene (a 1.2 MB gradient vector through the same all-reduce) on the first two devices
+        mesh = pkg.scene_by_name("mesh40x40fall")
+        hip.upload_scene(mesh)
+        cam2 = pkg.cornell_camera(128, 96)
+        rp2 = pkg.RenderParams(spp=4, min_bounces=4, absorb=1.0, seed=6, band_rows=16)
+        _, mg, _ = hip.render(cam2, rp2, backward=True)
+        g.upload_scene(mesh)
+        _, gg, _ = g.render(cam2, rp2, backward=True)
+        assert np.abs(gg - mg).max() <= 1e-6 * np.abs(mg).max()
+    finally:
+        g.close()
