@@ -26,7 +26,7 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libdrt_hip.so")
 
 # ---- enums / flags (include/drt_hip.h) ------------------------------------------------------
-SHAPE_PLANE, SHAPE_SPHERE, SHAPE_MESH = 0, 1, 2
+SHAPE_PLANE, SHAPE_SPHERE, SHAPE_MESH, SHAPE_USER = 0, 1, 2, 3
 BXDF_DIFFUSE, BXDF_SPECULAR, BXDF_MIRROR = 0, 1, 2
 RENDER_BACKWARD = 0x1
 RENDER_DEVICE_OUT = 0x2
@@ -43,7 +43,7 @@ FRAMES_IN_FLIGHT = 4          # drt_hip_render_async: DRT_HIP_FRAMES_IN_FLIGHT
 MAX_DEPTH = 64
 K_RAYGEN, K_INTERSECT, K_SHADE, K_FILM, K_BACKWARD, K_GRADREDUCE, K_INTERSECT_MESH, K_PATH, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ["raygen", "intersect", "shade", "film", "backward", "gradreduce", "intersect_mesh", "path"]
-ABI_VERSION = 7
+ABI_VERSION = 8
 UNIQUE_ID_BYTES = 128
 
 STATUS_NAMES = {0: "DRT_OK", -1: "DRT_ERR_INVALID", -2: "DRT_ERR_NO_DEVICE", -3: "DRT_ERR_HIP",
@@ -69,13 +69,18 @@ class EmitterDesc(C.Structure):
     _fields_ = [("param", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ShapeKindDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("intersect_src", C.c_char_p), ("normal_src", C.c_char_p)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("n_shapes", C.c_int32), ("n_materials", C.c_int32), ("n_emitters", C.c_int32),
                 ("n_params", C.c_int32),
                 ("shapes", C.POINTER(ShapeDesc)), ("materials", C.POINTER(MaterialDesc)),
                 ("emitters", C.POINTER(EmitterDesc)), ("params", C.POINTER(C.c_double)),
                 ("requires_grad", C.POINTER(C.c_uint8)),
-                ("n_meshes", C.c_int32), ("reserved", C.c_int32), ("meshes", C.POINTER(MeshDesc))]
+                ("n_meshes", C.c_int32), ("n_kinds", C.c_int32), ("meshes", C.POINTER(MeshDesc)),
+                ("kinds", C.POINTER(ShapeKindDesc)), ("user_params", C.POINTER(C.c_double))]
 
 
 class CameraDesc(C.Structure):
@@ -128,6 +133,10 @@ class Scene:
     shapes: List[Tuple[int, int, int, Tuple[float, float, float, float]]] = field(default_factory=list)
     meshes: list = field(default_factory=list)   # (vertices f64 [nv,3], indices u32 [nt,3], face_material i32 [nt] | None)
     mesh_face_param: list = field(default_factory=list)   # per mesh: colour-parameter index per face i32 [nt] (-1: the material's) | None
+    # caller-defined analytic shapes (any Shape<T> subclass, shape.hpp:11-35; drt_shape_kind_desc): kinds = [(name, intersect
+    # source, normal source)], user = {shape index: (kind index, values 4..7 of the shape's record)}
+    kinds: list = field(default_factory=list)
+    user: dict = field(default_factory=dict)
 
     # Vector<T,3,true>(value, requires_grad), vector.hpp:228-234
     def parameter(self, rgb: Sequence[float], requires_grad: bool = True, name: str = "") -> int:
@@ -166,6 +175,19 @@ class Scene:
     def sphere(self, center: Sequence[float], radius: float, material: int = -1, emitter: int = -1) -> int:
         self.shapes.append((SHAPE_SPHERE, material, emitter,
                             (float(center[0]), float(center[1]), float(center[2]), float(radius))))
+        return len(self.shapes) - 1
+
+    def shape_kind(self, name: str, intersect_src: str, normal_src: str) -> int:
+        """A caller-defined shape KIND: the bodies of Shape<T>::intersect / normal (shape.hpp:14-22) as HIP source over a record
+        of 8 values (include/drt_hip.h: drt_shape_kind_desc).  -> its index for user_shape()."""
+        self.kinds.append((name, intersect_src, normal_src))
+        return len(self.kinds) - 1
+
+    def user_shape(self, kind: int, record: Sequence[float], material: int = -1, emitter: int = -1) -> int:
+        rec = [float(v) for v in record] + [0.0] * (8 - len(record))
+        assert 0 <= kind < len(self.kinds) and len(rec) == 8
+        self.shapes.append((SHAPE_USER, material, emitter, tuple(rec[:4])))
+        self.user[len(self.shapes) - 1] = (kind, tuple(rec[4:]))
         return len(self.shapes) - 1
 
     # extension: a triangle mesh standing for its triangles at this position of the scene
@@ -218,7 +240,7 @@ class Scene:
         shapes = (ShapeDesc * max(1, len(self.shapes)))()
         for i, (t, m, e, p) in enumerate(self.shapes):
             shapes[i].type, shapes[i].material, shapes[i].emitter = t, m, e
-            shapes[i].mesh = int(p[0]) if t == SHAPE_MESH else 0
+            shapes[i].mesh = int(p[0]) if t == SHAPE_MESH else (self.user[i][0] if t == SHAPE_USER else 0)
             for j in range(4):
                 shapes[i].p[j] = 0.0 if t == SHAPE_MESH else p[j]
         mats = (MaterialDesc * max(1, len(self.materials)))()
@@ -239,9 +261,16 @@ class Scene:
             meshes[i].face_material = fm.ctypes.data_as(C.POINTER(C.c_int32)) if fm is not None else None
             fp = self.mesh_face_param[i] if i < len(self.mesh_face_param) else None
             meshes[i].face_param = fp.ctypes.data_as(C.POINTER(C.c_int32)) if fp is not None else None
+        kinds = (ShapeKindDesc * max(1, len(self.kinds)))()
+        for i, (name, isrc, nsrc) in enumerate(self.kinds):
+            kinds[i].name, kinds[i].intersect_src, kinds[i].normal_src = name.encode(), isrc.encode(), nsrc.encode()
+        uq = np.zeros((max(1, len(self.shapes)), 4), dtype=np.float64)
+        for i, (_, q) in self.user.items():
+            uq[i] = q
         d = SceneDesc(len(self.shapes), len(self.materials), len(self.emitters), len(self.params),
-                      shapes, mats, emis, params, rg, len(self.meshes), 0, meshes)
-        return d, [shapes, mats, emis, params, rg, meshes, self.meshes, self.mesh_face_param]
+                      shapes, mats, emis, params, rg, len(self.meshes), len(self.kinds), meshes,
+                      kinds, uq.ctypes.data_as(C.POINTER(C.c_double)) if self.user else None)
+        return d, [shapes, mats, emis, params, rg, meshes, self.meshes, self.mesh_face_param, kinds, uq]
 
 
 def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front_mirror: bool = False,
@@ -296,6 +325,68 @@ def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front
             s.materials.append((ty, s.parameter(col, True, name), ex))
             s.shapes[shape] = (t, len(s.materials) - 1, e, p4)
     s.sphere((0., 3., 3.), 1., -1, emitter)                     # :47 light (no BxDF)
+    return s
+
+
+# ---- two analytic shapes the library does NOT know, as a user of the reference would write them (a Shape<T> subclass each:
+# oracle/ref_harness.cpp holds the same two as plugins of the unmodified reference; the CPU checker restates them) ----------
+DISC_INTERSECT = """
+    // record: centre p[0..2], normal p[3..5] (as given), radius p[6]
+    const V3<R> c = mk<R>(p[0], p[1], p[2]), n = mk<R>(p[3], p[4], p[5]);
+    const R den = dot(d, n);
+    if (den == R(0)) return false;
+    t = dot(c - o, n) / den;
+    if (!(t > R(0))) return false;
+    const V3<R> q = (o + d * t) - c;
+    return dot(q, q) <= p[6] * p[6];
+"""
+DISC_NORMAL = """
+    (void)P;
+    return mk<R>(p[3], p[4], p[5]);
+"""
+BOX_INTERSECT = """
+    // record: lower corner p[0..2], upper corner p[3..5]; slabs, nearest positive crossing
+    const R lo[3] = {p[0], p[1], p[2]}, hi[3] = {p[3], p[4], p[5]}, oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    R tn = R(-1e300), tf = R(1e300);
+    if (sizeof(R) == 4) { tn = R(-3e38); tf = R(3e38); }
+    for (int a = 0; a < 3; ++a) {
+        const R t1 = (lo[a] - oo[a]) / dd[a], t2 = (hi[a] - oo[a]) / dd[a];
+        const R ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+        tn = ta > tn ? ta : tn;
+        tf = tb < tf ? tb : tf;
+    }
+    if (!(tn <= tf)) return false;
+    t = tn > R(0) ? tn : tf;
+    return t > R(0);
+"""
+BOX_NORMAL = """
+    // the face whose plane the point lies closest to
+    const R lo[3] = {p[0], p[1], p[2]}, hi[3] = {p[3], p[4], p[5]}, pp[3] = {P.x, P.y, P.z};
+    int axis = 0;
+    R sign = R(-1), best = abs_r(pp[0] - lo[0]);
+    for (int a = 0; a < 3; ++a) {
+        const R dl = abs_r(pp[a] - lo[a]), dh = abs_r(pp[a] - hi[a]);
+        if (dl < best) { best = dl; axis = a; sign = R(-1); }
+        if (dh < best) { best = dh; axis = a; sign = R(1); }
+    }
+    return mk<R>(axis == 0 ? sign : R(0), axis == 1 ? sign : R(0), axis == 2 ? sign : R(0));
+"""
+
+
+def cornell_with_user_shapes(box: bool = True) -> Scene:
+    """The reference's scene (render.cpp:26-59) with two shapes of caller-defined kinds in it: a tilted diffuse disc with an
+    albedo of its own, and (box) an axis-aligned box -- shapes the library has no code for."""
+    s = cornell_box()
+    disc = s.shape_kind("disc", DISC_INTERSECT, DISC_NORMAL)
+    n = _normalize((0.2, 1.0, -0.3))
+    alb = s.diffuse(s.parameter((0.7, 0.6, 0.2), True, "disc_albedo"))
+    light = s.shapes.pop()                        # (the light sphere, render.cpp:47, stays last)
+    s.user_shape(disc, (0.9, -1.4, 3.3, n[0], n[1], n[2], 0.9), alb)
+    if box:
+        bk = s.shape_kind("box", BOX_INTERSECT, BOX_NORMAL)
+        s.user_shape(bk, (-2.4, -3.0, 2.2, -1.5, -1.9, 3.0), s.diffuse(s.parameter((0.3, 0.5, 0.8), True, "box_albedo")))
+        s.user_shape(disc, (0.0, 2.9, 4.6, 0.0, -1.0, 0.0, 0.5), -1, s.area_emitter(s.parameter((2.0, 1.5, 1.0), True, "disc_light")))
+    s.shapes.append(light)
     return s
 
 
@@ -440,6 +531,10 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box(front_specular=True)
     if name == "cornell_walls":
         return cornell_box(per_wall=True)
+    if name == "cornell_disc":
+        return cornell_with_user_shapes(box=False)
+    if name == "cornell_disc_box":
+        return cornell_with_user_shapes(box=True)
     if name == "cornell_shapes":
         return cornell_box(per_shape=True)
     if name.startswith("params"):        # params<n>[of<m>]: n parameters in the room of the m-parameter scene

@@ -66,6 +66,7 @@ struct drt_hip_ctx {
     uint64_t scene_work = 0;              // path-bounces this scene has rendered through k_path (reset by upload_scene)
     std::map<std::string, hipFunction_t> jit_fn;   // instantiations loaded on this device, by name expression (nullptr: failed)
     std::vector<hipModule_t> jit_modules;
+    std::string user_header;              // the scene's caller-defined shape kinds as the header hiprtc compiles them from (drt_prog.h); empty: none
     std::string jit_error;                // why the last specialisation failed (the kind-sorted program renders instead)
     double jit_ms = 0;                    // compile + load time spent by this context
     int n_params = 0, n_shapes = 0;   // n_params: as the device sees them (user parameters + internal constants)

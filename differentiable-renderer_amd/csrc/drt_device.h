@@ -24,7 +24,8 @@
 #define DRT_BLOCK 256
 #define DRT_WAVE 64
 #define DRT_PROG_SORTED_MAX DRT_MAX_SHAPES   // shapes the kind-sorted program in LDS covers (every analytic scene the ABI takes)
-enum { DRT_PK_PLANE = 0, DRT_PK_SPHERE = 1, DRT_PK_AX = 2, DRT_PK_AY = 3, DRT_PK_AZ = 4 };
+enum { DRT_PK_PLANE = 0, DRT_PK_SPHERE = 1, DRT_PK_AX = 2, DRT_PK_AY = 3, DRT_PK_AZ = 4,
+       DRT_PK_USER0 = 5 /* ... DRT_PK_USER0 + DRT_MAX_USER_KINDS - 1: caller-defined kinds (drt_shape_kind_desc); 7 = a mesh record */ };
 
 // ---- scene records (one instance per compute type, built by drt_hip_upload_scene) ----------
 template <typename R>
@@ -70,6 +71,8 @@ struct DevScene {
     // (Vector<T,3,true>(value, requires_grad), vector.hpp:228-234): grad_slot[p] = its row, DRT_SLOT_NONE = none
     int n_grad_slots;
     unsigned short grad_slot[DRT_PATH_LDS_PARAMS];
+    // caller-defined shapes (DRT_SHAPE_USER; DevShape::type = DRT_SHAPE_USER + kind): values 4..7 of their records
+    R user_q[DRT_MAX_SHAPES][4];
 };
 
 // ---- 16-byte (f32) / 32-byte (f64) queue lanes ----------------------------------------------

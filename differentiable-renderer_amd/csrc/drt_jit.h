@@ -37,12 +37,20 @@ struct Code {
 };
 
 // the hiprtc work itself (no lock held; ~0.3-0.7 s of one host core)
-inline void build(const std::string& arch, const std::string& name_expr, Code& c)
+// (user_header: the scene's caller-defined shape kinds as "drt_user_shapes.h" -- drt_prog.h includes it under DRT_USER_SHAPES --,
+//  empty: none)
+inline void build(const std::string& arch, const std::string& name_expr, const std::string& user_header, Code& c)
 {
     const auto t0 = std::chrono::steady_clock::now();
     hiprtcProgram prog = nullptr;
-    hiprtcResult r = hiprtcCreateProgram(&prog, "#include \"drt_path.h\"\n", "drt_jit.hip", drt_jit_n_headers, drt_jit_header_srcs,
-                                         drt_jit_header_names);
+    std::vector<const char*> srcs(drt_jit_header_srcs, drt_jit_header_srcs + drt_jit_n_headers);
+    std::vector<const char*> names(drt_jit_header_names, drt_jit_header_names + drt_jit_n_headers);
+    if (!user_header.empty()) {
+        srcs.push_back(user_header.c_str());
+        names.push_back("drt_user_shapes.h");
+    }
+    hiprtcResult r = hiprtcCreateProgram(&prog, user_header.empty() ? "#include \"drt_path.h\"\n" : "#define DRT_USER_SHAPES 1\n#include \"drt_path.h\"\n",
+                                         "drt_jit.hip", (int)srcs.size(), srcs.data(), names.data());
     if (r != HIPRTC_SUCCESS) {
         c.log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
         return;
@@ -82,10 +90,10 @@ inline void build(const std::string& arch, const std::string& name_expr, Code& c
 // build() behind a catch-all: nothing may leave a compile as an exception -- it would leave the cache entry "in progress" for
 // ever (every later compile() of that key waits on the condition variable) and cross the C ABI.  A failed allocation is a
 // failed compile.
-inline void build_guarded(const std::string& arch, const std::string& name_expr, Code& c) noexcept
+inline void build_guarded(const std::string& arch, const std::string& name_expr, const std::string& user_header, Code& c) noexcept
 {
     try {
-        build(arch, name_expr, c);
+        build(arch, name_expr, user_header, c);
     } catch (...) {
         c.ok = false;
         try {
@@ -138,10 +146,24 @@ inline State& state() { static State s; return s; }
 
 // compile the instantiation `name_expr` of a kernel template of drt_path.h for `arch` and WAIT for it (thread-safe: the
 // members of a group context launch from threads of their own; a compile already running in the background is joined)
-inline EntryPtr compile(const std::string& arch, const std::string& name_expr)
+// (the cache key carries the caller-defined kinds' source: two scenes with the same signature and other shape code are two kernels)
+inline std::string cache_key(const std::string& arch, const std::string& name_expr, const std::string& user_header)
+{
+    std::string key = arch + "|" + name_expr;
+    if (!user_header.empty()) {
+        unsigned long long h = 1469598103934665603ull;        // FNV-1a
+        for (unsigned char ch : user_header) { h ^= ch; h *= 1099511628211ull; }
+        char buf[40];
+        snprintf(buf, sizeof buf, "|user:%016llx:%zu", h, user_header.size());
+        key += buf;
+    }
+    return key;
+}
+
+inline EntryPtr compile(const std::string& arch, const std::string& name_expr, const std::string& user_header = std::string())
 {
     State& st = state();
-    const std::string key = arch + "|" + name_expr;
+    const std::string key = cache_key(arch, name_expr, user_header);
     std::unique_lock<std::mutex> lock(st.m);
     auto it = st.cache.find(key);
     if (it != st.cache.end()) {
@@ -154,7 +176,7 @@ inline EntryPtr compile(const std::string& arch, const std::string& name_expr)
     st.cache[key] = e;
     st.order.push_back(key);
     lock.unlock();
-    build_guarded(arch, name_expr, e->code);
+    build_guarded(arch, name_expr, user_header, e->code);
     lock.lock();
     e->done = true;
     st.cv.notify_all();
@@ -164,10 +186,10 @@ inline EntryPtr compile(const std::string& arch, const std::string& name_expr)
 // the same WITHOUT waiting: nullptr while the compile runs -- started on a thread of its own by the first call -- and the
 // code once it is there.  What DRT_SPECIALISE_AUTO uses: the frames of a render loop never wait for the compiler, they
 // run the kind-sorted program (same results, bit for bit) until the specialised one has arrived.
-inline EntryPtr poll(const std::string& arch, const std::string& name_expr)
+inline EntryPtr poll(const std::string& arch, const std::string& name_expr, const std::string& user_header = std::string())
 {
     State& st = state();
-    const std::string key = arch + "|" + name_expr;
+    const std::string key = cache_key(arch, name_expr, user_header);
     std::lock_guard<std::mutex> lock(st.m);
     auto it = st.cache.find(key);
     if (it != st.cache.end())
@@ -177,8 +199,8 @@ inline EntryPtr poll(const std::string& arch, const std::string& name_expr)
     st.cache[key] = e;
     st.order.push_back(key);
     try {
-        st.workers.emplace_back([arch, name_expr, e, &st] {
-            build_guarded(arch, name_expr, e->code);
+        st.workers.emplace_back([arch, name_expr, user_header, e, &st] {
+            build_guarded(arch, name_expr, user_header, e->code);
             {
                 std::lock_guard<std::mutex> l(st.m);
                 e->done = true;

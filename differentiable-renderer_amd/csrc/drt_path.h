@@ -108,6 +108,9 @@ struct PathSceneLds {
         int flat[DRT_MAX_SHAPES];
     } sc;
     R params[DRT_PATH_LDS_PARAMS * 3];
+#ifdef DRT_USER_SHAPES
+    R user_q[DRT_MAX_SHAPES][4];           // caller-defined shapes: values 4..7 of their records (the normal needs the whole record)
+#endif
 };
 
 template <typename R, bool ALL_LDS = false>
@@ -140,6 +143,10 @@ __device__ inline void stage_path_scene(PathSceneLds<R>& lds, const DevScene<R>*
         lds.sc.emitter_param[i] = sc->emitter_param[i];
     for (int i = threadIdx.x; i < ns; i += blockDim.x)
         lds.sc.flat[i] = sc->flat[i];
+#ifdef DRT_USER_SHAPES
+    for (int i = threadIdx.x; i < ns * 4; i += blockDim.x)
+        lds.user_q[i >> 2][i & 3] = sc->user_q[i >> 2][i & 3];
+#endif
     const int np = sc->n_params < DRT_PATH_LDS_PARAMS ? sc->n_params : DRT_PATH_LDS_PARAMS;
     for (int i = threadIdx.x; i < np * 3; i += blockDim.x)
         lds.params[i] = params[i];
@@ -528,7 +535,13 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
     //  which flips one grazing path of the 64 x 48 x 8 smoke frame: measured, not kept; the literal form stays)
     const V3<R> nsph = normalize(P - ctr);                            // shape.hpp:105-106
     const bool is_plane = sh.type == DRT_SHAPE_PLANE;                 // shape.hpp:58-59: the normal as stored
-    const V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
+    V3<R> nrm = mk<R>(is_plane ? ctr.x : nsph.x, is_plane ? ctr.y : nsph.y, is_plane ? ctr.z : nsph.z);
+#ifdef DRT_USER_SHAPES
+    if (sh.type >= DRT_SHAPE_USER) {                                  // a caller-defined kind: its own normal(point) (shape.hpp:22)
+        const R p8[8] = {sh.p[0], sh.p[1], sh.p[2], sh.p[3], lds.user_q[prim][0], lds.user_q[prim][1], lds.user_q[prim][2], lds.user_q[prim][3]};
+        nrm = user_normal<R>(sh.type - DRT_SHAPE_USER, p8, P);
+    }
+#endif
     if (vo) {
         vo->P = P; vo->nrm = nrm; vo->d = d;
         vo->ids = ids;

@@ -15,6 +15,29 @@ __device__ inline double prog_rcp(double x) { return div_r(1.0, x); }
 __device__ inline float prog_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ inline double prog_sqrt(double x) { return sqrt_r(x); }
 
+// ---- caller-defined kinds (DRT_SHAPE_USER, include/drt_hip.h: drt_shape_kind_desc) ------------------------------------------
+// Their intersect / normal bodies exist only in a kernel hiprtc compiles for the scene: drt_jit.h hands the compiler a header
+// "drt_user_shapes.h" made from the scene's sources --
+//     template <typename R> __device__ inline bool drt_user_intersect_0(const R* p, V3<R> o, V3<R> d, R& t) { ... }
+//     template <typename R> __device__ inline V3<R> drt_user_normal_0(const R* p, V3<R> P) { ... }       (and _1)
+// -- and defines DRT_USER_SHAPES.  The library's own build knows no such kind: a scene that holds one renders through its own
+// kernel or not at all (DRT_ERR_UNSUPPORTED).
+#ifdef DRT_USER_SHAPES
+#include "drt_user_shapes.h"
+template <int K, typename R>
+__device__ inline bool user_intersect(const R* p, V3<R> o, V3<R> d, R& t)
+{
+    if (K == 0) return drt_user_intersect_0<R>(p, o, d, t);
+    return drt_user_intersect_1<R>(p, o, d, t);
+}
+template <typename R>
+__device__ inline V3<R> user_normal(int kind, const R* p, V3<R> P)
+{
+    if (kind == 0) return drt_user_normal_0<R>(p, P);
+    return drt_user_normal_1<R>(p, P);
+}
+#endif
+
 template <typename R>
 __device__ inline void prog_accept(R t, int s, R& tmin, int& prim)
 {
@@ -119,13 +142,21 @@ struct ProgLds {               // the kind-sorted program in LDS (scenes whose k
 template <int NSIG, typename R = float>
 struct ProgRecs {
     typename Q4<R>::T r[NSIG > 0 ? NSIG : 1];
+#ifdef DRT_USER_SHAPES
+    typename Q4<R>::T q[NSIG > 0 ? NSIG : 1];      // values 4..7 of a caller-defined shape's record (the others' entries are never read)
+#endif
     const ProgLds* lds;
     template <typename SG>
     __device__ inline void load(const DevScene<R>* __restrict__ sc)
     {
 #pragma unroll
-        for (int s = 0; s < NSIG; ++s)
+        for (int s = 0; s < NSIG; ++s) {
             r[s] = *reinterpret_cast<const typename Q4<R>::T*>(sc->sorted[SG::pos(s)]);
+#ifdef DRT_USER_SHAPES
+            if (SG::kind(s) >= DRT_PK_USER0 && SG::kind(s) < DRT_PK_USER0 + DRT_MAX_USER_KINDS)
+                q[s] = *reinterpret_cast<const typename Q4<R>::T*>(sc->user_q[s]);
+#endif
+        }
     }
 };
 
@@ -144,6 +175,15 @@ __device__ inline HitRec<R> closest_hit_sig(const ProgRecs<SG::n, R>& recs, V3<R
         else if (kind == DRT_PK_AY) prog_test<DRT_PK_AY, R>(r, s, o, d, inv_d, tmin, prim);
         else if (kind == DRT_PK_AZ) prog_test<DRT_PK_AZ, R>(r, s, o, d, inv_d, tmin, prim);
         else if (kind == DRT_PK_PLANE) prog_test<DRT_PK_PLANE, R>(r, s, o, d, inv_d, tmin, prim);
+#ifdef DRT_USER_SHAPES
+        else if (kind >= DRT_PK_USER0 && kind < DRT_PK_USER0 + DRT_MAX_USER_KINDS) {
+            const typename Q4<R>::T q = recs.q[s];
+            const R p8[8] = {r.x, r.y, r.z, r.w, q.x, q.y, q.z, q.w};
+            R t;
+            if (kind == DRT_PK_USER0 ? user_intersect<0, R>(p8, o, d, t) : user_intersect<1, R>(p8, o, d, t))
+                prog_accept(t, s, tmin, prim);
+        }
+#endif
         else prog_test<DRT_PK_SPHERE, R>(r, s, o, d, inv_d, tmin, prim);
     }
     HitRec<R> h;

@@ -83,7 +83,7 @@ hipFunction_t jit_function(drt_hip_ctx* ctx, const std::string& name_expr, bool 
         return it->second;
     const auto t0 = std::chrono::steady_clock::now();
     hipFunction_t fn = nullptr;
-    const drt_jit::EntryPtr pe = wait ? drt_jit::compile(ctx->arch, name_expr) : drt_jit::poll(ctx->arch, name_expr);
+    const drt_jit::EntryPtr pe = wait ? drt_jit::compile(ctx->arch, name_expr, ctx->user_header) : drt_jit::poll(ctx->arch, name_expr, ctx->user_header);
     if (!pe)
         return nullptr;
     const drt_jit::Code& c = pe->code;
@@ -229,7 +229,7 @@ struct Shard {
 
 // "k_path<float, SPEC, NP, NC, KindSig<...>, REGEN[, LOSS]>" / "k_path_unbiased<float, SPEC, NP, KindSig<...>>": the name expression
 // of the f32 instantiation a render would launch, for the scene's own signature
-inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss, bool gen)
+inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss, bool gen, bool f64 = false)
 {
     const std::string sg = drt_jit::sig_type(ctx->prog_sig, ctx->n_shapes);
     const char* sp = ctx->has_specular ? "true" : "false";
@@ -237,11 +237,11 @@ inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool 
     char name[400];
     // (gen: the general form, any number of parameters: DRT_NP_ANY = -1)
     if (unbiased)
-        snprintf(name, sizeof name, "k_path_unbiased<float, %s, %d, %s>", sp, gen ? -1 : (ctx->n_params > 4 ? 8 : 4), sg.c_str());
+        snprintf(name, sizeof name, "k_path_unbiased<%s, %s, %d, %s>", f64 ? "double" : "float", sp, gen ? -1 : (ctx->n_params > 4 ? 8 : 4), sg.c_str());
     else {
         const int np = tangents ? (gen ? -1 : (ctx->n_params > 4 ? 8 : 4)) : 0;
         const int nc = tangents ? (gen ? 0 : (ctx->n_params > 4 ? 8 : (three ? 3 : 4))) : 0;
-        snprintf(name, sizeof name, "k_path<float, %s, %d, %d, %s, %s%s>", sp, np, nc, sg.c_str(), regen ? "true" : "false", loss ? ", true" : "");
+        snprintf(name, sizeof name, "k_path<%s, %s, %d, %d, %s, %s%s>", f64 ? "double" : "float", sp, np, nc, sg.c_str(), regen ? "true" : "false", loss ? ", true" : "");
     }
     return name;
 }
@@ -313,9 +313,10 @@ void shard_plan(Shard<R>& s)
         s.use_path = false;
         // (DRT_SPECIALISE_AUTO: no frame waits for the compiler -- the compile runs on the library's own thread from the first
         //  such frame on, and the tape route renders until it has delivered; DRT_SPECIALISE_NOW waits)
-        if (sizeof(R) == 4 && !ctx->emissive_bxdf && ctx->jit_mode >= DRT_SPECIALISE_AUTO) {
+        if ((sizeof(R) == 4 || !ctx->user_header.empty()) && !ctx->emissive_bxdf && ctx->jit_mode >= DRT_SPECIALISE_AUTO) {
             const bool gen_loss = ctx->n_params > tuning().gen_above && ctx->n_params <= DRT_PATH_LDS_PARAMS && (tuning().path_general || ctx->n_params <= DRT_FAST_PARAMS);
-            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true, gen_loss), ctx->jit_mode > DRT_SPECIALISE_AUTO);
+            s.loss_kernel = jit_function(ctx, path_kernel_name(ctx, true, false, s.path_regen, true, gen_loss, sizeof(R) == 8),
+                                         ctx->jit_mode > DRT_SPECIALISE_AUTO || !ctx->user_header.empty());
             s.use_path = s.loss_kernel != nullptr;
         }
     }
@@ -640,8 +641,16 @@ int path_batch(Shard<R>& s)
     const bool tangents = backward || s.gimg_param >= 0;
     hipFunction_t jit = s.loss_kernel;
     ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(s.D > 0 ? s.D : 1);
-    if (!jit && !builtin && !s.mesh_path && ctx->jit_mode > 0 && sizeof(R) == 4 && (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
+    if (!jit && !builtin && !s.mesh_path && ctx->jit_mode > 0 && sizeof(R) == 4 && ctx->user_header.empty() &&
+        (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
         jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen), ctx->jit_mode > 1);
+    if (!ctx->user_header.empty() && !jit) {
+        // caller-defined shape kinds: their code exists only in a kernel compiled for this scene -- made now, waited for, in either
+        // compute type (shard_plan has checked that the context may compile)
+        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen, sizeof(R) == 8), true);
+        if (!jit)
+            return fail(ctx, DRT_ERR_UNSUPPORTED, ("render: the scene's caller-defined shape kinds did not compile: " + ctx->jit_error).c_str());
+    }
     st->path_program = builtin ? DRT_PROGRAM_BUILTIN : (jit ? DRT_PROGRAM_SPECIALISED : DRT_PROGRAM_SORTED);
     int rc;
     if ((rc = timing_begin(ctx, s.timing, DRT_K_PATH)) != DRT_OK) return rc;
@@ -1071,6 +1080,16 @@ int render_impl(drt_hip_ctx* ctx, const drt_camera_desc* cam, const drt_render_p
     s.d_params = sizeof(R) == 4 ? (const R*)ctx->d_params_f : (const R*)ctx->d_params_d;
     memcpy(&s.bvh, sizeof(R) == 4 ? (const void*)&ctx->bvh_f : (const void*)&ctx->bvh_d, sizeof s.bvh);
     shard_plan(s);
+    if (!ctx->user_header.empty()) {
+        // caller-defined shape kinds live in the one-launch path kernel hiprtc compiles for the scene, nowhere else
+        if (ctx->jit_mode <= 0)
+            return fail(ctx, DRT_ERR_UNSUPPORTED, "render: the scene holds caller-defined shape kinds (DRT_SHAPE_USER) and this context may not compile "
+                                                  "(drt_hip_set_specialisation / DRT_HIP_JIT)");
+        if (!s.use_path || s.mesh_path)
+            return fail(ctx, DRT_ERR_UNSUPPORTED, "render: caller-defined shape kinds render on the one-launch path kernels only -- not with "
+                                                  "bounces_per_launch >= 1, DRT_RENDER_UNFUSED, a gradient image of more than 8 parameters, or more "
+                                                  "parameters than the kernels stage (136)");
+    }
     int rc;
     if (ctx->adj_pending && s.d_adjoint) {
         // a host-buffer render's adjoint image sits in pinned memory: the one-launch routes read a pixel's seed ONCE per lane, so

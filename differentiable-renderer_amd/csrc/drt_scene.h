@@ -96,7 +96,10 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         flat += s->shapes[i].type == DRT_SHAPE_MESH ? s->meshes[s->shapes[i].mesh].n_triangles : 1;
         for (int j = 0; j < 4; ++j)
             ds.shapes[i].p[j] = (R)s->shapes[i].p[j];
-        ds.shapes[i].type = s->shapes[i].type;
+        ds.shapes[i].type = s->shapes[i].type == DRT_SHAPE_USER ? DRT_SHAPE_USER + s->shapes[i].mesh : s->shapes[i].type;
+        if (s->shapes[i].type == DRT_SHAPE_USER)
+            for (int j = 0; j < 4; ++j)
+                ds.user_q[i][j] = s->user_params ? (R)s->user_params[(size_t)i * 4 + j] : R(0);
         if (s->shapes[i].type == DRT_SHAPE_PLANE) ds.plane_mask |= 1ull << i;
         if (s->shapes[i].type == DRT_SHAPE_SPHERE) ds.sphere_mask |= 1ull << i;
         ds.shapes[i].material = s->shapes[i].material;
@@ -141,7 +144,7 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     }
     // k_path (drt_path.h): the parameter ids of every shape in one word, and the intersection program
     ds.prog_ok = 1;
-    bool has_mesh_shape = false;
+    bool has_mesh_shape = false, has_user_shape = false;
     int kinds[DRT_MAX_SHAPES];
     R recs[DRT_MAX_SHAPES][4];
     for (int i = 0; i < s->n_shapes; ++i) {
@@ -153,6 +156,12 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         recs[i][0] = recs[i][1] = recs[i][2] = recs[i][3] = R(0);   //  k_shade's tail tests the analytic rest)
         if (s->shapes[i].type == DRT_SHAPE_MESH) {
             has_mesh_shape = true;
+        } else if (s->shapes[i].type == DRT_SHAPE_USER) {
+            // a caller-defined kind: tested by the kernel hiprtc compiles for this scene (drt_prog.h), by no other program
+            has_user_shape = true;
+            kinds[i] = DRT_PK_USER0 + s->shapes[i].mesh;
+            for (int j = 0; j < 4; ++j)
+                recs[i][j] = (R)s->shapes[i].p[j];
         } else {
             int kind = s->shapes[i].type == DRT_SHAPE_SPHERE ? DRT_PK_SPHERE : DRT_PK_PLANE;
             R rec[4] = {(R)s->shapes[i].p[0], (R)s->shapes[i].p[1], (R)s->shapes[i].p[2], (R)s->shapes[i].p[3]};
@@ -175,7 +184,7 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
     }
     {   // the kind-sorted copy (stable: scene order inside a kind)
         int n = 0;
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < DRT_PK_USER0 + DRT_MAX_USER_KINDS; ++k) {     // (the user kinds' records too: KindSig::pos counts them)
             ds.kind_begin[k] = n;
             for (int i = 0; i < s->n_shapes; ++i)
                 if (kinds[i] == k) {
@@ -184,10 +193,10 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
                     ds.sorted_shape[n++] = i;
                 }
         }
-        for (int k = 5; k < 8; ++k)
+        for (int k = DRT_PK_USER0 + DRT_MAX_USER_KINDS; k < 8; ++k)
             ds.kind_begin[k] = n;
     }
-    ds.prog_sorted = ds.prog_ok;                   // the sorted program is valid (for the analytic shapes)
+    ds.prog_sorted = has_user_shape ? 0 : ds.prog_ok;   // the sorted program is valid (for the analytic shapes; it knows no caller-defined kind)
     if (has_mesh_shape)
         ds.prog_ok = 0;                         // ... but k_path is not for scenes with a mesh
     params.assign((size_t)ds.n_params * 3, R(1));
@@ -207,9 +216,21 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
         (s->n_shapes && !s->shapes) || (s->n_materials && !s->materials) ||
         (s->n_emitters && !s->emitters) || (s->n_params && !s->params))
         return fail(ctx, DRT_ERR_INVALID, "scene: bad counts or null arrays");
+    bool any_user = false, any_mesh = false;
     for (int i = 0; i < s->n_shapes; ++i) {
         const drt_shape_desc& sh = s->shapes[i];
-        if (sh.type == DRT_SHAPE_MESH) {
+        if (sh.type == DRT_SHAPE_USER) {
+            any_user = true;
+            if (s->n_kinds < 1 || s->n_kinds > DRT_MAX_USER_KINDS || !s->kinds)
+                return fail(ctx, DRT_ERR_INVALID, "scene: a DRT_SHAPE_USER shape needs 1 .. DRT_MAX_USER_KINDS entries in drt_scene_desc.kinds");
+            if (sh.mesh < 0 || sh.mesh >= s->n_kinds)
+                return fail(ctx, DRT_ERR_INVALID, "scene: shape kind index out of range");
+            if (!s->kinds[sh.mesh].intersect_src || !s->kinds[sh.mesh].normal_src)
+                return fail(ctx, DRT_ERR_INVALID, "scene: a shape kind without intersect / normal source");
+        }
+        any_mesh = any_mesh || sh.type == DRT_SHAPE_MESH;
+        if (sh.type == DRT_SHAPE_USER) {
+        } else if (sh.type == DRT_SHAPE_MESH) {
             if (sh.mesh < 0 || sh.mesh >= s->n_meshes || !s->meshes)
                 return fail(ctx, DRT_ERR_INVALID, "scene: mesh index out of range");
             const drt_mesh_desc& m = s->meshes[sh.mesh];
@@ -242,6 +263,25 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     for (int i = 0; i < s->n_emitters; ++i)
         if (s->emitters[i].param < 0 || s->emitters[i].param >= s->n_params)
             return fail(ctx, DRT_ERR_INVALID, "scene: emitter parameter index out of range");
+    if (any_user && any_mesh)
+        return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: caller-defined shape kinds and a triangle mesh in one scene (the kinds live in the one-launch "
+                                              "path kernel compiled for the scene; mesh scenes walk their BVH in kernels of the library's own)");
+    // the caller-defined kinds as the header hiprtc compiles them from (drt_prog.h: DRT_USER_SHAPES)
+    std::string user_header;
+    if (any_user) {
+        for (int k = 0; k < DRT_MAX_USER_KINDS; ++k) {
+            const bool have = k < s->n_kinds;
+            char head[320];
+            snprintf(head, sizeof head, "// kind %d: %s\ntemplate <typename R> __device__ inline bool drt_user_intersect_%d(const R* p, V3<R> o, V3<R> d, R& t)\n{\n",
+                     k, have && s->kinds[k].name ? s->kinds[k].name : "(none)", k);
+            user_header += head;
+            user_header += have ? s->kinds[k].intersect_src : "(void)p; (void)o; (void)d; (void)t; return false;";
+            snprintf(head, sizeof head, "\n}\ntemplate <typename R> __device__ inline V3<R> drt_user_normal_%d(const R* p, V3<R> P)\n{\n", k);
+            user_header += head;
+            user_header += have ? s->kinds[k].normal_src : "(void)p; return P;";
+            user_header += "\n}\n";
+        }
+    }
 
     // (drt_hip_wait hands a frame over with the scene's parameter count and requires_grad flags: they must still be the ones
     //  the frame was rendered with)
@@ -283,7 +323,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     // The kernels hiprtc made for the PREVIOUS scene's shape kinds are of no use to a scene with other kinds: unload them (a
     // long-lived context that sees scene after scene -- an editor, a fuzzer -- otherwise keeps one loaded module per signature
     // and variant until it is destroyed).  Nothing of this context is running: the streams were waited for above.
-    if (memcmp(ctx->prog_sig, sig, sizeof ctx->prog_sig) != 0 || ctx->n_shapes != s->n_shapes) {
+    if (memcmp(ctx->prog_sig, sig, sizeof ctx->prog_sig) != 0 || ctx->n_shapes != s->n_shapes || ctx->user_header != user_header) {
         for (int i = 0; i < 2; ++i)
             if (ctx->path_stream[i])
                 (void)hipStreamSynchronize(ctx->path_stream[i]);
@@ -294,6 +334,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     }
     for (int i = 0; i < 4; ++i)
         ctx->prog_sig[i] = sig[i];
+    ctx->user_header = user_header;
     ctx->max_colour_param = -1;
     for (int i = 0; i < hf->n_materials; ++i)
         ctx->max_colour_param = std::max(ctx->max_colour_param, hf->materials[i].param);

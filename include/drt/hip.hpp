@@ -15,6 +15,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -62,6 +63,8 @@ struct FlatScene {
     std::vector<drt_mesh_desc> meshes;
     std::vector<std::vector<double>> mesh_vertices;
     std::vector<std::vector<uint32_t>> mesh_indices;
+    std::vector<drt_shape_kind_desc> kinds;    // caller-defined shape kinds (ShapeKind::User), by kind_name
+    std::vector<double> user_params;           // n_shapes x 4: values 4..7 of the shapes' records
 
     drt_scene_desc desc() const
     {
@@ -76,8 +79,10 @@ struct FlatScene {
         d.params = params.data();
         d.requires_grad = requires_grad.data();
         d.n_meshes = (int32_t)meshes.size();
-        d.reserved = 0;
+        d.n_kinds = (int32_t)kinds.size();
         d.meshes = meshes.data();
+        d.kinds = kinds.data();
+        d.user_params = kinds.empty() ? nullptr : user_params.data();
         return d;
     }
 
@@ -97,6 +102,13 @@ struct FlatScene {
             mix(&sh.type, sizeof sh.type); mix(&sh.material, sizeof sh.material); mix(&sh.emitter, sizeof sh.emitter);
             mix(&sh.mesh, sizeof sh.mesh); mix(sh.p, sizeof sh.p);
         }
+        mix_n(kinds.size());
+        for (const drt_shape_kind_desc& k : kinds) {
+            mix(k.intersect_src, std::strlen(k.intersect_src));
+            mix(k.normal_src, std::strlen(k.normal_src));
+        }
+        if (!kinds.empty())
+            mix(user_params.data(), user_params.size() * sizeof(double));
         mix_n(materials.size());
         for (const drt_material_desc& m : materials) {
             mix(&m.type, sizeof m.type); mix(&m.param, sizeof m.param); mix(&m.exponent, sizeof m.exponent);
@@ -158,10 +170,30 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
                     is.push_back(t[c]);
             f.mesh_vertices.push_back(std::move(vs));
             f.mesh_indices.push_back(std::move(is));
+        } else if (rec.kind == ShapeKind::User) {
+            // any other analytic shape: its own intersect / normal, compiled into the scene's path kernel (ABI v8)
+            if (!rec.kind_name || !rec.intersect_src || !rec.normal_src)
+                throw std::runtime_error("drt::hip: a ShapeKind::User record needs kind_name, intersect_src and normal_src");
+            int k = -1;
+            for (std::size_t i = 0; i < f.kinds.size(); ++i)
+                if (std::strcmp(f.kinds[i].name, rec.kind_name) == 0)
+                    k = (int)i;
+            if (k < 0) {
+                if (f.kinds.size() >= DRT_MAX_USER_KINDS)
+                    throw std::runtime_error("drt::hip: more caller-defined shape kinds in one scene than the device path takes (DRT_MAX_USER_KINDS)");
+                drt_shape_kind_desc kd{rec.kind_name, rec.intersect_src, rec.normal_src};
+                k = (int)f.kinds.size();
+                f.kinds.push_back(kd);
+            }
+            sd.type = DRT_SHAPE_USER;
+            sd.mesh = k;
         } else
-            throw std::runtime_error("drt::hip: shape type has no device record (describe() not implemented)");
+            throw std::runtime_error("drt::hip: shape type has no device record (describe() reports neither one of the library's kinds "
+                                     "nor ShapeKind::User with its source)");
         for (int i = 0; i < 4; ++i)
             sd.p[i] = rec.p[i];
+        for (int i = 0; i < 4; ++i)
+            f.user_params.push_back(rec.q[i]);
         sd.material = -1;
         sd.emitter = -1;
         if (BxDF<T>* b = shape->bxdf()) {

@@ -15,11 +15,19 @@
 
 namespace drt {
 
-enum class ShapeKind { Plane, Sphere, Mesh, Other };
+enum class ShapeKind { Plane, Sphere, Mesh, Other, User };
 
+// What a shape tells the device path about itself.  Plane / Sphere / Mesh: the library's own kinds.  User: ANY other analytic
+// shape -- a subclass describes itself with a record of up to 8 values and the bodies of its intersect() / normal() as HIP source
+// over that record (include/drt_hip.h: drt_shape_kind_desc says what the source may use); drt::hip::render has it compiled into the
+// scene's path kernel.  Shapes of one class share one `kind_name` and one pair of sources.
 struct ShapeRecord {
     ShapeKind kind = ShapeKind::Other;
-    double p[4] = {0, 0, 0, 0};   // Plane: normal.xyz, offset   Sphere: center.xyz, radius
+    double p[4] = {0, 0, 0, 0};   // Plane: normal.xyz, offset   Sphere: center.xyz, radius   User: values 0..3 of the record
+    double q[4] = {0, 0, 0, 0};   // User: values 4..7
+    const char* kind_name = nullptr;        // User
+    const char* intersect_src = nullptr;    // User: body of  template <typename R> bool intersect(const R* p, V3<R> o, V3<R> d, R& t)
+    const char* normal_src = nullptr;       // User: body of  template <typename R> V3<R> normal(const R* p, V3<R> P)
 };
 
 template <typename T>

@@ -61,7 +61,7 @@ typedef unsigned long size_t;
 extern "C" {
 #endif
 
-#define DRT_HIP_ABI_VERSION 7
+#define DRT_HIP_ABI_VERSION 8
 
 typedef enum drt_status {
     DRT_OK = 0,
@@ -77,7 +77,9 @@ typedef enum drt_status {
 /* ---- scene description (host-side POD, doubles: the reference computes in double,
  *      src/render.cpp:22; the device converts to its compute type) ------------------------ */
 
-enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2 };
+enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2,
+       DRT_SHAPE_USER = 3 /* a shape of a caller-defined KIND (drt_shape_kind_desc): any analytic Shape<T> subclass,
+                             shape.hpp:11-35 -- `mesh` = index into drt_scene_desc.kinds */ };
 enum { DRT_BXDF_DIFFUSE = 0, DRT_BXDF_SPECULAR = 1,
        DRT_BXDF_MIRROR = 2 /* bxdf.hpp:126-144 repaired: f = 1/cos, dir = reflect(dir_in, n), pdf 1; param = -1;
                               its sample discards two draws (see drt_rng_u31) */ };
@@ -88,8 +90,29 @@ typedef struct drt_shape_desc {
     int32_t emitter;   /* index into emitters,  -1 = no emitter (shape.hpp:29-30) */
     int32_t mesh;      /* MESH: index into meshes; otherwise ignored */
     double p[4];       /* PLANE: normal.xyz (NOT normalised, shape.hpp:58-59), offset
-                          SPHERE: center.xyz, radius   MESH: unused */
+                          SPHERE: center.xyz, radius   MESH: unused
+                          USER: values 0..3 of the shape's record (4..7: drt_scene_desc.user_params) */
 } drt_shape_desc;
+
+/* A caller-defined analytic shape (ABI v8): what a subclass of the reference's Shape<T> plugin interface (shape.hpp:11-35:
+ * virtual intersect(orig, dir, double& t) and normal(point)) becomes on the device.  The two function BODIES are HIP source,
+ * compiled at run time (hiprtc) into the scene's own path kernel next to the library's plane and sphere tests:
+ *     template <typename R> bool intersect(const R* p, V3<R> o, V3<R> d, R& t) { <intersect_src> }
+ *     template <typename R> V3<R> normal(const R* p, V3<R> P)                  { <normal_src> }
+ * p = the shape's record of 8 values (drt_shape_desc.p + user_params), o / d = ray origin and (unit) direction, P = the hit
+ * point; R is float or double (DRT_RENDER_F64).  Available: V3<R> with .x .y .z and + - * (component-wise, and by a scalar),
+ * mk<R>(x, y, z), dot, cross, normalize, sqrt_r, rsqrt_r, div_r, abs_r, min_r, max_r, fma_r (csrc/drt_device.h).  `intersect`
+ * returns whether the ray hits at a t > 0 it stores (the contract of shape.hpp:49-56); the closest hit over all shapes and the
+ * first-shape-wins tie rule stay the library's (pathtracer.hpp:72-89).  At most DRT_MAX_USER_KINDS kinds per scene.  Scenes
+ * with such shapes render on the one-launch path kernels (analytic scenes, any number of parameters, biased and unbiased
+ * operator); a context that may not compile (drt_hip_set_specialisation(-1 / 0)) and scenes that also hold a mesh answer
+ * DRT_ERR_UNSUPPORTED. */
+#define DRT_MAX_USER_KINDS 2
+typedef struct drt_shape_kind_desc {
+    const char* name;            /* for messages (and for test checkers that know the kind by name) */
+    const char* intersect_src;
+    const char* normal_src;
+} drt_shape_kind_desc;
 
 /* Triangle mesh: an EXTENSION behind the Shape<T> plugin surface (the reference has no
  * triangles).  A MESH shape stands for its triangles listed in index order at
@@ -129,8 +152,11 @@ typedef struct drt_scene_desc {
     const drt_emitter_desc* emitters;
     const double* params;                /* n_params x 3 (RGB) */
     const uint8_t* requires_grad;        /* n_params, NULL = all true */
-    int32_t n_meshes, reserved;
+    int32_t n_meshes;
+    int32_t n_kinds;                     /* (ABI <= 7: reserved, 0) caller-defined shape kinds; 0: the fields below are not read */
     const drt_mesh_desc* meshes;
+    const drt_shape_kind_desc* kinds;    /* n_kinds */
+    const double* user_params;           /* n_shapes x 4: values 4..7 of every shape's record (read for USER shapes only), or NULL: zeros */
 } drt_scene_desc;
 
 typedef struct drt_camera_desc {

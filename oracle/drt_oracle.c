@@ -82,8 +82,72 @@ uint32_t drt_oracle_rng_u31(uint32_t seed, uint64_t path, uint32_t n)
 }
 
 /* ---- shapes, shape.hpp:49-59 (Plane), 78-106 (Sphere) ------------------------------------ */
+/* ---- caller-defined kinds (DRT_SHAPE_USER): this CHECKER knows the two test kinds by name -- "disc" and "box", the Disc and
+ * AABox plugins of oracle/ref_harness.cpp restated operation for operation (the product compiles the caller's own source) ---- */
+static const drt_scene_desc* g_scene;     /* (set by drt_oracle_render: the kinds' names and records 4..7) */
+static int user_kind_is(const drt_shape_desc* s, const char* name)
+{
+    return s->type == DRT_SHAPE_USER && g_scene && s->mesh >= 0 && s->mesh < g_scene->n_kinds && g_scene->kinds[s->mesh].name &&
+           strcmp(g_scene->kinds[s->mesh].name, name) == 0;
+}
+static void user_record(const drt_shape_desc* s, double p[8])
+{
+    const long i = (long)(s - g_scene->shapes);
+    for (int j = 0; j < 4; ++j) {
+        p[j] = s->p[j];
+        p[4 + j] = g_scene->user_params ? g_scene->user_params[i * 4 + j] : 0.0;
+    }
+}
+static int user_intersect(const drt_shape_desc* s, v3 orig, v3 dir, double* t)
+{
+    double p[8];
+    user_record(s, p);
+    if (user_kind_is(s, "disc")) {
+        v3 c = v3_make(p[0], p[1], p[2]), n = v3_make(p[3], p[4], p[5]);
+        double den = v3_dot(dir, n);
+        if (den == 0)
+            return 0;
+        *t = v3_dot(v3_sub(c, orig), n) / den;
+        if (!(*t > 0))
+            return 0;
+        v3 q = v3_sub(v3_add(orig, v3_scale(dir, *t)), c);
+        return v3_dot(q, q) <= p[6] * p[6];
+    }
+    /* box */
+    const double lo[3] = {p[0], p[1], p[2]}, hi[3] = {p[3], p[4], p[5]}, oo[3] = {orig.v[0], orig.v[1], orig.v[2]}, dd[3] = {dir.v[0], dir.v[1], dir.v[2]};
+    double tn = -1e300, tf = 1e300;
+    for (int a = 0; a < 3; ++a) {
+        const double t1 = (lo[a] - oo[a]) / dd[a], t2 = (hi[a] - oo[a]) / dd[a];
+        const double ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+        tn = ta > tn ? ta : tn;
+        tf = tb < tf ? tb : tf;
+    }
+    if (!(tn <= tf))
+        return 0;
+    *t = tn > 0 ? tn : tf;
+    return *t > 0;
+}
+static v3 user_normal(const drt_shape_desc* s, v3 point)
+{
+    double p[8];
+    user_record(s, p);
+    if (user_kind_is(s, "disc"))
+        return v3_make(p[3], p[4], p[5]);
+    const double lo[3] = {p[0], p[1], p[2]}, hi[3] = {p[3], p[4], p[5]}, pp[3] = {point.v[0], point.v[1], point.v[2]};
+    int axis = 0;
+    double sign = -1, best = fabs(pp[0] - lo[0]);
+    for (int a = 0; a < 3; ++a) {
+        const double dl = fabs(pp[a] - lo[a]), dh = fabs(pp[a] - hi[a]);
+        if (dl < best) { best = dl; axis = a; sign = -1; }
+        if (dh < best) { best = dh; axis = a; sign = 1; }
+    }
+    return v3_make(axis == 0 ? sign : 0.0, axis == 1 ? sign : 0.0, axis == 2 ? sign : 0.0);
+}
+
 static int shape_intersect(const drt_shape_desc* s, v3 orig, v3 dir, double* t)
 {
+    if (s->type == DRT_SHAPE_USER)
+        return user_intersect(s, orig, dir, t);
     if (s->type == DRT_SHAPE_PLANE) {
         v3 n = v3_make(s->p[0], s->p[1], s->p[2]);
         double h = v3_dot(orig, n) - s->p[3];
@@ -117,6 +181,8 @@ static int shape_intersect(const drt_shape_desc* s, v3 orig, v3 dir, double* t)
 
 static v3 shape_normal(const drt_shape_desc* s, v3 point)
 {
+    if (s->type == DRT_SHAPE_USER)
+        return user_normal(s, point);
     if (s->type == DRT_SHAPE_PLANE)
         return v3_make(s->p[0], s->p[1], s->p[2]);
     return v3_normalize(v3_sub(point, v3_make(s->p[0], s->p[1], s->p[2])));
@@ -471,11 +537,15 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
         return DRT_ERR_INVALID;
     for (int i = 0; i < scene->n_shapes; ++i) {
         const drt_shape_desc* s = &scene->shapes[i];
-        if ((s->type != DRT_SHAPE_PLANE && s->type != DRT_SHAPE_SPHERE && s->type != DRT_SHAPE_MESH) ||
+        if ((s->type != DRT_SHAPE_PLANE && s->type != DRT_SHAPE_SPHERE && s->type != DRT_SHAPE_MESH && s->type != DRT_SHAPE_USER) ||
             s->material >= scene->n_materials || s->emitter >= scene->n_emitters ||
             (s->type == DRT_SHAPE_MESH && (s->mesh < 0 || s->mesh >= scene->n_meshes)))
             return DRT_ERR_INVALID;
+        g_scene = scene;
+        if (s->type == DRT_SHAPE_USER && !user_kind_is(s, "disc") && !user_kind_is(s, "box"))
+            return DRT_ERR_UNSUPPORTED;      /* (a kind this checker has no restatement of) */
     }
+    g_scene = scene;
     const int W = cam->width, H = cam->height, spp = rp->spp;
     const int unbiased = (oracle_flags & DRT_ORACLE_UNBIASED) != 0;
     const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;

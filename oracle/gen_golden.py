@@ -166,6 +166,14 @@ SMALL = [
          absorb=0.35, seed=27, unbiased=True),
     dict(name="p6_cornell_shapes_default_roulette_40x40x8", scene="cornell_shapes", width=40, height=40, spp=8, min_bounces=1,
          absorb=0.5, seed=28, adjoint_seed=10),
+    # shapes the library has NO code for (a Shape<T> subclass each, shape.hpp:11-35): the Disc and AABox plugins of the harness
+    # inside the unmodified reference path tracer; the device compiles the same bodies from the caller's HIP source
+    dict(name="s1_disc_box_48x48x8_d6", scene="cornell_disc_box", width=48, height=48, spp=8, min_bounces=6,
+         absorb=1.0, seed=31, dump_paths=96),
+    dict(name="s2_disc_box_40x32x8_rr_adj", scene="cornell_disc_box", width=40, height=32, spp=8, min_bounces=1,
+         absorb=0.5, seed=32, adjoint_seed=11),
+    dict(name="s3_unbiased_disc_32x32x4_rr", scene="cornell_disc", width=32, height=32, spp=4, min_bounces=2,
+         absorb=0.35, seed=33, unbiased=True),
     # the reference's uniform() returns exactly 1.0 for path 2133's roulette draw at depth 5 (rand() == RAND_MAX): with absorb == 1
     # the path survives, p = 1 - absorb = 0, and the reference divides by it -- a NaN pixel and NaN gradients IN THE FIXTURE.
     # The restatement reproduces that; the device ends the path (the one deliberate deviation)

@@ -153,8 +153,12 @@ def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, d
                 for t in range(len(idx)):
                     f.write(f"{int(idx[t][0])} {int(idx[t][1])} {int(idx[t][2])}" + (f" {int(fm[t])}" if fm is not None else "") + "\n")
         f.write(f"shapes {len(scene.shapes)}\n")
-        for t, m, e, p in scene.shapes:
-            f.write(f"{t} {m} {e} {p[0]!r} {p[1]!r} {p[2]!r} {p[3]!r}\n")
+        for i, (t, m, e, p) in enumerate(scene.shapes):
+            extra = ""
+            if t == 3:      # a shape of a caller-defined kind: the harness holds the same class as a plugin of the reference, by name
+                kind, q = scene.user[i]
+                extra = f" {scene.kinds[kind][0]} {q[0]!r} {q[1]!r} {q[2]!r} {q[3]!r}"
+            f.write(f"{t} {m} {e} {p[0]!r} {p[1]!r} {p[2]!r} {p[3]!r}{extra}\n")
         v = [cam.vfov, *cam.eye, *cam.forward, *cam.right, *cam.up]
         f.write(f"camera {cam.width} {cam.height} " + " ".join(repr(float(x)) for x in v) + "\n")
         f.write(f"render {rp.spp} {rp.min_bounces} {rp.absorb!r} {rp.seed} {rng_mode} {int(backward)} {dump_paths}\n")

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = C.CDLL(pkg.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(lib, s), f"libdrt_hip.so does not export {s}"
-    assert pkg.load_library().drt_hip_abi_version() == pkg.ABI_VERSION == 7   # v2 meshes, v3 queue statistics, v4 groups + communicators, v5 asynchronous host-buffer renders, v6 scene-specialised path kernels, v7 pinned caller buffers
+    assert pkg.load_library().drt_hip_abi_version() == pkg.ABI_VERSION == 8   # v2 meshes, v3 queue statistics, v4 groups + communicators, v5 asynchronous host-buffer renders, v6 scene-specialised path kernels, v7 pinned caller buffers, v8 caller-defined shape kinds
     assert sorted(pkg._ABI_SYMBOLS) == declared_symbols()
 
 

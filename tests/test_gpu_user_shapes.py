@@ -1,0 +1,112 @@
+"""Shapes of caller-defined KINDS on the device (ABI v8: drt_shape_kind_desc): what a subclass of the reference's Shape<T> plugin
+interface (shape.hpp:11-35) becomes -- its intersect / normal bodies as HIP source, compiled by hiprtc into the scene's own path
+kernel.  The two kinds here, a disc and an axis-aligned box, are shapes the library has NO code for; the fixtures come from the
+same two classes compiled as plugins against the UNMODIFIED reference headers (oracle/ref_harness.cpp: Disc, AABox; fixtures s1-s3).
+Tolerances: f64 mode 1e-9 of the largest gradient component with identical segment counts; f32 1e-4 (north star)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from conftest import USER_SHAPE_GOLDENS, USER_SHAPE_UNBIASED_GOLDENS, case_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, want):
+    return float(np.abs(got - want).max() / np.abs(want).max())
+
+
+@pytest.mark.parametrize("name", USER_SHAPE_GOLDENS + USER_SHAPE_UNBIASED_GOLDENS)
+def test_caller_defined_shapes_match_the_reference_plugins(pkg, hip, name):
+    g = load_golden(name)
+    case = g["case"]
+    scene, cam, rp, adjoint = case_inputs(pkg, case)
+    unbiased = bool(case.get("unbiased"))
+    assert scene.kinds and scene.user
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True, adjoint=adjoint, f64=True, unbiased=unbiased)
+    assert st["kernels"]["path"]["launches"] == 1 and st["kernels"]["shade"]["launches"] == 0
+    assert st["path_program"] == "specialised"             # the kernel hiprtc compiled for this scene: nothing else knows a disc
+    assert st["segments"] == int(g["segments"])
+    assert rel(grads, g["grads"]) < 1e-9
+    np.testing.assert_allclose(img, g["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    i32, g32, st32 = hip.render(cam, rp, backward=True, adjoint=adjoint, unbiased=unbiased)
+    bad = np.abs(i32.astype(np.float64) - g["image"]).max(-1) > 2e-4 * np.abs(g["image"]).max()
+    assert abs(st32["segments"] - int(g["segments"])) <= 64
+    if not bad.any():
+        assert rel(g32, g["grads"]) <= 1e-4
+    else:                                                  # (a path that took another surface under f32 rounding)
+        assert bad.sum() <= 2 and rel(g32, g["grads"]) <= 2e-2
+    # forward only
+    f32, _, fst = hip.render(cam, rp, backward=False)
+    assert fst["kernels"]["path"]["launches"] == 1
+    np.testing.assert_allclose(f32, i32, rtol=2e-6, atol=1e-9)     # (two kernels, compiled apart: the last bit may differ)
+
+
+def test_caller_defined_shapes_every_form_of_the_path_kernel(pkg, hip, oracle):
+    """lockstep and regenerating forms, a depth cap, the gradient image, the per-sample loss, shards -- against the restatement
+    (oracle/drt_oracle.c knows the two test kinds by name)."""
+    scene = pkg.scene_by_name("cornell_disc_box")
+    cam = pkg.Camera(44, 36).look_at((0.3, -0.2, 0.1), (0.1, -0.3, 1))
+    hip.upload_scene(scene)
+    adj = np.random.RandomState(2).uniform(-1, 2, (36, 44, 3)).astype(np.float32)
+    for kw in (dict(min_bounces=5, absorb=1.0), dict(min_bounces=1, absorb=0.5), dict(min_bounces=2, absorb=0.2, max_depth=9)):
+        rp = pkg.RenderParams(spp=6, seed=41, **kw)
+        want = oracle.render(scene, cam, rp, backward=True, adjoint=adj)
+        img, grads, st = hip.render(cam, rp, backward=True, adjoint=adj, f64=True)
+        assert st["kernels"]["path"]["launches"] == 1 and st["segments"] == want["stats"]["segments"]
+        assert rel(grads, want["grads"]) < 1e-9
+        np.testing.assert_allclose(img, want["image"].astype(np.float32), rtol=2e-7, atol=1e-12)
+    rp = pkg.RenderParams(spp=6, seed=42, min_bounces=4, absorb=1.0)
+    # the per-pixel gradient image of the disc's albedo (README.md:142-145)
+    p = scene.param_names.index("disc_albedo")
+    want = oracle.render(scene, cam, rp, backward=True, grad_image_param=p)
+    _, gimg, st = hip.render_gradient_image(cam, rp, p, f64=True)
+    assert st["kernels"]["path"]["launches"] == 1
+    np.testing.assert_allclose(gimg, want["grad_image"].astype(np.float32), rtol=1e-5, atol=1e-9)
+    # the unbiased operator, and the shards of a frame
+    want = oracle.render(scene, cam, rp, backward=True, unbiased=True)
+    _, gu, st = hip.render(cam, rp, backward=True, unbiased=True, f64=True)
+    assert st["segments"] == want["stats"]["segments"] and rel(gu, want["grads"]) < 1e-9
+    whole = oracle.render(scene, cam, rp, backward=True)
+    total = np.zeros_like(whole["grads"])
+    for shard in range(3):
+        _, gs, _ = hip.render(cam, dataclasses.replace(rp, shard=shard, n_shards=3, band_rows=4), backward=True, f64=True)
+        total += gs
+    assert rel(total, whole["grads"]) < 1e-9
+
+
+def test_caller_defined_shapes_where_they_cannot_render(pkg, hip):
+    scene = pkg.scene_by_name("cornell_disc")
+    cam = pkg.cornell_camera(32, 24)
+    rp = pkg.RenderParams(spp=2, seed=1, min_bounces=3, absorb=1.0)
+    hip.upload_scene(scene)
+    hip.render(cam, rp, backward=True)
+    # one launch per bounce = the queue wavefront: its kernels are the library's own
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_UNSUPPORTED.*one-launch"):
+        hip.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True)
+    # a context that may not compile
+    hip.set_specialisation(pkg.SPECIALISE_NEVER)
+    try:
+        with pytest.raises(pkg.DrtHipError, match="DRT_ERR_UNSUPPORTED.*may not compile"):
+            hip.render(cam, rp, backward=True)
+    finally:
+        hip.set_specialisation(pkg.SPECIALISE_AUTO)
+    # source that does not compile: the compiler's message comes back, the context stays usable
+    broken = pkg.cornell_box()
+    k = broken.shape_kind("broken", "this is not HIP;", "return P;")
+    broken.user_shape(k, (0, 0, 2, 0, 0, 1, 0.5), 2)
+    hip.upload_scene(broken)
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_UNSUPPORTED.*did not compile"):
+        hip.render(cam, rp, backward=True)
+    # with a mesh in the scene
+    mixed = pkg.scene_by_name("mesh6x8")
+    k = mixed.shape_kind("disc", pkg.DISC_INTERSECT, pkg.DISC_NORMAL)
+    mixed.user_shape(k, (0, 0, 2, 0, 0, 1, 0.5), 2)
+    with pytest.raises(pkg.DrtHipError, match="DRT_ERR_UNSUPPORTED.*mesh"):
+        hip.upload_scene(mixed)
+    # the library's own shapes render as before on the same context
+    hip.upload_scene(pkg.cornell_box())
+    img, g, st = hip.render(cam, rp, backward=True)
+    assert st["kernels"]["path"]["launches"] == 1 and np.isfinite(g).all()

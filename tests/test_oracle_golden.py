@@ -5,10 +5,11 @@ import numpy as np
 import pytest
 
 from conftest import (DEPTH_LIMIT_GOLDENS, LOSS_GOLDENS, MANY_PARAM_UNBIASED_GOLDENS, QUIRK_GOLDENS, SMALL_GOLDENS, UNBIASED_GOLDENS,
+                      USER_SHAPE_GOLDENS, USER_SHAPE_UNBIASED_GOLDENS,
                       case_inputs, load_golden)
 
 
-@pytest.mark.parametrize("name", SMALL_GOLDENS + ["g6_libc_64x64x8_d4", "m3_mirror_libc_32x32x4_d4"])
+@pytest.mark.parametrize("name", SMALL_GOLDENS + USER_SHAPE_GOLDENS + ["g6_libc_64x64x8_d4", "m3_mirror_libc_32x32x4_d4"])
 def test_oracle_bit_exact_vs_reference_golden(pkg, oracle, name):
     g = load_golden(name)
     case = g["case"]
@@ -67,7 +68,7 @@ def test_gradient_image_bit_exact(pkg, oracle, name):
     np.testing.assert_allclose(r["grad_image"].sum((0, 1)) * rp.spp, r["grads"][p], rtol=1e-12)
 
 
-@pytest.mark.parametrize("name", UNBIASED_GOLDENS + DEPTH_LIMIT_GOLDENS + MANY_PARAM_UNBIASED_GOLDENS)
+@pytest.mark.parametrize("name", UNBIASED_GOLDENS + DEPTH_LIMIT_GOLDENS + MANY_PARAM_UNBIASED_GOLDENS + USER_SHAPE_UNBIASED_GOLDENS)
 def test_unbiased_integrator_bit_exact(pkg, oracle, name):
     """integrate(..., unbiased=true): fixtures from the reference's own integration operator driven
     by the harness tracer (the reference's Pathtracer hard-codes the biased one).  Forward image
