@@ -525,9 +525,10 @@ def main():
     #  needs none, is what the top level carries then)
     top = valu_view if (issue_bound and valu_view) else hbm_view
     roofline = {"bound": ("valu-issue (paths are register-resident: the kernel moves almost no bytes)" if register_resident
-                          else ("valu-issue at partial lanes (divergent BVH walk out of L2: 37 of 64 lanes per vector instruction, the vector pipes 75 % busy by "
-                                "SQ_ACTIVE_INST_VALU, 0.37 of the nominal issue rate by instruction count -- profiles/r05_walk_counters.txt; "
-                                "far from the HBM roof)" if dominant == "intersect_mesh" else "hbm")),
+                          else ("the CU's L1 path (divergent BVH walk out of L2; by the TCP's and TD's own counters, profiles/r06_walk_counters.txt: "
+                                "the L1 clocked 93 % of a launch, 31 % of the cycles stalled behind lines in flight, 780 cycles per wave-load against "
+                                "230 for an L2 hit, the data-return unit 86 % busy) -- neither roof is near: vector issue 0.37 of nominal (SQ_INSTS_VALU "
+                                "x 2 cycles, 37 of 64 lanes per instruction; the fraction printed here), HBM 0.10" if dominant == "intersect_mesh" else "hbm")),
                 "kernel": "k_" + dominant, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                 "frac": top["frac"],
                 "traffic": traffic,

@@ -18,7 +18,9 @@
 #define DRT_MAX_EMITTERS 64
 #define DRT_LDS_PARAMS 256       // parameters staged in LDS by K3/K6 (more: read from L2)
 #define DRT_FAST_PARAMS 8        // parameter ids accumulated in registers by K6
+#ifndef DRT_PATH_LDS_PARAMS
 #define DRT_PATH_LDS_PARAMS 136  // parameters the one-launch kernels stage in LDS: every analytic scene's (<= 64 materials + 64 emitters + the mirrors' constant)
+#endif
 #define DRT_SLOT_NONE 0xFFFFu    // DevScene::grad_slot of a parameter nobody wants a gradient for
 #define DRT_ID_NONE 0xFFFFu
 #define DRT_BLOCK 256

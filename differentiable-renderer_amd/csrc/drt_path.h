@@ -235,6 +235,9 @@ struct Tangents {
 // A zero channel (red = (0.5, 0, 0), render.cpp:26): vertex j's own factor is the only zero of the channel iff zc_ch == 1, and
 // then d/dc of that channel is T_ch (the product WITHOUT the zero factor, which is what the lane's T holds) -- else 0.
 #define DRT_NP_ANY (-1)
+#ifndef DRT_REGEN_MIN_BLOCKS
+#define DRT_REGEN_MIN_BLOCKS 5       // blocks per CU the f32 regenerating diffuse k_path is compiled for
+#endif
 #ifndef DRT_F64_MIN_BLOCKS
 #define DRT_F64_MIN_BLOCKS 4         // blocks per CU the f64 lockstep diffuse k_path is compiled for: 128 registers instead of 142-145, four waves per
                                      // SIMD instead of three (config 3 in f64: 1.938 -> 1.890 ms, an albedo per shape 2.19 -> 1.97; 3 and 5: no gain)
@@ -655,7 +658,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
 // (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
 template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false, bool LOSS = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? 5 : ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS) : ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)
@@ -665,7 +668,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     typedef typename Q4<R>::T R4;
     typedef typename Q2<R>::T R2;
     __shared__ PathSceneLds<R> lds;
-    __shared__ double s_red[DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];
+    __shared__ double s_red[REGEN ? 1 : DRT_BLOCK / DRT_WAVE][DRT_FAST_PARAMS * 3];   // (REGEN: the block's gradient partials reuse the pixel sums' table)
     __shared__ TangentLds<R> s_tl;
     constexpr bool GEN = NP == DRT_NP_ANY;                // any number of parameters: history + per-wave tables (see Tangents<R, DRT_NP_ANY>)
     __shared__ typename PickT<GEN, GenBlock<R>, NoLds>::T s_gen;
@@ -715,11 +718,13 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
     const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
     ProgRecs<SG::n, R> recs;
-    __shared__ ProgLds s_prog;
-    recs.lds = &s_prog;
+    // (the kind-sorted program's 1.3 KB only where it runs: with the kinds compiled in they are what stands between the
+    //  regenerating kernel and a sixth block per CU)
+    __shared__ typename PickT<(SG::n == 0), ProgLds, NoLds>::T s_prog;
+    recs.lds = reinterpret_cast<const ProgLds*>(&s_prog);
     if (SG::n > 0)
         recs.template load<SG>(sc);
-    if (sizeof(R) == 4 && SG::n == 0) {
+    if constexpr (sizeof(R) == 4 && SG::n == 0) {
         const DevScene<float>* scf = reinterpret_cast<const DevScene<float>*>(sc);
         if (threadIdx.x < DRT_PROG_SORTED_MAX) {
             s_prog.rec[threadIdx.x] = *reinterpret_cast<const float4*>(scf->sorted[threadIdx.x]);
@@ -906,6 +911,11 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     if (NP > 0) {
         // block reduction in fp64: thread -> wave (shuffles) -> block (LDS), fixed order; K7 adds the blocks
         const int wv = threadIdx.x / DRT_WAVE;
+        double (*red)[DRT_FAST_PARAMS * 3] = s_red;
+        if (REGEN) {
+            __syncthreads();                               // (every thread has read its pixel's sums out of s_film)
+            red = reinterpret_cast<double (*)[DRT_FAST_PARAMS * 3]>(&s_film[0][0]);
+        }
 #pragma unroll
         for (int r = 0; r < NP * 3; ++r) {
             double v = (double)tg.acc[r * DRT_BLOCK];
@@ -913,14 +923,14 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
             for (int o2 = DRT_WAVE / 2; o2 > 0; o2 >>= 1)
                 v += __shfl_down(v, o2);
             if (lane == 0)
-                s_red[wv][r] = v;
+                red[wv][r] = v;
         }
         __syncthreads();
         if (threadIdx.x < DRT_FAST_PARAMS * 3) {
             double v = 0;
             if ((int)threadIdx.x < NP * 3)
                 for (int ww = 0; ww < DRT_BLOCK / DRT_WAVE; ++ww)
-                    v += s_red[ww][threadIdx.x];
+                    v += red[ww][threadIdx.x];
             gpart[(size_t)blockIdx.x * (DRT_FAST_PARAMS * 3) + threadIdx.x] = v;
         }
     }

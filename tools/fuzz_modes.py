@@ -27,7 +27,10 @@ rg.set_specialisation(pkg.SPECIALISE_GENERIC)
 rj.set_specialisation(pkg.SPECIALISE_NOW)
 n_bitwise = 0
 scenes = ["cornell", "cornell_specular", "cornell_walls", "cornell_emissive_wall", "cornell_mirror_wall", "random3", "random7",
-          "mesh6x8", "mesh10x12f5"]
+          "mesh6x8", "mesh10x12f5",
+          # round 6: more parameters than the register form holds (the general form of the one-launch kernels against the tape), and
+          # shapes of caller-defined kinds (the one-launch kernels only: no second route to compare, the restatement is the check)
+          "cornell_shapes", "params12", "params40", "mesh10x12f12", "cornell_disc_box"]
 worst = 0.0
 t0 = time.time()
 for case in range(n_cases):
@@ -57,7 +60,8 @@ for case in range(n_cases):
     r.upload_scene(scene)
     t1 = time.time()
     a = r.render(cam, rp, backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
-    q = r.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
+    user_kinds = bool(scene.kinds)
+    q = a if user_kinds else r.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
     f = r.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
     dt = time.time() - t1
     assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all() and np.isfinite(f[0]).all() and np.isfinite(f[1]).all(), (case, name, kw)
@@ -76,7 +80,13 @@ for case in range(n_cases):
     worst = max(worst, err)
     # (a chain that went the other way on one route carries whatever weight it has where it diverged: 1e-6 covers what round 4's
     #  90,000 cases showed; round 5's 6,000 met one glossy scene, unbiased, absorption 0.1, whose diverged chain weighed 6.6e-6)
-    assert err < (1e-9 if a[2]["segments"] == q[2]["segments"] else (1e-4 if (deep and unbiased) else 1e-6)), (case, name, kw, unbiased, err, a[2]["segments"], q[2]["segments"])
+    # (the bound stays where the measurements are: 1e-6, and 2e-5 for the deep unbiased chains -- 3 x the one case; every case that
+    #  needed more than 1e-9 is LOGGED with what replays it)
+    bound = 1e-9 if a[2]["segments"] == q[2]["segments"] else (2e-5 if (deep and unbiased) else 1e-6)
+    if err >= 1e-9:
+        print(f"{case:3d} {name:22s} EXCUSED: the routes' segment counts differ ({a[2]['segments']} / {q[2]['segments']}), gradient difference "
+              f"{err:.2e} (bound {bound:g}); replay: tools/fuzz_modes.py {n_cases} {sys.argv[2] if len(sys.argv) > 2 else 1}, case {case}: {kw} unbiased {unbiased}", flush=True)
+    assert err < bound, (case, name, kw, unbiased, err, a[2]["segments"], q[2]["segments"])
     np.testing.assert_allclose(a[0], q[0], rtol=1e-6, atol=1e-9)
     assert a[2]["capped_paths"] == q[2]["capped_paths"] or a[2]["segments"] != q[2]["segments"], (case, name, kw, a[2]["capped_paths"], q[2]["capped_paths"])
     # ... and both against the CPU restatement of the reference (which knows the extensions: max_depth, shards): ray counts
@@ -126,7 +136,7 @@ for case in range(n_cases):
             gs = max(1e-300, float(np.abs(og["grad_image"]).max()))
             assert float(np.abs(gi[1] - og["grad_image"]).max() / gs) < 1e-6, (case, name, kw, "gradient image", gp)
         extra += f" gimg{gp}"
-    if not name.startswith("mesh") and "bounces_per_launch" not in kw:
+    if not name.startswith("mesh") and "bounces_per_launch" not in kw and not user_kinds:
         rg.upload_scene(scene); rj.upload_scene(scene)
         fg = rg.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
         fj = rj.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
