@@ -636,6 +636,35 @@ def main():
             except Exception as exc:
                 generic_view = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # `many_parameters`: config 3's frame with an albedo per SHAPE of the reference's scene (10 parameters instead of 4; the reference
+    # differentiates with respect to any number, vector.hpp:185-191): serial frames through the one-launch kernel's general form
+    # (vertex history + per-wave gradient tables) -- until round 6 such a scene took the queue wavefront (2.40 ms per frame)
+    many_view = None
+    if rank == 0 and world == 1 and not a.no_extra_views and a.is_config and a.config == 3 and backward:
+        try:
+            sm = pkg.scene_by_name("cornell_shapes")
+            rm = pkg.HipRenderer(local_rank)
+            rm.set_specialisation(pkg.SPECIALISE_NOW)
+            rm.upload_scene(sm)
+            gm = torch.zeros((sm.n_params, 3), dtype=torch.float64, device=dev)
+            rps_m = dataclasses.replace(rp, flags=rp.flags | pkg.RENDER_SERIAL)
+            for _ in range(5):
+                rm.render_device(cam, rps_m, out_rgb.data_ptr(), gm.data_ptr(), backward=True, sync=False)
+            rm.synchronize(); torch.cuda.synchronize(dev)
+            tm = time.perf_counter()
+            for _ in range(a.steps):
+                rm.render_device(cam, rps_m, out_rgb.data_ptr(), gm.data_ptr(), backward=True, sync=False)
+            rm.synchronize(); torch.cuda.synchronize(dev)
+            dtm = (time.perf_counter() - tm) / a.steps
+            stm = rm.render_device(cam, rps_m, out_rgb.data_ptr(), gm.data_ptr(), backward=True, timing=True)
+            many_view = {"scene": "cornell_shapes", "n_params": sm.n_params, "value": round(stm["segments"] / dtm * 1e-6, 2), "unit": "Mray/s",
+                         "ms_per_step": round(dtm * 1e3, 4), "launches": {k: v["launches"] for k, v in stm["kernels"].items() if v["launches"]},
+                         "note": "serial frames (DRT_RENDER_SERIAL), an albedo parameter per shape of render.cpp's scene; compare `serial_frame` "
+                                 "(4 parameters); profiles/r06_param_cliff_before.txt holds the 2.40 ms of the queue wavefront"}
+            rm.close()
+        except Exception as exc:
+            many_view = {"error": f"{type(exc).__name__}: {exc}"}
+
     f64_view = fwd_view = unb_view = None
     if extra and not a.unbiased and backward and world == 1:
         unb_view = dict(timed_variant(unbiased=True), note="the same frame with the reference's UNBIASED integration operator "
@@ -879,7 +908,7 @@ def main():
             "serial_frame": serial_view, "generic_program": generic_view,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "host_buffers": host_buffers,
             "preheat_ms": a.preheat_ms, "preheat_frames": preheat_frames,
-            "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view, "two_contexts": two_ctx_view,
+            "f64": f64_view, "fwd_only": fwd_view, "unbiased": unb_view, "two_contexts": two_ctx_view, "many_parameters": many_view,
         }
     # teardown in the same order on every rank: the library's communicator first (all ranks are still here), then the
     # launcher's process group, then the context

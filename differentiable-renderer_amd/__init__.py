@@ -240,7 +240,7 @@ class Scene:
         shapes = (ShapeDesc * max(1, len(self.shapes)))()
         for i, (t, m, e, p) in enumerate(self.shapes):
             shapes[i].type, shapes[i].material, shapes[i].emitter = t, m, e
-            shapes[i].mesh = int(p[0]) if t == SHAPE_MESH else (self.user[i][0] if t == SHAPE_USER else 0)
+            shapes[i].mesh = int(p[0]) if t == SHAPE_MESH else (self.user.get(i, (0, None))[0] if t == SHAPE_USER else 0)
             for j in range(4):
                 shapes[i].p[j] = 0.0 if t == SHAPE_MESH else p[j]
         mats = (MaterialDesc * max(1, len(self.materials)))()
@@ -266,7 +266,8 @@ class Scene:
             kinds[i].name, kinds[i].intersect_src, kinds[i].normal_src = name.encode(), isrc.encode(), nsrc.encode()
         uq = np.zeros((max(1, len(self.shapes)), 4), dtype=np.float64)
         for i, (_, q) in self.user.items():
-            uq[i] = q
+            if i < len(uq):
+                uq[i] = q
         d = SceneDesc(len(self.shapes), len(self.materials), len(self.emitters), len(self.params),
                       shapes, mats, emis, params, rg, len(self.meshes), len(self.kinds), meshes,
                       kinds, uq.ctypes.data_as(C.POINTER(C.c_double)) if self.user else None)

@@ -52,6 +52,8 @@ struct PathArgs {
     int32_t gimg_param;             // >= 0: the lanes' gradient sums of this parameter also leave per pixel (gradient image)
     uint32_t gen_rows, gen_clog2;   // NP = DRT_NP_ANY: rows of the gradient tables (3 per parameter that requires a gradient), log2 of the copies a wave keeps of each
     uint32_t hist_lds, hist_stride; // ... full history words a thread keeps in LDS (the rest: global memory), threads of the grid
+    uint32_t gimg_row, pad_gen;     // ... the table row of the gradient image's parameter (NC == 1), DRT_SLOT_NONE: it requires no gradient
+    unsigned long long hist_ovf;    // ... the history's global part (uint32_t[words][hist_stride]), 0: none
     double p_rr, inv_p_rr;          // 1 - absorb and its reciprocal (pathtracer.hpp:130)
     // camera
     double eye[3], fwd[3], right[3], up[3];
@@ -298,6 +300,10 @@ struct Tangents<R, DRT_NP_ANY, NC> {
     GT* table;                      // the wave's table, at the lane's copy: element (row, copy) at table[(row << clog2)]
     uint32_t clog2;
     R* acc;                         // (unused: the register / column forms' sums)
+    // NC == 1, the gradient IMAGE (README.md:142-145; lockstep form, a lane IS a pixel): what the lane itself adds to the row of
+    // the image's parameter, next to the wave's table
+    V3<R> gsum;
+    uint32_t gimg_row;
     __device__ inline void new_path() { cur = 0xFFFFFFFFu; zc = 0; nv = 0; }
     __device__ inline void store_word(uint32_t w, uint32_t v)
     {
@@ -332,6 +338,10 @@ struct Tangents<R, DRT_NP_ANY, NC> {
     }
     __device__ inline void add(uint32_t row, V3<R> v)
     {
+        if constexpr (NC == 1) {
+            const bool mine = row == gimg_row;
+            gsum = mk<R>(gsum.x + (mine ? v.x : R(0)), gsum.y + (mine ? v.y : R(0)), gsum.z + (mine ? v.z : R(0)));
+        }
         GT* t = table + ((row * 3u) << clog2);
         atomicAdd(t, (GT)v.x);
         atomicAdd(t + (1u << clog2), (GT)v.y);
@@ -382,6 +392,8 @@ __device__ inline void gen_begin(GenBlock<R>& gb, const SL& lds, const DevScene<
     tg.gl = &gb.gl;
     tg.hist = hist + threadIdx.x;
     tg.hist_ovf = hist_ovf + (size_t)blockIdx.x * DRT_BLOCK + threadIdx.x;
+    tg.gsum = mk<R>(R(0), R(0), R(0));
+    tg.gimg_row = a.gimg_row;
     tg.hist_lds = a.hist_lds;
     tg.hist_stride = a.hist_stride;
     tg.clog2 = a.gen_clog2;
@@ -692,7 +704,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     __shared__ R s_acc[NP > 0 ? NP * 3 : 1][DRT_BLOCK];
     tg.acc = &s_acc[0][threadIdx.x];
     if constexpr (GEN)
-        gen_begin(s_gen, lds, sc, a, s_hist, reinterpret_cast<uint32_t*>(gimg_part), tg);   // (no gradient image in this form: the pointer carries the history's global part)
+        gen_begin(s_gen, lds, sc, a, s_hist, reinterpret_cast<uint32_t*>(a.hist_ovf), tg);
     else {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
@@ -892,6 +904,11 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
         if (fpart && have) {
             double* f = fpart + ((size_t)range * 3) * a.Pb + lp;       // [range][channel][pixel]: coalesced
             f[0] = fx; f[(size_t)a.Pb] = fy; f[(size_t)a.Pb * 2] = fz;
+        }
+        if constexpr (GEN && NC == 1) if (gimg_part && have) {
+            // gradient image, general form: the lane's own adds to the row of the image's parameter
+            double* f = gimg_part + ((size_t)range * 3) * a.Pb + lp;
+            f[0] = (double)tg.gsum.x; f[(size_t)a.Pb] = (double)tg.gsum.y; f[(size_t)a.Pb * 2] = (double)tg.gsum.z;
         }
         if constexpr (NP > 0) if (gimg_part && have) {
             // gradient image (README.md:142-145): a lane IS a pixel, its gradient sum of one parameter over the samples of

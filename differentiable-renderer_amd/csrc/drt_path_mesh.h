@@ -76,7 +76,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     Tangents<R, NP, NC> tg;
     tg.acc = &s_acc[0][threadIdx.x];
     if constexpr (GEN)
-        gen_begin(s_gen, lds, sc, a, s_hist, ovf + (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) * ovf_stride, tg);   // (behind the traversal stacks' global part)
+        gen_begin(s_gen, lds, sc, a, s_hist, reinterpret_cast<uint32_t*>(a.hist_ovf), tg);   // (behind the traversal stacks' global part)
     else {
 #pragma unroll
         for (int p = 0; p < NP; ++p)

@@ -229,7 +229,8 @@ struct Shard {
 
 // "k_path<float, SPEC, NP, NC, KindSig<...>, REGEN[, LOSS]>" / "k_path_unbiased<float, SPEC, NP, KindSig<...>>": the name expression
 // of the f32 instantiation a render would launch, for the scene's own signature
-inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss, bool gen, bool f64 = false)
+inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool unbiased, bool regen, bool loss, bool gen, bool f64 = false,
+                                    bool gen_gimg = false)
 {
     const std::string sg = drt_jit::sig_type(ctx->prog_sig, ctx->n_shapes);
     const char* sp = ctx->has_specular ? "true" : "false";
@@ -240,7 +241,7 @@ inline std::string path_kernel_name(const drt_hip_ctx* ctx, bool tangents, bool 
         snprintf(name, sizeof name, "k_path_unbiased<%s, %s, %d, %s>", f64 ? "double" : "float", sp, gen ? -1 : (ctx->n_params > 4 ? 8 : 4), sg.c_str());
     else {
         const int np = tangents ? (gen ? -1 : (ctx->n_params > 4 ? 8 : 4)) : 0;
-        const int nc = tangents ? (gen ? 0 : (ctx->n_params > 4 ? 8 : (three ? 3 : 4))) : 0;
+        const int nc = tangents ? (gen ? (gen_gimg ? 1 : 0) : (ctx->n_params > 4 ? 8 : (three ? 3 : 4))) : 0;   // (general form: 1 = + the lanes' own sums of one row, the gradient image)
         snprintf(name, sizeof name, "k_path<%s, %s, %d, %d, %s, %s%s>", f64 ? "double" : "float", sp, np, nc, sg.c_str(), regen ? "true" : "false", loss ? ", true" : "");
     }
     return name;
@@ -274,10 +275,10 @@ void shard_plan(Shard<R>& s)
     const bool mesh_ok = ctx->has_mesh && (long long)s.cam->width * s.cam->height * s.spp <= tuning().mesh_path_max && ctx->prog_sorted && !(rp->flags & DRT_RENDER_UNFUSED) && !s.unbiased &&
                          !s.loss_l2;
     // gradients: <= 8 parameters in registers / LDS columns; any number the kernels can stage (136: every analytic scene) through
-    // the general form -- vertex history + per-wave tables (drt_path.h, DRT_NP_ANY) -- except the gradient IMAGE, which is
-    // the lanes' own sums
+    // the general form -- vertex history + per-wave tables (drt_path.h, DRT_NP_ANY); the gradient IMAGE (the lanes' own sums) in
+    // analytic scenes too
     const bool grads_ok = !(s.backward || s.gimg_param >= 0) || ctx->n_params <= DRT_FAST_PARAMS ||
-                          (ctx->n_params <= DRT_PATH_LDS_PARAMS && s.gimg_param < 0 && tuning().path_general);
+                          (ctx->n_params <= DRT_PATH_LDS_PARAMS && tuning().path_general && (s.gimg_param < 0 || !ctx->has_mesh));
     s.use_path = ((s.can_fuse && ctx->prog_ok) || mesh_ok) && D > 0 && grads_ok &&
                  rp->bounces_per_launch <= 0 && tuning().shade_bounces <= 0 && tuning().dump_path == -1;
     s.mesh_path = s.use_path && ctx->has_mesh;
@@ -322,8 +323,9 @@ void shard_plan(Shard<R>& s)
     }
     // (the general form also where the register form would do but is slower: its 5 ... 8-parameter instantiation keeps 24 LDS
     //  columns per thread -- 0.78 ms against the general form's 0.75 on config 3's frame with an albedo per wall)
-    s.path_gen = s.use_path && s.backward && s.gimg_param < 0 && ctx->n_params > tuning().gen_above && ctx->n_params <= DRT_PATH_LDS_PARAMS &&
-                 (tuning().path_general || ctx->n_params <= DRT_FAST_PARAMS);
+    s.path_gen = s.use_path && (s.backward || s.gimg_param >= 0) && ctx->n_params <= DRT_PATH_LDS_PARAMS &&
+                 (s.gimg_param >= 0 ? ctx->n_params > DRT_FAST_PARAMS && !s.mesh_path       // (the image keeps the column form where it exists)
+                                    : ctx->n_params > tuning().gen_above && (tuning().path_general || ctx->n_params <= DRT_FAST_PARAMS));
     // Batch = the paths that are in flight at once on the queue route.  The BVH walk wants it LARGE: its launches end in a
     // tail of ~0.1 ms whatever their size (the list counters run dry, every wave finishes what it holds), so config 4 at full
     // size (1024^2 x 256 spp) takes 115 / 101 / 98 / 96 ms with 2^24 / 2^26 / 2^27 / 2^28 paths per batch and one GPU's
@@ -606,7 +608,6 @@ int path_batch(Shard<R>& s)
     uint32_t* counts = s.counts;
     double* fpart = s.film ? (double*)s.fpart_buf->p : (double*)nullptr;
     double* gpix = s.gimg_param >= 0 ? (double*)ctx->gpix.p : (double*)nullptr;   // gradient image partials
-    double* hist_global = nullptr;   // the general form (never with a gradient image): the kernel's gradient-image argument carries its history's global part
     // The closest-hit program.  The kinds of the reference's own scene are compiled in, in the instantiation the library
     // carries (f64 too: the verification mode runs the same program with full-precision reciprocals and square roots); any
     // other analytic scene reads its kinds at run time (the kind-sorted program) until it has rendered enough for a kernel
@@ -643,11 +644,11 @@ int path_batch(Shard<R>& s)
     ctx->scene_work += (uint64_t)a.n_paths * (uint64_t)(s.D > 0 ? s.D : 1);
     if (!jit && !builtin && !s.mesh_path && ctx->jit_mode > 0 && sizeof(R) == 4 && ctx->user_header.empty() &&
         (ctx->jit_mode > 1 || ctx->scene_work >= DRT_JIT_AFTER_WORK))
-        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen), ctx->jit_mode > 1);
+        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen, false, s.path_gen && s.gimg_param >= 0), ctx->jit_mode > 1);
     if (!ctx->user_header.empty() && !jit) {
         // caller-defined shape kinds: their code exists only in a kernel compiled for this scene -- made now, waited for, in either
         // compute type (shard_plan has checked that the context may compile)
-        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen, sizeof(R) == 8), true);
+        jit = jit_function(ctx, path_kernel_name(ctx, tangents, unbiased, path_regen, false, s.path_gen, sizeof(R) == 8, s.path_gen && s.gimg_param >= 0), true);
         if (!jit)
             return fail(ctx, DRT_ERR_UNSUPPORTED, ("render: the scene's caller-defined shape kinds did not compile: " + ctx->jit_error).c_str());
     }
@@ -658,10 +659,10 @@ int path_batch(Shard<R>& s)
     do {                                                                                                                 \
         if (path_regen)                                                                                                  \
             hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, true>), dim3(gpath), dim3(DRT_BLOCK), hist_bytes, ks,        \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gen ? hist_global : gpix); \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
         else                                                                                                             \
             hipLaunchKernelGGL((k_path<R, SPEC, NP, NC, SG, false>), dim3(gpath), dim3(DRT_BLOCK), hist_bytes, ks,       \
-                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gen ? hist_global : gpix); \
+                               pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix);                   \
     } while (0)
 #define DRT_LAUNCH_PATH_SIG(SPEC, NP, NC)                                                  \
     do {                                                                                   \
@@ -687,10 +688,19 @@ int path_batch(Shard<R>& s)
         const size_t words = (size_t)hist_ovf_words + (s.mesh_path ? (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) : 0);
         int rce;
         if ((rce = ensure(ctx, hb, words * ovf_stride * sizeof(uint32_t))) != DRT_OK) return rce;
-        if (s.mesh_path)
+        if (s.mesh_path) {
             ovf = (uint32_t*)hb.p;
-        else
-            hist_global = (double*)hb.p;
+            pa.hist_ovf = (unsigned long long)(uintptr_t)(ovf + (size_t)(DRT_BVH_STACK - DRT_MESH_LDS_STACK) * ovf_stride);
+        } else
+            pa.hist_ovf = (unsigned long long)(uintptr_t)hb.p;
+    }
+    // the gradient image in the general form: the row of its parameter (none: the parameter requires no gradient -- its image is zero)
+    pa.gimg_row = DRT_SLOT_NONE;
+    if (gen && s.gimg_param >= 0 && s.gimg_param < DRT_PATH_LDS_PARAMS && ctx->requires_grad[(size_t)s.gimg_param]) {
+        uint32_t row = 0;
+        for (int p2 = 0; p2 < s.gimg_param; ++p2)
+            row += ctx->requires_grad[(size_t)p2] ? 1u : 0u;
+        pa.gimg_row = row;
     }
     const DevBvh<R> bvh = s.bvh;
 #define DRT_LAUNCH_MESH(SPEC, NP, NC)                                                                              \
@@ -705,14 +715,19 @@ int path_batch(Shard<R>& s)
     } else
 #undef DRT_LAUNCH_MESH
     if (jit) {
-        double* aux = gen ? hist_global : gpix;
-        void* args_path[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal, &aux};
+        void* args_path[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal, &gpix};
         void* args_unb[] = {&pa, &d_scene, &d_params, &d_adjoint, &gpart, &fpart, &counts, &ptotal};
         HIPCHK(ctx, hipModuleLaunchKernel(jit, (unsigned)gpath, 1, 1, DRT_BLOCK, 1, 1, unbiased ? 0u : hist_bytes, ks, unbiased ? args_unb : args_path, nullptr));
     } else if (unbiased) {                      // the unbiased operator: fresh suffix paths per vertex, in registers
         if (gen) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, DRT_NP_ANY); else DRT_LAUNCH_UNB(false, DRT_NP_ANY); }
         else if (ctx->n_params > 4) { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 8); else DRT_LAUNCH_UNB(false, 8); }
         else { if (ctx->has_specular) DRT_LAUNCH_UNB(true, 4); else DRT_LAUNCH_UNB(false, 4); }
+    } else if (tangents && gen && s.gimg_param >= 0) {   // ... and the gradient image of one of them (lockstep: a lane is a pixel)
+#define DRT_LAUNCH_GIMG(SPEC, SG) hipLaunchKernelGGL((k_path<R, SPEC, DRT_NP_ANY, 1, SG, false>), dim3(gpath), dim3(DRT_BLOCK), hist_bytes, ks, \
+                                                     pa, d_scene, d_params, d_adjoint, gpart, fpart, counts, ptotal, gpix)
+        if (ctx->has_specular) { if (builtin) DRT_LAUNCH_GIMG(true, SigCornell); else DRT_LAUNCH_GIMG(true, SigNone); }
+        else { if (builtin) DRT_LAUNCH_GIMG(false, SigCornell); else DRT_LAUNCH_GIMG(false, SigNone); }
+#undef DRT_LAUNCH_GIMG
     } else if (tangents && gen) {                      // any number of parameters
         if (ctx->has_specular) DRT_LAUNCH_PATH_SIG(true, DRT_NP_ANY, 0);
         else DRT_LAUNCH_PATH_SIG(false, DRT_NP_ANY, 0);

@@ -43,8 +43,8 @@ python3 bench.py --gpus 2 --dist-backend gloo --same-gpu --no-cpu-baseline --no-
 python3 tools/mesh_scale.py > "$E/mesh_scale.txt" 2>&1
 python3 bench.py --scene mesh160x160 --unbiased --no-extra-views --steps 5 --warmup 2 > "$E/bench_unbiased_mesh160x160.json" 2>> "$E/bench.err"
 python3 tools/async_timing.py > "$E/async_host_buffers.txt" 2>&1
-python3 tools/fuzz_reference.py 150 11 > "$E/fuzz_vs_reference.txt" 2>&1
-python3 tools/fuzz_overlap.py 300 1 2>&1 | grep -v amdgpu > "$E/fuzz_overlap.txt"
+timeout 900 python3 tools/fuzz_reference.py 400 11 > "$E/fuzz_vs_reference.txt" 2>&1
+timeout 900 python3 tools/fuzz_overlap.py 300 1 2>&1 | grep -v amdgpu > "$E/fuzz_overlap.txt"
 (echo "## frames overlapping (default)"; python3 tools/one_ctx_frames.py 2>&1 | grep -v amdgpu; echo "## DRT_HIP_OVERLAP_FRAMES=0"; DRT_HIP_OVERLAP_FRAMES=0 python3 tools/one_ctx_frames.py 2>&1 | grep -v amdgpu) > "$E/one_ctx_frames.txt"
 python3 tools/two_frames.py cornell 2>&1 | grep -v amdgpu > "$E/two_frames.txt"
 (python3 tools/jit_background.py random11; python3 tools/jit_background.py random5) 2>&1 | grep -v amdgpu > "$E/jit_background.txt"
@@ -60,6 +60,11 @@ python3 bench.py --config 4 --per-face > "$E/bench_config4_per_face.json" 2>> "$
 python3 bench.py --single-process --gpus 2 --same-gpu 2>> "$E/bench.err" | grep "^{" > "$E/bench_group_2members_same_gpu_plumbing.json"
 (timeout 300 python3 tools/allreduce_overlap.py; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager; timeout 300 python3 tools/allreduce_overlap.py --torch-dist-eager --context-between) 2>&1 | grep "ms per frame\|initialised" > "$E/launch_order.txt"
 (timeout 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline --no-extra-views 2>> "$E/bench.err" | grep "^{") > "$E/bench_1rank_under_torchrun.json"
+# round 6: what the number of scene parameters costs (the general form of the one-launch kernels); many-parameter bench lines;
+# the f64 route's kernel time
+python3 tools/param_cliff.py 2>&1 | grep -v amdgpu > "$E/param_cliff.txt"
+for sc in cornell_shapes params16 params64; do python3 bench.py --scene $sc --no-extra-views --no-cpu-baseline > "$E/bench_$sc.json" 2>> "$E/bench.err"; done
+python3 tools/f64_frames.py 10 2>&1 | grep -v amdgpu > "$E/f64_frames.txt"
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
 [ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
 for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh ${T}_fwd; do

@@ -17,13 +17,14 @@ export TMPDIR=/tmp
 export DRT_HIP_OVERLAP_FRAMES=0
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-extra-views $*"
 cd "$PWD"
+# (every profiler run under `timeout`: a run that aborts has been seen to hang until the box is taken away)
 # 1) per-kernel time
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 # 2) HBM traffic counters, one pass each (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_write.err"
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
+timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_write.err"
 # 3) wave-level counters
-rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_sq.err"
+timeout -k 10 900 rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > /dev/null 2> "$OUT/pmc_sq.err"
 python3 tools/summarize_profile.py "$OUT" "$WORKLOAD" > "$OUT/summary.txt" 2> "$OUT/summary.err"
 cat "$OUT/summary.txt"
 # keep only small files in gpurun_out (it is merged back, <= 64 MiB)
