@@ -254,8 +254,20 @@ __device__ inline double pow_r(double x, double y) { return pow(x, y); }
 __device__ inline void sincospi_r(float x, float* s, float* c) { sincospif(x, s, c); }
 __device__ inline void sincospi_r(double x, double* s, double* c) { sincospi(x, s, c); }
 // sin and cos of phi = 2 pi u for the 31-bit draw r, f32: drt_sincos.h (also compiled on the host by its known-answer test)
+#ifndef DRT_F64_LIBM
+// f64 (the verification mode's bound is 1e-9 of the reference, not its last bit): u = r / RAND_MAX as a product with the
+// reciprocal (one ulp; the IEEE division is ten instructions, three draws per vertex), and sin / cos of 2 pi u without the
+// math library's sincospi (~70 instructions of general range reduction and special cases): the argument in QUARTER TURNS,
+// x = 4 r / RAND_MAX in [0, 4], its nearest integer is the quadrant, the remainder times pi / 2 lies in [-pi/4, pi/4] -- exact up
+// to the product's rounding, 1e-15 rad -- and Cephes' double-precision minimax polynomials take it from there (abs error
+// <= 2e-15 against libm over all 2^31 draws' range, swept on the host: tests/cpp/sincos_kat.cpp).  Round 6: 467 -> ~380 vector
+// instructions per wave-bounce of the f64 k_path.
+__device__ inline double u01_f64(uint32_t r) { return (double)r * (1.0 / DRT_RAND_MAX_D); }   // random.hpp:9
+__device__ inline void sincos_2pi_u31(uint32_t r, double* s, double* c) { drt_sincos_2pi_u31_f64(r, s, c); }
+#else
 __device__ inline double u01_f64(uint32_t r) { return (double)r / DRT_RAND_MAX_D; }   // random.hpp:9
 __device__ inline void sincos_2pi_u31(uint32_t r, double* s, double* c) { sincospi(2.0 * u01_f64(r), s, c); }
+#endif
 template <typename R> __device__ inline V3<R> normalize(V3<R> a) { return a * rsqrt_r(dot(a, a)); }
 // vector.hpp:602-606
 template <typename R> __device__ inline V3<R> reflect(V3<R> v, V3<R> n) { return n * (R(2) * dot(n, v)) - v; }

@@ -48,6 +48,27 @@ DRT_SC_HD void sincos_2pi_u31(uint32_t r, float* s, float* c)
     *c = drt_bits_to_float(drt_float_to_bits(cc) ^ (((q + 1u) & 2u) << 30));
 }
 
+// ... the same in f64 (the verification mode; DRT_RENDER_F64): quadrant in quarter turns, Cephes' sin / cos kernels for doubles
+DRT_SC_HD void drt_sincos_2pi_u31_f64(uint32_t r, double* s, double* c)
+{
+    const double x = (double)r * (4.0 / 2147483647.0);            // quarter turns, [0, 4]
+    const double qf = __builtin_rint(x);
+    const double y = (x - qf) * 1.5707963267948966192;            // [-pi/4, pi/4]
+    const uint32_t q = (uint32_t)(int)qf;                         // 0 .. 4
+    const double z = y * y;
+    const double ps = ((((1.58962301576546568060e-10 * z - 2.50507477628578072866e-8) * z + 2.75573136213857245213e-6) * z
+                        - 1.98412698295895385996e-4) * z + 8.33333333332211858878e-3) * z - 1.66666666666666307295e-1;
+    const double pc = ((((-1.13585365213876817300e-11 * z + 2.08757008419747316778e-9) * z - 2.75573141792967388112e-7) * z
+                        + 2.48015872888517045348e-5) * z - 1.38888888888730564116e-3) * z + 4.16666666666665929218e-2;
+    const double sp = y + y * z * ps;
+    const double cp = 1.0 - 0.5 * z + z * z * pc;
+    const bool swap = (q & 1u) != 0;
+    const double ss = swap ? cp : sp, cc = swap ? sp : cp;
+    // quadrant 0: (s, c); 1: (c, -s); 2: (-s, -c); 3: (-c, s); 4 = 0
+    *s = (q & 2u) ? -ss : ss;
+    *c = ((q + 1u) & 2u) ? -cc : cc;
+}
+
 // (2) The specular lobe's theta (bxdf.hpp:106-113): cos^2 = u^(2/(e+2)) = exp(x), sin^2 = 1 - exp(x), x = log(u) 2/(e+2).
 // log(u) for u = r / RAND_MAX: near u = 1 it is formed from the EXACT integer w = (RAND_MAX - r) / RAND_MAX as the
 // series of log1p(-w) (six terms, relative error < 3e-9 for w < 1/16) -- the float u would have lost w's low bits --

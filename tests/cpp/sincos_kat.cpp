@@ -23,6 +23,20 @@ int main()
     sincos_2pi_u31(1073741824u, &s, &c);                 // half a turn: (0, -1)
     const bool half = std::fabs(s) < 1e-7f && c == -1.f;
     std::printf("sin/cos: max abs error %.3e at r = %u\n", worst, at);
+    // the f64 mode's sin / cos (quarter-turn reduction + Cephes' double kernels) against libm, in long double
+    long double worst64 = 0;
+    for (uint64_t r = 0; r <= 2147483647ull; r += (r < 100000 || r > 2147383647ull) ? 1 : 509) {
+        double s64, c64;
+        drt_sincos_2pi_u31_f64((uint32_t)r, &s64, &c64);
+        const long double phi = 2 * 3.14159265358979323846264338327950288L * (long double)r / 2147483647.0L;
+        const long double e = fmaxl(fabsl((long double)s64 - sinl(phi)), fabsl((long double)c64 - cosl(phi)));
+        if (e > worst64) worst64 = e;
+    }
+    double s0, c0, sq, cq;
+    drt_sincos_2pi_u31_f64(0u, &s0, &c0);
+    drt_sincos_2pi_u31_f64(2147483647u, &sq, &cq);
+    std::printf("sin/cos f64: max abs error %.3Le\n", worst64);
+    if (!(worst64 < 2e-15L) || s0 != 0.0 || c0 != 1.0 || std::fabs(sq) > 1e-15 || cq != 1.0) { std::printf("f64 sin/cos FAILED\n"); return 1; }
     // the specular lobe's helpers: log(u), exp(x), 1 - exp(x) against libm in double (relative errors)
     double e_log = 0, e_exp = 0, e_ome = 0;
     for (uint64_t r = 1; r < 2147483647ull; r += (r < 200000 || r > 2147283647ull) ? 1 : 4099) {
