@@ -671,8 +671,8 @@ def main():
                                                            "(integrate.hpp:39-52: a fresh suffix path per vertex, O(depth^2) segments)")
     if extra and not a.unbiased:
         f64_view = dict(timed_variant(f64=True), roofline={
-            "bound": "f64 vector issue", "kernel": "k_path<double>", "valu_per_launch": 9.786e8, "launch_ms_profiled": 1.829,
-            "achieved": 535.0, "unit": "G wave-instr/s", "peak_all_f64": 614.4, "peak_all_f32": 1228.8, "frac_of_f64_rate": 0.87,
+            "bound": "f64 vector issue", "kernel": "k_path<double>", "valu_per_launch": 9.208e8, "launch_ms_profiled": 1.707,
+            "achieved": 539.0, "unit": "G wave-instr/s", "peak_all_f64": 614.4, "peak_all_f32": 1228.8, "frac_of_f64_rate": 0.88,
             "frac_of_f32_rate": 0.44, "waves_per_simd": 4,
             "source": "profiles/r06_f64_counters.txt (rocprofv3 --pmc SQ_INSTS_VALU over tools/f64_frames.py: a STORED count, "
                       "valid for config 3's frame only)"} if a.is_config and a.config == 3 else None, note="the same call with DRT_RENDER_F64: every kernel computes and stores in "
