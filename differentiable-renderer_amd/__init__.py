@@ -27,7 +27,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libdrt_hip.so")
 
 # ---- enums / flags (include/drt_hip.h) ------------------------------------------------------
 SHAPE_PLANE, SHAPE_SPHERE, SHAPE_MESH, SHAPE_USER = 0, 1, 2, 3
-BXDF_DIFFUSE, BXDF_SPECULAR, BXDF_MIRROR = 0, 1, 2
+BXDF_DIFFUSE, BXDF_SPECULAR, BXDF_MIRROR, BXDF_USER = 0, 1, 2, 3
 RENDER_BACKWARD = 0x1
 RENDER_DEVICE_OUT = 0x2
 RENDER_SYNC = 0x4
@@ -73,6 +73,10 @@ class ShapeKindDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("intersect_src", C.c_char_p), ("normal_src", C.c_char_p)]
 
 
+class BxdfKindDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("sample_src", C.c_char_p)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("n_shapes", C.c_int32), ("n_materials", C.c_int32), ("n_emitters", C.c_int32),
                 ("n_params", C.c_int32),
@@ -80,7 +84,9 @@ class SceneDesc(C.Structure):
                 ("emitters", C.POINTER(EmitterDesc)), ("params", C.POINTER(C.c_double)),
                 ("requires_grad", C.POINTER(C.c_uint8)),
                 ("n_meshes", C.c_int32), ("n_kinds", C.c_int32), ("meshes", C.POINTER(MeshDesc)),
-                ("kinds", C.POINTER(ShapeKindDesc)), ("user_params", C.POINTER(C.c_double))]
+                ("kinds", C.POINTER(ShapeKindDesc)), ("user_params", C.POINTER(C.c_double)),
+                ("n_bxdf_kinds", C.c_int32), ("reserved2", C.c_int32), ("bxdf_kinds", C.POINTER(BxdfKindDesc)),
+                ("user_bxdf_params", C.POINTER(C.c_double))]
 
 
 class CameraDesc(C.Structure):
@@ -137,6 +143,10 @@ class Scene:
     # source, normal source)], user = {shape index: (kind index, values 4..7 of the shape's record)}
     kinds: list = field(default_factory=list)
     user: dict = field(default_factory=dict)
+    # caller-defined BxDF kinds (any BxDF<T> subclass of the form colour x scalar lobe, bxdf.hpp:12-25; drt_bxdf_kind_desc):
+    # bxdf_kinds = [(name, sample source)], user_m = {material index: value 1 of its record} (value 0 rides in `exponent`)
+    bxdf_kinds: list = field(default_factory=list)
+    user_m: dict = field(default_factory=dict)
 
     # Vector<T,3,true>(value, requires_grad), vector.hpp:228-234
     def parameter(self, rgb: Sequence[float], requires_grad: bool = True, name: str = "") -> int:
@@ -176,6 +186,18 @@ class Scene:
         self.shapes.append((SHAPE_SPHERE, material, emitter,
                             (float(center[0]), float(center[1]), float(center[2]), float(radius))))
         return len(self.shapes) - 1
+
+    def bxdf_kind(self, name: str, sample_src: str) -> int:
+        """A caller-defined BxDF KIND: sample + evaluate as ONE body of HIP source over a record of 2 values
+        (include/drt_hip.h: drt_bxdf_kind_desc).  -> its index for user_bxdf()."""
+        self.bxdf_kinds.append((name, sample_src))
+        return len(self.bxdf_kinds) - 1
+
+    def user_bxdf(self, kind: int, param: int, v0: float = 0.0, v1: float = 0.0) -> int:
+        assert 0 <= kind < len(self.bxdf_kinds)
+        self.materials.append((BXDF_USER + kind, param, float(v0)))
+        self.user_m[len(self.materials) - 1] = float(v1)
+        return len(self.materials) - 1
 
     def shape_kind(self, name: str, intersect_src: str, normal_src: str) -> int:
         """A caller-defined shape KIND: the bodies of Shape<T>::intersect / normal (shape.hpp:14-22) as HIP source over a record
@@ -268,10 +290,20 @@ class Scene:
         for i, (_, q) in self.user.items():
             if i < len(uq):
                 uq[i] = q
+        bk = (BxdfKindDesc * max(1, len(self.bxdf_kinds)))()
+        for i, (name, src) in enumerate(self.bxdf_kinds):
+            bk[i].name, bk[i].sample_src = name.encode(), src.encode()
+        um = np.zeros(max(1, len(self.materials)), dtype=np.float64)
+        for i, v1 in self.user_m.items():
+            if i < len(um):
+                um[i] = v1
+        # (n_kinds: -1 = no shape kinds, but the fields behind them -- the BxDF kinds -- are there)
+        n_kinds = len(self.kinds) if self.kinds else (-1 if self.bxdf_kinds else 0)
         d = SceneDesc(len(self.shapes), len(self.materials), len(self.emitters), len(self.params),
-                      shapes, mats, emis, params, rg, len(self.meshes), len(self.kinds), meshes,
-                      kinds, uq.ctypes.data_as(C.POINTER(C.c_double)) if self.user else None)
-        return d, [shapes, mats, emis, params, rg, meshes, self.meshes, self.mesh_face_param, kinds, uq]
+                      shapes, mats, emis, params, rg, len(self.meshes), n_kinds, meshes,
+                      kinds, uq.ctypes.data_as(C.POINTER(C.c_double)) if self.user else None,
+                      len(self.bxdf_kinds), 0, bk, um.ctypes.data_as(C.POINTER(C.c_double)) if self.user_m else None)
+        return d, [shapes, mats, emis, params, rg, meshes, self.meshes, self.mesh_face_param, kinds, uq, bk, um]
 
 
 def cornell_box(front_specular: bool = False, emissive_wall: bool = False, front_mirror: bool = False,
@@ -372,6 +404,36 @@ BOX_NORMAL = """
     }
     return mk<R>(axis == 0 ? sign : R(0), axis == 1 ? sign : R(0), axis == 2 ? sign : R(0));
 """
+
+
+COSLOBE_SAMPLE = """
+    // a power-cosine lobe around the normal, record: p[0] = k.  cos(theta) = u1^(1 / (k + 1)), pdf = (k + 1) / (2 pi) cos^k,
+    // f = colour (k + 2) / (2 pi) cos^k(theta_out)
+    (void)d;
+    const R k = p[0];
+    const R ct = pow_r(u1, R(1) / (k + R(1)));
+    const R st = sqrt_r(max_r(R(0), R(1) - ct * ct));
+    R sphi, cphi;
+    sincospi_r(R(2) * u2, &sphi, &cphi);
+    V3<R> t, b;
+    make_frame(n, t, b);
+    wo = t * (cphi * st) + b * (sphi * st) + n * ct;
+    pdf = (k + R(1)) * R(0.15915494309189535) * pow_r(ct, k);
+    const R c = dot(n, wo);
+    bs = c > R(0) ? (k + R(2)) * R(0.15915494309189535) * pow_r(c, k) : R(0);
+"""
+
+
+def cornell_with_user_bxdf(with_disc: bool = False) -> Scene:
+    """The reference's scene with a material the library has NO code for on its front sphere and ground: a power-cosine lobe
+    (oracle/ref_harness.cpp: CosLobeBxDF, a BxDF<T> subclass inside the unmodified reference); with_disc: a caller-defined shape too."""
+    s = cornell_with_user_shapes(box=False) if with_disc else cornell_box()
+    kind = s.bxdf_kind("coslobe", COSLOBE_SAMPLE)
+    glossy = s.user_bxdf(kind, s.parameter((0.8, 0.7, 0.5), True, "lobe_albedo"), 6.0)
+    wide = s.user_bxdf(kind, 2, 1.5)                      # (the white parameter under a wide lobe)
+    t, m, e, p4 = s.shapes[0]; s.shapes[0] = (t, glossy, e, p4)      # sphere_front
+    t, m, e, p4 = s.shapes[6]; s.shapes[6] = (t, wide, e, p4)        # ground
+    return s
 
 
 def cornell_with_user_shapes(box: bool = True) -> Scene:
@@ -532,6 +594,10 @@ def scene_by_name(name: str) -> Scene:
         return cornell_box(front_specular=True)
     if name == "cornell_walls":
         return cornell_box(per_wall=True)
+    if name == "cornell_coslobe":
+        return cornell_with_user_bxdf()
+    if name == "cornell_coslobe_disc":
+        return cornell_with_user_bxdf(with_disc=True)
     if name == "cornell_disc":
         return cornell_with_user_shapes(box=False)
     if name == "cornell_disc_box":

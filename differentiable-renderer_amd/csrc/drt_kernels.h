@@ -496,6 +496,15 @@ __device__ inline void sample_bxdf(const DevMaterial<R>& m, V3<R> nrm, V3<R> d, 
         return;
     }
     r1 = min(max(r1, 1u), 2147483646u);                      // (v_med3_u32)
+#ifdef DRT_USER_SHAPES
+    if (SPEC && m.type >= DRT_BXDF_USER) {
+        // a BxDF of a caller-defined kind (drt_bxdf_kind_desc): its own sample + evaluate over its two draws, from the source
+        // hiprtc compiled into this kernel (drt_prog.h); record = (exponent, norm) of the material
+        const R p2[2] = {m.exponent, m.norm};
+        user_bxdf<R>(m.type - DRT_BXDF_USER, p2, nrm, d, u01(R(0), r1), u01(R(0), r2), wo, q, bs);
+        return;
+    }
+#endif
     R sphi, cphi;
     sincos_2pi_u31(r2, &sphi, &cphi);                          // phi = 2 pi u2
     V3<R> tg, bt;

@@ -36,6 +36,13 @@ __device__ inline V3<R> user_normal(int kind, const R* p, V3<R> P)
     if (kind == 0) return drt_user_normal_0<R>(p, P);
     return drt_user_normal_1<R>(p, P);
 }
+// ... and caller-defined BxDF kinds (drt_bxdf_kind_desc): sample + evaluate in one body
+template <typename R>
+__device__ inline void user_bxdf(int kind, const R* p, V3<R> n, V3<R> d, R u1, R u2, V3<R>& wo, R& pdf, R& bs)
+{
+    if (kind == 0) drt_user_bxdf_0<R>(p, n, d, u1, u2, wo, pdf, bs);
+    else drt_user_bxdf_1<R>(p, n, d, u1, u2, wo, pdf, bs);
+}
 #endif
 
 template <typename R>

@@ -613,7 +613,8 @@ int path_batch(Shard<R>& s)
     // other analytic scene reads its kinds at run time (the kind-sorted program) until it has rendered enough for a kernel
     // of its own to pay (drt_jit.h; f32 only: the f64 mode keeps the reference's literal shape loop for such scenes).
     const bool builtin = tuning().builtin_program && ctx->jit_mode >= 0 && ctx->n_shapes == DRT_NSIG_CORNELL &&
-                         ctx->prog_sig[0] == DRT_SIG_CORNELL && !s.loss_kernel && !s.mesh_path;
+                         ctx->prog_sig[0] == DRT_SIG_CORNELL && !s.loss_kernel && !s.mesh_path &&
+                         ctx->user_header.empty();      // (caller-defined kinds -- a BxDF on the reference's own shapes -- exist in hiprtc's kernel only)
     unsigned long long* ptotal = s.path_finish ? s.totals : (unsigned long long*)nullptr;
     // (frames that overlap: this frame's grid goes to the lane's own stream, behind whoever still uses the lane's buffers, and
     //  the finishing launch on the context's stream waits for it.  Scene uploads block until they are done; a parameter update

@@ -134,6 +134,8 @@ void fill_scene(DevScene<R>& ds, std::vector<R>& params, const drt_scene_desc* s
         ds.materials[i].param = s->materials[i].type == DRT_BXDF_MIRROR ? s->n_params : s->materials[i].param;
         ds.materials[i].exponent = (R)s->materials[i].exponent;
         ds.materials[i].norm = (R)((s->materials[i].exponent + 2.0) / (2.0 * DRT_PI));
+        if (s->materials[i].type >= DRT_BXDF_USER)      // a caller-defined kind: (exponent, norm) = the two values of its record
+            ds.materials[i].norm = (s->n_kinds != 0 && s->user_bxdf_params) ? (R)s->user_bxdf_params[i] : R(0);
     }
     for (int i = 0; i < s->n_emitters; ++i)
         ds.emitter_param[i] = s->emitters[i].param;
@@ -252,9 +254,17 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
         if (sh.material < -1 || sh.material >= s->n_materials || sh.emitter < -1 || sh.emitter >= s->n_emitters)
             return fail(ctx, DRT_ERR_INVALID, "scene: shape material/emitter index out of range");
     }
+    bool any_user_bxdf = false;
+    const int n_bxdf_kinds = s->n_kinds != 0 ? s->n_bxdf_kinds : 0;      // (ABI <= 7 callers: the fields behind `meshes` do not exist)
     for (int i = 0; i < s->n_materials; ++i) {
         if (s->materials[i].type == DRT_BXDF_MIRROR)
             continue;                  // no colour parameter
+        if (s->materials[i].type >= DRT_BXDF_USER) {
+            const int k = s->materials[i].type - DRT_BXDF_USER;
+            if (n_bxdf_kinds < 1 || n_bxdf_kinds > DRT_MAX_USER_BXDF_KINDS || !s->bxdf_kinds || k >= n_bxdf_kinds || !s->bxdf_kinds[k].sample_src)
+                return fail(ctx, DRT_ERR_INVALID, "scene: unknown material type (a DRT_BXDF_USER + k material needs entry k of drt_scene_desc.bxdf_kinds)");
+            any_user_bxdf = true;
+        } else
         if (s->materials[i].type != DRT_BXDF_DIFFUSE && s->materials[i].type != DRT_BXDF_SPECULAR)
             return fail(ctx, DRT_ERR_INVALID, "scene: unknown material type");
         if (s->materials[i].param < 0 || s->materials[i].param >= s->n_params)
@@ -263,14 +273,23 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
     for (int i = 0; i < s->n_emitters; ++i)
         if (s->emitters[i].param < 0 || s->emitters[i].param >= s->n_params)
             return fail(ctx, DRT_ERR_INVALID, "scene: emitter parameter index out of range");
-    if (any_user && any_mesh)
-        return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: caller-defined shape kinds and a triangle mesh in one scene (the kinds live in the one-launch "
+    if ((any_user || any_user_bxdf) && any_mesh)
+        return fail(ctx, DRT_ERR_UNSUPPORTED, "scene: caller-defined shape or BxDF kinds and a triangle mesh in one scene (the kinds live in the one-launch "
                                               "path kernel compiled for the scene; mesh scenes walk their BVH in kernels of the library's own)");
     // the caller-defined kinds as the header hiprtc compiles them from (drt_prog.h: DRT_USER_SHAPES)
     std::string user_header;
-    if (any_user) {
+    if (any_user || any_user_bxdf) {
+        for (int k = 0; k < DRT_MAX_USER_BXDF_KINDS; ++k) {
+            const bool have = k < n_bxdf_kinds;
+            char head[320];
+            snprintf(head, sizeof head, "// BxDF kind %d: %s\ntemplate <typename R> __device__ inline void drt_user_bxdf_%d(const R* p, V3<R> n, V3<R> d, R u1, R u2, "
+                                        "V3<R>& wo, R& pdf, R& bs)\n{\n", k, have && s->bxdf_kinds[k].name ? s->bxdf_kinds[k].name : "(none)", k);
+            user_header += head;
+            user_header += have ? s->bxdf_kinds[k].sample_src : "(void)p; (void)d; (void)u1; (void)u2; wo = n; pdf = R(1); bs = R(0);";
+            user_header += "\n}\n";
+        }
         for (int k = 0; k < DRT_MAX_USER_KINDS; ++k) {
-            const bool have = k < s->n_kinds;
+            const bool have = any_user && k < s->n_kinds;
             char head[320];
             snprintf(head, sizeof head, "// kind %d: %s\ntemplate <typename R> __device__ inline bool drt_user_intersect_%d(const R* p, V3<R> o, V3<R> d, R& t)\n{\n",
                      k, have && s->kinds[k].name ? s->kinds[k].name : "(none)", k);

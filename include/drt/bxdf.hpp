@@ -21,7 +21,7 @@
 
 namespace drt {
 
-enum class BxDFKind { Diffuse, Specular, Mirror, Other };
+enum class BxDFKind { Diffuse, Specular, Mirror, Other, User };
 
 template <typename T>
 class BxDF {
@@ -35,6 +35,12 @@ public:
     virtual BxDFKind kind() const { return BxDFKind::Other; }
     virtual const Vector<T, 3, true>* parameter() const { return nullptr; }
     virtual double exponent() const { return 0; }
+    // BxDFKind::User: ANY other BxDF of the form colour x scalar lobe reaches the device by naming its kind and handing over sample()
+    // and operator() as ONE body of HIP source over its two draws and a record of two values -- exponent() and value1() --
+    // (include/drt_hip.h: drt_bxdf_kind_desc says what the source sees); parameter() is its colour.
+    virtual const char* device_kind_name() const { return nullptr; }
+    virtual const char* device_sample_src() const { return nullptr; }
+    virtual double value1() const { return 0; }
 };
 
 namespace internal {

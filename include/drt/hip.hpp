@@ -65,6 +65,8 @@ struct FlatScene {
     std::vector<std::vector<uint32_t>> mesh_indices;
     std::vector<drt_shape_kind_desc> kinds;    // caller-defined shape kinds (ShapeKind::User), by kind_name
     std::vector<double> user_params;           // n_shapes x 4: values 4..7 of the shapes' records
+    std::vector<drt_bxdf_kind_desc> bxdf_kinds;   // caller-defined BxDF kinds (BxDFKind::User), by name
+    std::vector<double> user_bxdf_params;      // n_materials: value 1 of the materials' records
 
     drt_scene_desc desc() const
     {
@@ -79,10 +81,14 @@ struct FlatScene {
         d.params = params.data();
         d.requires_grad = requires_grad.data();
         d.n_meshes = (int32_t)meshes.size();
-        d.n_kinds = (int32_t)kinds.size();
+        d.n_kinds = kinds.empty() ? (bxdf_kinds.empty() ? 0 : -1) : (int32_t)kinds.size();
         d.meshes = meshes.data();
         d.kinds = kinds.data();
         d.user_params = kinds.empty() ? nullptr : user_params.data();
+        d.n_bxdf_kinds = (int32_t)bxdf_kinds.size();
+        d.reserved2 = 0;
+        d.bxdf_kinds = bxdf_kinds.data();
+        d.user_bxdf_params = bxdf_kinds.empty() ? nullptr : user_bxdf_params.data();
         return d;
     }
 
@@ -109,6 +115,11 @@ struct FlatScene {
         }
         if (!kinds.empty())
             mix(user_params.data(), user_params.size() * sizeof(double));
+        mix_n(bxdf_kinds.size());
+        for (const drt_bxdf_kind_desc& k : bxdf_kinds)
+            mix(k.sample_src, std::strlen(k.sample_src));
+        if (!bxdf_kinds.empty())
+            mix(user_bxdf_params.data(), user_bxdf_params.size() * sizeof(double));
         mix_n(materials.size());
         for (const drt_material_desc& m : materials) {
             mix(&m.type, sizeof m.type); mix(&m.param, sizeof m.param); mix(&m.exponent, sizeof m.exponent);
@@ -206,12 +217,30 @@ inline FlatScene<T> flatten(const Scene<T>& scene)
                     md.type = DRT_BXDF_SPECULAR;
                 else if (b->kind() == BxDFKind::Mirror)
                     md.type = DRT_BXDF_MIRROR;
-                else
-                    throw std::runtime_error("drt::hip: BxDF type has no device record");
+                else if (b->kind() == BxDFKind::User) {
+                    // any other BxDF of the form colour x scalar: its own sample-and-evaluate body, compiled into the scene's path kernel
+                    if (!b->device_kind_name() || !b->device_sample_src() || !b->parameter())
+                        throw std::runtime_error("drt::hip: a BxDFKind::User material needs device_kind_name(), device_sample_src() and parameter()");
+                    int k = -1;
+                    for (std::size_t i = 0; i < f.bxdf_kinds.size(); ++i)
+                        if (std::strcmp(f.bxdf_kinds[i].name, b->device_kind_name()) == 0)
+                            k = (int)i;
+                    if (k < 0) {
+                        if (f.bxdf_kinds.size() >= DRT_MAX_USER_BXDF_KINDS)
+                            throw std::runtime_error("drt::hip: more caller-defined BxDF kinds in one scene than the device path takes (DRT_MAX_USER_BXDF_KINDS)");
+                        drt_bxdf_kind_desc kd{b->device_kind_name(), b->device_sample_src()};
+                        k = (int)f.bxdf_kinds.size();
+                        f.bxdf_kinds.push_back(kd);
+                    }
+                    md.type = DRT_BXDF_USER + k;
+                } else
+                    throw std::runtime_error("drt::hip: BxDF type has no device record (kind() reports neither one of the library's kinds "
+                                             "nor BxDFKind::User with its source)");
                 md.param = md.type == DRT_BXDF_MIRROR ? -1 : param_index(*b->parameter());
                 md.exponent = b->exponent();
                 it = material_of.emplace(b, (int)f.materials.size()).first;
                 f.materials.push_back(md);
+                f.user_bxdf_params.push_back(b->value1());
             }
             sd.material = it->second;
         }

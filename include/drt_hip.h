@@ -82,7 +82,9 @@ enum { DRT_SHAPE_PLANE = 0, DRT_SHAPE_SPHERE = 1, DRT_SHAPE_MESH = 2,
                              shape.hpp:11-35 -- `mesh` = index into drt_scene_desc.kinds */ };
 enum { DRT_BXDF_DIFFUSE = 0, DRT_BXDF_SPECULAR = 1,
        DRT_BXDF_MIRROR = 2 /* bxdf.hpp:126-144 repaired: f = 1/cos, dir = reflect(dir_in, n), pdf 1; param = -1;
-                              its sample discards two draws (see drt_rng_u31) */ };
+                              its sample discards two draws (see drt_rng_u31) */,
+       DRT_BXDF_USER = 3   /* DRT_BXDF_USER + k: a BxDF of the caller-defined kind k (drt_bxdf_kind_desc): any other subclass of
+                              BxDF<T>, bxdf.hpp:12-25, whose value is colour x a scalar lobe */ };
 
 typedef struct drt_shape_desc {
     int32_t type;      /* DRT_SHAPE_* */
@@ -136,8 +138,23 @@ typedef struct drt_mesh_desc {
 typedef struct drt_material_desc {
     int32_t type;      /* DRT_BXDF_* */
     int32_t param;     /* index of the colour parameter (bxdf.hpp:82,122 m_color); MIRROR: -1 */
-    double exponent;   /* SPECULAR only (bxdf.hpp:123), not differentiable */
+    double exponent;   /* SPECULAR only (bxdf.hpp:123), not differentiable.  USER: value 0 of the BxDF's record (value 1:
+                          drt_scene_desc.user_bxdf_params) */
 } drt_material_desc;
+
+/* A caller-defined BxDF (ABI v8): what a subclass of the reference's BxDF<T> plugin interface (bxdf.hpp:12-25: sample(normal,
+ * dir_in) -> (dir_out, pdf) and operator()(normal, dir_in, dir_out) -> f) becomes on the device, for BxDFs of the form
+ * f = colour parameter x scalar (all of the reference's are).  ONE body, HIP source, compiled at run time into the scene's path kernel:
+ *     template <typename R> void bxdf(const R* p, V3<R> n, V3<R> d, R u1, R u2, V3<R>& wo, R& pdf, R& bs) { <sample_src> }
+ * p = the BxDF's record of 2 values, n = the surface normal as the shape returns it, d = the direction of the ARRIVING ray
+ * (dir_in = -d), u1 / u2 = the two uniform draws sample() consumes, in its order (every BxDF of this build consumes exactly two:
+ * drt_rng_u31); out: wo = the sampled direction, pdf = its density, bs = the scalar with f(n, -d, wo) = colour x bs.  Also
+ * available: make_frame(n, t, b), sincospi_r(x, &s, &c), pow_r, sqrt_r (csrc/drt_device.h).  Same limits as caller-defined shapes. */
+#define DRT_MAX_USER_BXDF_KINDS 2
+typedef struct drt_bxdf_kind_desc {
+    const char* name;
+    const char* sample_src;
+} drt_bxdf_kind_desc;
 
 typedef struct drt_emitter_desc {
     int32_t param;     /* index of the emission parameter (emitter.hpp:24) */
@@ -153,10 +170,14 @@ typedef struct drt_scene_desc {
     const double* params;                /* n_params x 3 (RGB) */
     const uint8_t* requires_grad;        /* n_params, NULL = all true */
     int32_t n_meshes;
-    int32_t n_kinds;                     /* (ABI <= 7: reserved, 0) caller-defined shape kinds; 0: the fields below are not read */
+    int32_t n_kinds;                     /* (ABI <= 7: reserved, 0) caller-defined shape kinds; -1: none, but caller-defined BxDF kinds
+                                            below (n_bxdf_kinds is read); 0: none of the fields behind `meshes` is read */
     const drt_mesh_desc* meshes;
     const drt_shape_kind_desc* kinds;    /* n_kinds */
     const double* user_params;           /* n_shapes x 4: values 4..7 of every shape's record (read for USER shapes only), or NULL: zeros */
+    int32_t n_bxdf_kinds, reserved2;     /* caller-defined BxDF kinds; 0: the fields below are not read (n_kinds == 0 too: neither are these) */
+    const drt_bxdf_kind_desc* bxdf_kinds;
+    const double* user_bxdf_params;      /* n_materials: value 1 of every material's record (read for USER BxDFs only), or NULL: zeros */
 } drt_scene_desc;
 
 typedef struct drt_camera_desc {

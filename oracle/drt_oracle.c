@@ -306,6 +306,18 @@ static v3 bxdf_sample(const drt_material_desc* m, v3 normal, v3 dir_in, rng_t* r
         return v3_make(0, 0, 0);
     }
     v3 frame[3];
+    if (m->type >= DRT_BXDF_USER) {
+        /* a caller-defined kind: this CHECKER knows the test kind "coslobe" (the CosLobeBxDF plugin of oracle/ref_harness.cpp restated):
+         * a power-cosine lobe around the normal, cos(theta) = u1^(1 / (k + 1)), pdf = (k + 1) / (2 pi) cos^k */
+        double k = m->exponent;
+        double cos_t = pow(rng_uniform(rng), 1 / (k + 1));
+        double theta = acos(cos_t);
+        double phi = 2 * k_pi * rng_uniform(rng);
+        make_frame(normal, frame);
+        v3 dir = angle_to_dir(theta, phi, frame);
+        *pdf = (k + 1) / (2 * k_pi) * pow(cos_t, k);
+        return dir;
+    }
     if (m->type == DRT_BXDF_MIRROR) {
         /* bxdf.hpp:137-142 (reflect(dir_in, normal), pdf 1).  Convention of this build (harness
          * plugin, host API, oracle, device): EVERY BxDF sample advances the stream by two draws, so a
@@ -347,6 +359,11 @@ static double bxdf_scalar(const drt_material_desc* m, v3 normal, v3 dir_in, v3 d
     if (m->type == DRT_BXDF_MIRROR) {
         *is_div = 1;                      /* bxdf.hpp:133-135: 1 / cos_theta, on every channel */
         return v3_dot(normal, dir_out);
+    }
+    if (m->type >= DRT_BXDF_USER) {       /* "coslobe": colour * (k + 2) / (2 pi) cos^k(theta_out), 0 below the surface */
+        double c = v3_dot(normal, dir_out);
+        *is_div = 0;
+        return c > 0 ? (m->exponent + 2) / (2 * k_pi) * pow(c, m->exponent) : 0.0;
     }
     v3 halfway = v3_normalize(v3_add(dir_in, dir_out));
     double cos_theta = v3_dot(normal, halfway);
@@ -546,6 +563,15 @@ int drt_oracle_render(const drt_scene_desc* scene, const drt_camera_desc* cam,
             return DRT_ERR_UNSUPPORTED;      /* (a kind this checker has no restatement of) */
     }
     g_scene = scene;
+    for (int i = 0; i < scene->n_materials; ++i) {
+        const int t = scene->materials[i].type;
+        if (t >= DRT_BXDF_USER) {             /* a caller-defined BxDF kind: this checker restates "coslobe" only */
+            const int k = t - DRT_BXDF_USER;
+            if (scene->n_kinds == 0 || k >= scene->n_bxdf_kinds || !scene->bxdf_kinds || !scene->bxdf_kinds[k].name ||
+                strcmp(scene->bxdf_kinds[k].name, "coslobe") != 0)
+                return DRT_ERR_UNSUPPORTED;
+        }
+    }
     const int W = cam->width, H = cam->height, spp = rp->spp;
     const int unbiased = (oracle_flags & DRT_ORACLE_UNBIASED) != 0;
     const int n_shards = rp->n_shards > 1 ? rp->n_shards : 1;

@@ -174,6 +174,14 @@ SMALL = [
          absorb=0.5, seed=32, adjoint_seed=11),
     dict(name="s3_unbiased_disc_32x32x4_rr", scene="cornell_disc", width=32, height=32, spp=4, min_bounces=2,
          absorb=0.35, seed=33, unbiased=True),
+    # a BxDF the library has NO code for (a BxDF<T> subclass, bxdf.hpp:12-25): the CosLobeBxDF plugin of the harness inside the
+    # unmodified reference path tracer; the device compiles the same sample-and-evaluate body from the caller's HIP source
+    dict(name="b1_coslobe_48x40x8_d6", scene="cornell_coslobe", width=48, height=40, spp=8, min_bounces=6,
+         absorb=1.0, seed=51, dump_paths=96),
+    dict(name="b2_coslobe_disc_40x32x8_rr_adj", scene="cornell_coslobe_disc", width=40, height=32, spp=8, min_bounces=1,
+         absorb=0.5, seed=52, adjoint_seed=12),
+    dict(name="b3_unbiased_coslobe_32x28x4_rr", scene="cornell_coslobe", width=32, height=28, spp=4, min_bounces=2,
+         absorb=0.35, seed=53, unbiased=True),
     # the reference's uniform() returns exactly 1.0 for path 2133's roulette draw at depth 5 (rand() == RAND_MAX): with absorb == 1
     # the path survives, p = 1 - absorb = 0, and the reference divides by it -- a NaN pixel and NaN gradients IN THE FIXTURE.
     # The restatement reproduces that; the device ends the path (the one deliberate deviation)

@@ -139,8 +139,11 @@ def write_scene_file(path: str, scene, cam, rp, rng_mode: int, backward: bool, d
         for rgb, rg in zip(scene.params, scene.requires_grad):
             f.write(f"{rgb[0]!r} {rgb[1]!r} {rgb[2]!r} {int(rg)}\n")
         f.write(f"materials {len(scene.materials)}\n")
-        for t, p, e in scene.materials:
-            f.write(f"{t} {p} {e!r}\n")
+        for i, (t, p, e) in enumerate(scene.materials):
+            extra = ""
+            if t >= 3:      # a BxDF of a caller-defined kind: the harness holds the same class as a plugin of the reference, by name
+                extra = f" {scene.bxdf_kinds[t - 3][0]} {scene.user_m.get(i, 0.0)!r}"
+            f.write(f"{t} {p} {e!r}{extra}\n")
         f.write(f"emitters {len(scene.emitters)}\n")
         for p in scene.emitters:
             f.write(f"{p}\n")

@@ -67,8 +67,9 @@ MANY_PARAM_GOLDENS = ["p1_cornell_shapes_48x48x8_d8", "p2_params12_40x40x6_rr_ad
                       "p4_params40_32x32x4_d6", "p6_cornell_shapes_default_roulette_40x40x8"]
 SMALL_GOLDENS += MANY_PARAM_GOLDENS
 # shapes of caller-defined kinds (drt_shape_kind_desc): a disc and an axis-aligned box, the harness's plugins of the reference
-USER_SHAPE_GOLDENS = ["s1_disc_box_48x48x8_d6", "s2_disc_box_40x32x8_rr_adj"]
-USER_SHAPE_UNBIASED_GOLDENS = ["s3_unbiased_disc_32x32x4_rr"]
+# ... and a BxDF of a caller-defined kind (drt_bxdf_kind_desc): a power-cosine lobe, the harness's CosLobeBxDF plugin
+USER_SHAPE_GOLDENS = ["s1_disc_box_48x48x8_d6", "s2_disc_box_40x32x8_rr_adj", "b1_coslobe_48x40x8_d6", "b2_coslobe_disc_40x32x8_rr_adj"]
+USER_SHAPE_UNBIASED_GOLDENS = ["s3_unbiased_disc_32x32x4_rr", "b3_unbiased_coslobe_32x28x4_rr"]
 
 
 UNBIASED_GOLDENS = ["u1_unbiased_cornell_40x30x4_rr", "u2_unbiased_cornell_48x48x4_d4",

@@ -1,5 +1,5 @@
-// A shape the library does not know, written the way a user of the reference writes one -- a subclass of drt::Shape<T>
-// (shape.hpp:11-35) -- rendered by the device through drt::hip::render and by the host API's own per-ray loop (render.cpp:72-86)
+// A shape and a material the library does not know, written the way a user of the reference writes them -- subclasses of
+// drt::Shape<T> (shape.hpp:11-35) and drt::BxDF<T> (bxdf.hpp:12-25) -- rendered by the device through drt::hip::render and by the host API's own per-ray loop (render.cpp:72-86)
 // on the same per-path random streams.  The one additive piece is describe(): the record and the two bodies as HIP source.
 // Prints "ok <max relative gradient difference>" and exits 0, or says what differs.
 #include <cmath>
@@ -62,17 +62,52 @@ private:
     double m_r;
 };
 
+// ... and a material the library does not know: a power-cosine lobe around the normal, colour x (k + 2) / (2 pi) cos^k
+class CosLobe : public BxDF<T> {
+public:
+    CosLobe(const Var3& color, double k) : m_color(color), m_k(k) { }
+    Var3 operator()(const Vec3& normal, const Vec3&, const Vec3& dir_out) const override
+    {
+        const double c = dot(normal, dir_out);
+        const double factor = c > 0 ? (m_k + 2) / (2 * pi) * std::pow(c, m_k) : 0.0;
+        return factor * m_color;
+    }
+    std::tuple<Vec3, double> sample(const Vec3& normal, const Vec3&) const override
+    {
+        const double cos_t = std::pow(random::uniform(), 1 / (m_k + 1));
+        const double theta = std::acos(cos_t);
+        const double phi = 2 * pi * random::uniform();
+        const auto frame = internal::make_frame(normal);
+        return std::make_tuple(internal::angle_to_dir(theta, phi, frame), (m_k + 1) / (2 * pi) * std::pow(cos_t, m_k));
+    }
+    BxDFKind kind() const override { return BxDFKind::User; }
+    const Var3* parameter() const override { return &m_color; }
+    double exponent() const override { return m_k; }
+    const char* device_kind_name() const override { return "coslobe"; }
+    const char* device_sample_src() const override
+    {
+        return "(void)d; const R k = p[0]; const R ct = pow_r(u1, R(1) / (k + R(1))); const R st = sqrt_r(max_r(R(0), R(1) - ct * ct));\n"
+               "R sphi, cphi; sincospi_r(R(2) * u2, &sphi, &cphi); V3<R> t, b; make_frame(n, t, b);\n"
+               "wo = t * (cphi * st) + b * (sphi * st) + n * ct; pdf = (k + R(1)) * R(0.15915494309189535) * pow_r(ct, k);\n"
+               "const R c = dot(n, wo); bs = c > R(0) ? (k + R(2)) * R(0.15915494309189535) * pow_r(c, k) : R(0);\n";
+    }
+private:
+    Var3 m_color;
+    double m_k;
+};
+
 int main()
 {
     // the reference's scene, render.cpp:26-59, and a tilted disc with an albedo of its own in it
     Var3 red(Vec3{0.5, 0., 0.}, true), green(Vec3{0., 0.5, 0.}, true), white(Vec3(0.5), true), emission(Vec3(1.), true);
-    Var3 disc_albedo(Vec3{0.7, 0.6, 0.2}, true);
+    Var3 disc_albedo(Vec3{0.7, 0.6, 0.2}, true), lobe_albedo(Vec3{0.8, 0.7, 0.5}, true);
     auto diffuse_red = std::make_shared<DiffuseBxDF<T>>(red);
     auto diffuse_green = std::make_shared<DiffuseBxDF<T>>(green);
     auto diffuse_white = std::make_shared<DiffuseBxDF<T>>(white);
     auto diffuse_disc = std::make_shared<DiffuseBxDF<T>>(disc_albedo);
     auto emitter = std::make_shared<AreaEmitter<T>>(emission);
-    Sphere<T> sphere_front(Vec3{0., 0., 3.}, 1., diffuse_white);
+    auto lobe = std::make_shared<CosLobe>(lobe_albedo, 6.0);
+    Sphere<T> sphere_front(Vec3{0., 0., 3.}, 1., lobe);
     Sphere<T> sphere_back(Vec3{-1., 1., 4.5}, 1., diffuse_white);
     Plane<T> left(Vec3{-1., 0., 0.}, -3., diffuse_red), right(Vec3{1., 0., 0.1}, -3., diffuse_green);
     Plane<T> back(Vec3{0., 0., -1.}, -6., diffuse_white), front(Vec3{0, 0, 1}, 0, diffuse_white);
@@ -86,7 +121,7 @@ int main()
     Camera<T> cam(W, H);
     cam.look_at(Vec3{0., 0., 0.}, Vec3{0., 0., 1.});
     Pathtracer<T> tracer(1.0, 5);
-    std::vector<Var3*> params = {&red, &green, &white, &emission, &disc_albedo};
+    std::vector<Var3*> params = {&red, &green, &white, &emission, &disc_albedo, &lobe_albedo};
 
     // the host API's own loop (render.cpp:72-86) on the device's per-path streams
     std::vector<Vec3> cpu(W * H, Vec3(0.));
@@ -126,7 +161,7 @@ int main()
         for (int c = 0; c < 3; ++c)
             img_worst = std::fmax(img_worst, std::fabs(dev[i][c] - cpu[i][c]));
     hip::release_contexts();
-    if (!(worst <= 1e-9 * scale) || !(img_worst <= 1e-6) || !(std::fabs(g_cpu[4][0]) > 0)) {
+    if (!(worst <= 1e-9 * scale) || !(img_worst <= 1e-6) || !(std::fabs(g_cpu[4][0]) > 0) || !(std::fabs(g_cpu[5][0]) > 0)) {
         std::printf("FAILED: gradient difference %.3g of %.3g, image difference %.3g, d/d(disc albedo) %.3g\n", worst, scale, img_worst, g_cpu[4][0]);
         return 1;
     }

@@ -30,7 +30,7 @@ scenes = ["cornell", "cornell_specular", "cornell_walls", "cornell_emissive_wall
           "mesh6x8", "mesh10x12f5",
           # round 6: more parameters than the register form holds (the general form of the one-launch kernels against the tape), and
           # shapes of caller-defined kinds (the one-launch kernels only: no second route to compare, the restatement is the check)
-          "cornell_shapes", "params12", "params40", "mesh10x12f12", "cornell_disc_box"]
+          "cornell_shapes", "params12", "params40", "mesh10x12f12", "cornell_disc_box", "cornell_coslobe_disc"]
 worst = 0.0
 t0 = time.time()
 for case in range(n_cases):
@@ -60,7 +60,7 @@ for case in range(n_cases):
     r.upload_scene(scene)
     t1 = time.time()
     a = r.render(cam, rp, backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
-    user_kinds = bool(scene.kinds)
+    user_kinds = bool(scene.kinds) or bool(scene.bxdf_kinds)
     q = a if user_kinds else r.render(cam, dataclasses.replace(rp, bounces_per_launch=1), backward=True, f64=True, unbiased=unbiased, adjoint=adjoint)
     f = r.render(cam, rp, backward=True, unbiased=unbiased, adjoint=adjoint)
     dt = time.time() - t1

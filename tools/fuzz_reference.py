@@ -24,7 +24,7 @@ scenes = ["cornell", "cornell_specular", "cornell_walls", "cornell_emissive_wall
           "random19", "mesh6x8", "mesh10x12f5",
           # round 6: more parameters than the one-launch kernels' register form holds (their general form), and shapes of
           # caller-defined kinds (the Disc / AABox plugins of the harness inside the reference)
-          "cornell_shapes", "params12", "params20", "mesh10x12f12", "cornell_disc_box", "cornell_disc"]
+          "cornell_shapes", "params12", "params20", "mesh10x12f12", "cornell_disc_box", "cornell_disc", "cornell_coslobe", "cornell_coslobe_disc"]
 worst64 = worst32 = 0.0
 n_chaotic = 0
 t0 = time.time()
