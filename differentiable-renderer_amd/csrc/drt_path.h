@@ -670,7 +670,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
 // (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
 template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false, bool LOSS = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS) : ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? ((NP == DRT_NP_ANY && SG::n == 0) ? 4 : (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS)) :   /* (general form + the kind-sorted program: 34 KB of LDS) */ ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)

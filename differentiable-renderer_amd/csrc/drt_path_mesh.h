@@ -32,7 +32,7 @@
 enum { DRT_MS_DONE = 0, DRT_MS_NEW = 1, DRT_MS_HIT = 2, DRT_MS_WALK = 3 };
 
 template <typename R, bool SPEC, int NP, int NC>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4) ? DRT_MESH_MIN_BLOCKS : 1)
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4) ? (NP == DRT_NP_ANY ? DRT_MESH_MIN_BLOCKS - 1 : DRT_MESH_MIN_BLOCKS) : 1)   // (the general form's tables: 41 KB of LDS, three blocks per CU)
 k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
             DevBvh<R> bvh, uint32_t* __restrict__ ovf, uint32_t ovf_stride,
             double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,

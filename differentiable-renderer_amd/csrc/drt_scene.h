@@ -282,7 +282,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
         for (int k = 0; k < DRT_MAX_USER_BXDF_KINDS; ++k) {
             const bool have = k < n_bxdf_kinds;
             char head[320];
-            snprintf(head, sizeof head, "// BxDF kind %d: %s\ntemplate <typename R> __device__ inline void drt_user_bxdf_%d(const R* p, V3<R> n, V3<R> d, R u1, R u2, "
+            snprintf(head, sizeof head, "// BxDF kind %d: %.64s\ntemplate <typename R> __device__ inline void drt_user_bxdf_%d(const R* p, V3<R> n, V3<R> d, R u1, R u2, "
                                         "V3<R>& wo, R& pdf, R& bs)\n{\n", k, have && s->bxdf_kinds[k].name ? s->bxdf_kinds[k].name : "(none)", k);
             user_header += head;
             user_header += have ? s->bxdf_kinds[k].sample_src : "(void)p; (void)d; (void)u1; (void)u2; wo = n; pdf = R(1); bs = R(0);";
@@ -291,7 +291,7 @@ int upload_scene_one(drt_hip_ctx* ctx, const drt_scene_desc* s)
         for (int k = 0; k < DRT_MAX_USER_KINDS; ++k) {
             const bool have = any_user && k < s->n_kinds;
             char head[320];
-            snprintf(head, sizeof head, "// kind %d: %s\ntemplate <typename R> __device__ inline bool drt_user_intersect_%d(const R* p, V3<R> o, V3<R> d, R& t)\n{\n",
+            snprintf(head, sizeof head, "// kind %d: %.64s\ntemplate <typename R> __device__ inline bool drt_user_intersect_%d(const R* p, V3<R> o, V3<R> d, R& t)\n{\n",
                      k, have && s->kinds[k].name ? s->kinds[k].name : "(none)", k);
             user_header += head;
             user_header += have ? s->kinds[k].intersect_src : "(void)p; (void)o; (void)d; (void)t; return false;";
