@@ -163,3 +163,44 @@ def test_full_size_config_on_one_gpu_equals_its_eight_shards(pkg, hip, config):
     # (a lane adds up the gradient terms of its sample range in f32 before the f64 block sums; the whole frame and a
     # shard cut the 1024 samples into different ranges: equal to f32 accumulation, measured 1.2e-7)
     np.testing.assert_allclose(g_sum, grads, rtol=2e-6)
+
+
+@pytest.mark.timeout(900)
+def test_config3_frame_with_an_albedo_per_shape_full_size(pkg, hip, oracle):
+    """BASELINE config 3's frame (512 x 512, 64 spp, depth 8, fwd+bwd) with an albedo parameter per SHAPE of the reference's
+    scene -- 10 parameters, the one-launch kernel's general form at the size bench.py's `many_parameters` view times: one
+    launch; the frame's properties (every path traced, linear in the emission, the unused `white` has no gradient, the per-shape
+    gradients of the white shapes sum to what the shared `white` of the plain scene gets -- all their albedos differ, so compare
+    through the light instead: its gradient does not know how the walls are parametrised); four whole rows against the fp64
+    restatement, exactly in the f64 mode and to the stated f32 bounds; rows of the full frame = the rows rendered alone."""
+    scene = pkg.scene_by_name("cornell_shapes")
+    assert scene.n_params == 10
+    cam = pkg.cornell_camera(512, 512)
+    rp = pkg.RenderParams(spp=64, min_bounces=8, absorb=1.0, seed=1)
+    hip.upload_scene(scene)
+    img, grads, st = hip.render(cam, rp, backward=True)
+    assert st["paths"] == 512 * 512 * 64 and st["kernels"]["path"]["launches"] == 1 and st["kernels"]["shade"]["launches"] == 0
+    assert np.isfinite(img).all() and np.isfinite(grads).all()
+    e = scene.param_names.index("emission")
+    total = img.astype(np.float64).sum((0, 1)) * rp.spp
+    np.testing.assert_allclose(grads[e] * np.array(scene.params[e]), total, rtol=5e-6)    # linear in the emission
+    assert not grads[scene.param_names.index("white")].any()                              # declared (render.cpp:28), no shape's colour here
+    again, g2, _ = hip.render(cam, rp, backward=True)
+    np.testing.assert_array_equal(again, img)
+    np.testing.assert_array_equal(g2, grads)                                              # bitwise reproducible
+    whole = np.zeros_like(grads)
+    for row in (3, 200, 317, 508):
+        rr = one_row(rp, row, 512)
+        ref = oracle.render(scene, cam, rr, backward=True)
+        i64, g64, s64 = hip.render(cam, rr, backward=True, f64=True)
+        assert s64["kernels"]["path"]["launches"] == 1 and s64["segments"] == ref["stats"]["segments"]
+        assert grad_rel_err(g64, ref["grads"]) < 1e-9
+        np.testing.assert_allclose(i64[row], ref["image"][row].astype(np.float32), rtol=2e-7, atol=1e-12)
+        i32, g32, s32 = hip.render(cam, rr, backward=True)
+        assert abs(s32["segments"] - ref["stats"]["segments"]) <= 64
+        assert grad_rel_err(g32, ref["grads"]) <= 1e-4
+        bad = np.abs(i32[row].astype(np.float64) - ref["image"][row]).max(-1) > 2e-4 * np.abs(ref["image"][row]).max()
+        assert bad.sum() <= 1
+        np.testing.assert_array_equal(i32[row], img[row])       # the full frame's row IS that row rendered alone
+        whole += g32
+    assert np.isfinite(whole).all()
