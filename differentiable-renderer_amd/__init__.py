@@ -453,7 +453,7 @@ def cornell_with_user_shapes(box: bool = True) -> Scene:
     return s
 
 
-def many_param_scene(n_params: int, n_geometry: int = 0, seed: int = 77, zero_channels: bool = True) -> Scene:
+def many_param_scene(n_params: int, n_geometry: int = 0, seed: int = 77, zero_channels: bool = True, emissive_spheres: bool = True) -> Scene:
     """A closed box of six walls and small spheres, every shape a diffuse albedo parameter: `n_params` parameters in all
     (two emissions, n_params - 2 albedos handed to the shapes round-robin).  The GEOMETRY is that of the scene with
     `n_geometry` parameters (default: n_params, at most 64) -- `many_param_scene(4, 64)` is the 64-parameter scene's room with three
@@ -489,7 +489,7 @@ def many_param_scene(n_params: int, n_geometry: int = 0, seed: int = 77, zero_ch
     geo = np.random.RandomState(seed + 1)         # (the geometry's own stream: the same room whatever n_params)
     for i in range(max(0, n_bxdf_shapes - 6)):
         c = (geo.uniform(-2.4, 2.4), geo.uniform(-2.4, 1.6), geo.uniform(1.5, 5.4))
-        s.sphere(c, geo.uniform(0.15, 0.45), mat(), lights[i] if i < n_em - 1 else -1)
+        s.sphere(c, geo.uniform(0.15, 0.45), mat(), lights[i] if (i < n_em - 1 and emissive_spheres) else -1)
     s.sphere((0., 3., 3.), 1., -1, lights[-1])
     return s
 
@@ -604,9 +604,11 @@ def scene_by_name(name: str) -> Scene:
         return cornell_with_user_shapes(box=True)
     if name == "cornell_shapes":
         return cornell_box(per_shape=True)
-    if name.startswith("params"):        # params<n>[of<m>]: n parameters in the room of the m-parameter scene
-        n, _, m = name[len("params"):].partition("of")
-        return many_param_scene(int(n), int(m) if m else 0)
+    if name.startswith("params"):        # params<n>[of<m>][x]: n parameters in the room of the m-parameter scene; x: no sphere emits
+        body = name[len("params"):]
+        plain = body.endswith("x")
+        n, _, m = body.rstrip("x").partition("of")
+        return many_param_scene(int(n), int(m) if m else 0, emissive_spheres=not plain)
     if name == "cornell_emissive_wall":
         return cornell_box(emissive_wall=True)
     if name == "cornell_mirror":
