@@ -237,6 +237,10 @@ struct Tangents {
 // A zero channel (red = (0.5, 0, 0), render.cpp:26): vertex j's own factor is the only zero of the channel iff zc_ch == 1, and
 // then d/dc of that channel is T_ch (the product WITHOUT the zero factor, which is what the lane's T holds) -- else 0.
 #define DRT_NP_ANY (-1)
+#ifndef DRT_LOCKSTEP_MIN_BLOCKS
+#define DRT_LOCKSTEP_MIN_BLOCKS 6    // blocks per CU the f32 lockstep diffuse k_path is compiled for: 80 registers + 24 bytes of scratch per lane; at five (96
+                                     // registers, no scratch) it is slower: profiles/r06_scratch_vs_waves.txt
+#endif
 #ifndef DRT_REGEN_MIN_BLOCKS
 #define DRT_REGEN_MIN_BLOCKS 5       // blocks per CU the f32 regenerating diffuse k_path is compiled for
 #endif
@@ -670,7 +674,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
 // (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
 template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false, bool LOSS = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : 6) : ((sizeof(R) == 4 && NP <= 4) ? ((NP == DRT_NP_ANY && SG::n == 0) ? 4 : (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS)) :   /* (general form + the kind-sorted program: 34 KB of LDS) */ ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : DRT_LOCKSTEP_MIN_BLOCKS) : ((sizeof(R) == 4 && NP <= 4) ? ((NP == DRT_NP_ANY && SG::n == 0) ? 4 : (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS)) :   /* (general form + the kind-sorted program: 34 KB of LDS) */ ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)
