@@ -13,7 +13,8 @@ dev = torch.device("cuda", 0); torch.zeros(1, device=dev)
 n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 a, b = pkg.HipRenderer(0), pkg.HipRenderer(0)          # a: the context under test, b: the synchronous twin
-names = ["cornell", "cornell_specular", "cornell_walls", "random3", "mesh6x8"]
+names = ["cornell", "cornell_specular", "cornell_walls", "random3", "mesh6x8",
+         "cornell_shapes", "params12", "cornell_disc_box", "cornell_coslobe"]      # (round 6: the general form, caller-defined kinds)
 scene = None
 pending = []                                            # (out tensor, grad tensor | None, expected image, expected grads | None)
 def flush():
