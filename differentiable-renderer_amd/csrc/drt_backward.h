@@ -345,7 +345,12 @@ __device__ inline V3<R> path_seed(const BatchArgs& a, const float* __restrict__ 
 
 // ---- K6 (kernel; the tape walk and the accumulators it uses are defined above) ----
 template <typename R, int NP>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : 1)
+#ifndef DRT_BACKWARD_GEN_MIN_BLOCKS
+#define DRT_BACKWARD_GEN_MIN_BLOCKS 4   // blocks per CU K6's general accumulator (NP = 0: any number of parameters, an albedo per face) is compiled for: 128
+                                        // registers + 88 B of scratch per lane (the compiler's own choice: 150, three waves per SIMD).  An albedo per face,
+                                        // 1024 x 1024 x 8, ms per step, builds alternating: 0.79 -> 0.74 at four; five: 1.92 (tools/ab_kernel.py)
+#endif
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : ((sizeof(R) == 4 && NP == 0) ? DRT_BACKWARD_GEN_MIN_BLOCKS : 1))
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
            const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad,

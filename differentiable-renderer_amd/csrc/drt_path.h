@@ -238,8 +238,16 @@ struct Tangents {
 // then d/dc of that channel is T_ch (the product WITHOUT the zero factor, which is what the lane's T holds) -- else 0.
 #define DRT_NP_ANY (-1)
 #ifndef DRT_LOCKSTEP_MIN_BLOCKS
-#define DRT_LOCKSTEP_MIN_BLOCKS 6    // blocks per CU the f32 lockstep diffuse k_path is compiled for: 80 registers + 24 bytes of scratch per lane; at five (96
-                                     // registers, no scratch) it is slower: profiles/r06_scratch_vs_waves.txt
+#define DRT_LOCKSTEP_MIN_BLOCKS 7    // blocks per CU the f32 lockstep diffuse k_path of <= 4 parameters is compiled for: 72 registers + 60 bytes of scratch
+                                     // per lane.  Config 3's frame, ms per launch, builds alternating in one process: five (96 registers, no scratch)
+                                     // 0.716, six (80 + 24 B) 0.695-0.702, seven 0.673, eight (64 + 96 B) 0.694: profiles/r06_scratch_vs_waves.txt
+#endif
+#ifndef DRT_LOCKSTEP_GEN_MIN_BLOCKS
+#define DRT_LOCKSTEP_GEN_MIN_BLOCKS 6   // ... its general form (any number of parameters): 80 registers + 32 B; seven 0.735 -> 0.743, eight 0.777
+#endif
+#ifndef DRT_LOCKSTEP_SPEC_MIN_BLOCKS
+#define DRT_LOCKSTEP_SPEC_MIN_BLOCKS 6  // ... the kernels of <= 4 parameters that carry the glossy lobe (config 5): 80 registers + 32 B; config 5's shape
+                                        // (2048 x 2048, depth 16), ms per launch at 16 spp: five 7.92, six 7.79, seven 7.81 (tools/ab_config5.py)
 #endif
 #ifndef DRT_REGEN_MIN_BLOCKS
 #define DRT_REGEN_MIN_BLOCKS 5       // blocks per CU the f32 regenerating diffuse k_path is compiled for
@@ -660,6 +668,19 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
     return path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
 }
 
+// blocks per CU (= waves per SIMD) a k_path instantiation is compiled for (its register budget); the knobs are above
+template <size_t RB, bool SPEC, int NP, int NSG, bool REGEN>
+constexpr int path_min_blocks()
+{
+    if (RB == 4 && NP <= 4) {
+        if (!REGEN)
+            return SPEC ? (NP == DRT_NP_ANY ? 5 : DRT_LOCKSTEP_SPEC_MIN_BLOCKS) : (NP == DRT_NP_ANY ? DRT_LOCKSTEP_GEN_MIN_BLOCKS : DRT_LOCKSTEP_MIN_BLOCKS);
+        return (NP == DRT_NP_ANY && NSG == 0) ? 4             // (general form + the kind-sorted program: 34 KB of LDS)
+                                              : (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS);
+    }
+    return (RB == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1;
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------
 // The bounce loop is written WITHOUT per-lane branches: every lane of the wave executes every bounce of the sample --
 // a lane whose path has ended keeps tracing a stale ray whose results are never used (`live` guards every
@@ -672,9 +693,9 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // bookkeeping, the camera code runs whenever some lane starts over, the light's emission is added when the lane's
 // path ends.  ~35 % more instructions per bounce, but roulette-terminated renders (the reference's defaults, -b 1
 // -p 0.5: 2.5 vertices per path on average, some paths 20) keep their lanes busy.
-// (six blocks per CU = six waves per SIMD for the f32 lockstep kernels of up to four parameters: 80 VGPRs, no scratch)
+// (waves per SIMD by form: path_min_blocks above)
 template <typename R, bool SPEC, int NP, int NC, typename SG, bool REGEN = false, bool LOSS = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP <= 4 && !REGEN) ? (SPEC ? 5 : DRT_LOCKSTEP_MIN_BLOCKS) : ((sizeof(R) == 4 && NP <= 4) ? ((NP == DRT_NP_ANY && SG::n == 0) ? 4 : (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS)) :   /* (general form + the kind-sorted program: 34 KB of LDS) */ ((sizeof(R) == 8 && NP <= 4 && !REGEN && !SPEC) ? DRT_F64_MIN_BLOCKS : 1)))
+__global__ void __launch_bounds__(DRT_BLOCK, (path_min_blocks<sizeof(R), SPEC, NP, SG::n, REGEN>()))
 k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
        double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
        unsigned long long* __restrict__ total, double* __restrict__ gimg_part)
@@ -1013,8 +1034,13 @@ __device__ inline void unbiased_walk(const PathArgs& a, const PathSceneLds<R>& l
     }
 }
 
+#ifndef DRT_UNBIASED_MIN_BLOCKS
+#define DRT_UNBIASED_MIN_BLOCKS 4    // blocks per CU the f32 k_path_unbiased is compiled for: 128 registers + 96 B of scratch per lane.  Left to itself the
+                                     // compiler takes 153-173 registers (three / two waves per SIMD).  Config 3's frame, ms per launch, builds alternating:
+                                     // diffuse 5.47 -> 4.77 at four (five: 4.93, six: 5.56), with the glossy sphere 9.41 -> 6.65 (7.09, 7.98)
+#endif
 template <typename R, bool SPEC, int NP, typename SG>
-__global__ void __launch_bounds__(DRT_BLOCK)
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 ? DRT_UNBIASED_MIN_BLOCKS : 1))
 k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params, const float* __restrict__ adjoint,
                 double* __restrict__ gpart, double* __restrict__ fpart, uint32_t* __restrict__ counts,
                 unsigned long long* __restrict__ total)

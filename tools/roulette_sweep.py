@@ -17,11 +17,13 @@ def one():
     r.upload_scene(pkg.cornell_box())
     r.set_specialisation(pkg.SPECIALISE_NOW)
     cam = pkg.cornell_camera(512, 512)
-    rp = pkg.RenderParams(spp=64, min_bounces=1, absorb=0.5, seed=1)
+    # (SWEEP_MODE=d8: config 3 itself, every path to depth 8 -- the lockstep kernel -- under the same knobs)
+    rp = pkg.RenderParams(spp=64, min_bounces=8, absorb=1.0, seed=1) if os.environ.get("SWEEP_MODE") == "d8" else \
+         pkg.RenderParams(spp=64, min_bounces=1, absorb=0.5, seed=1)
     for _ in range(5):
         r.render(cam, rp, backward=True)
     best = None
-    for _ in range(9):
+    for _ in range(15 if os.environ.get("SWEEP_MODE") == "d8" else 9):
         _, _, st = r.render(cam, rp, backward=True, timing=True)
         ms = st["kernels"]["path"]["ms"]
         best = ms if best is None else min(best, ms)
@@ -34,7 +36,10 @@ if __name__ == "__main__":
         one()
     else:
         variants = [""] + [f"DRT_HIP_PATH_SPR={s}" for s in (64, 32, 16, 8, 4)] + [f"DRT_HIP_PATH_REGEN_MIN={m}" for m in (1, 4, 16, 24, 32)] + \
-                   ["DRT_HIP_PATH_REGEN=0"] + (os.environ.get("SWEEP_EXTRA", "").split(";") if os.environ.get("SWEEP_EXTRA") else [])
+                   ["DRT_HIP_PATH_REGEN=0"]
+        if os.environ.get("SWEEP_ONLY_EXTRA"):
+            variants = [""]
+        variants += os.environ.get("SWEEP_EXTRA", "").split(";") if os.environ.get("SWEEP_EXTRA") else []
         for v in variants:
             env = dict(os.environ, **dict(kv.split("=") for kv in v.split(",") if kv))
             out = subprocess.run([sys.executable, __file__, "one"], env=env, capture_output=True, text=True, timeout=600)
