@@ -350,7 +350,10 @@ template <typename R, int NP>
                                         // registers + 88 B of scratch per lane (the compiler's own choice: 150, three waves per SIMD).  An albedo per face,
                                         // 1024 x 1024 x 8, ms per step, builds alternating: 0.79 -> 0.74 at four; five: 1.92 (tools/ab_kernel.py)
 #endif
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? 4 : ((sizeof(R) == 4 && NP == 0) ? DRT_BACKWARD_GEN_MIN_BLOCKS : 1))
+#ifndef DRT_BACKWARD_MIN_BLOCKS
+#define DRT_BACKWARD_MIN_BLOCKS 4       // ... the register accumulators' kernel (NP = 4): config 4's K6, ms per step: 0.196 at four, 0.232 at three, 0.565 at five
+#endif
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && NP == 4) ? DRT_BACKWARD_MIN_BLOCKS : ((sizeof(R) == 4 && NP == 0) ? DRT_BACKWARD_GEN_MIN_BLOCKS : 1))
 k_backward(BatchArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
            const TapeRec<R>* __restrict__ tape, const uint32_t* __restrict__ nv,
            const float* __restrict__ adjoint, double* __restrict__ gpart, double* __restrict__ grad,

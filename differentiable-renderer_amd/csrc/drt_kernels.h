@@ -737,8 +737,12 @@ k_raygen(BatchArgs a, const DevScene<R>* __restrict__ sc, typename Q4<R>::T* __r
 // right here, while it is still in registers, and handed to the BVH walk if it reaches the mesh -- K2's analytic pass
 // (k_intersect) then only runs for the camera rays, and the queue is not read a second time (24 bytes per ray).  The
 // candidate list of a region is the region's own span of the candidate arrays; hit_next is the hit lane of the NEXT depth.
+#ifndef DRT_SHADE_MIN_BLOCKS
+#define DRT_SHADE_MIN_BLOCKS 1       // blocks per CU the f32 diffuse k_shade is compiled for (1 = the compiler's own choice: 66-89 registers, 5-7 waves per
+                                     // SIMD).  Config 4's shade launches, 1024 x 1024 x 8, ms per step: 1.38 as it is, 1.51 forced to six, 1.80 to seven
+#endif
 template <typename R, bool SPEC, bool FUSED, bool CAM = false, bool TAIL = false>
-__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : 1)
+__global__ void __launch_bounds__(DRT_BLOCK, (sizeof(R) == 4 && SPEC) ? 4 : (sizeof(R) == 4 ? DRT_SHADE_MIN_BLOCKS : 1))
 k_shade(BatchArgs a, int k, int nb, const DevScene<R>* __restrict__ sc, const R* __restrict__ params,
         const typename Q4<R>::T* __restrict__ ray_a, const typename Q2<R>::T* __restrict__ ray_b,
         const uint2* __restrict__ ray_id, const HitRec<R>* __restrict__ hit,

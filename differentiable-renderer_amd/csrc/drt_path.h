@@ -58,6 +58,10 @@ struct PathArgs {
     // camera
     double eye[3], fwd[3], right[3], up[3];
     double tan_half, aspect, inv_W, inv_H;
+    // what the f32 kernels use of the doubles above, cast on the host: a scalar register each instead of a v_cvt_f32_f64 result in a vector one
+    // (at the END of the record: the f64 kernels' argument offsets stay what their register allocation was tuned at)
+    float p_rr_f, inv_p_rr_f;
+    float eye_f[3], fwd_f[3], right_f[3], up_f[3], cs_step_f, ct_step_f;   // (cs = cs0 + u1 cs_step: camera.hpp:53-58 in CameraLane's form)
 };
 
 __device__ inline uint32_t path_global_pixel(const PathArgs& a, uint32_t lp)
@@ -623,20 +627,30 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
 }
 
 // Camera::sample (camera.hpp:51-60) of sample `sl` of the lane's pixel
-template <typename R>
+// ARGS_F32: the camera's constants come as the floats the host made of them (PathArgs::eye_f ...: scalar registers, re-loaded from the
+// kernel's arguments where the compiler runs out of them).  Left to itself the compiler converts the double arguments with v_cvt_f32_f64,
+// whose result is a VECTOR register: seventeen wave-uniform values lived through the whole kernel that way (eleven of them in scratch once
+// the lockstep kernel was compiled for seven waves per SIMD).  Config 3's frame: 0.666 -> 0.659 ms, an albedo per shape 0.733 -> 0.725.  The
+// regenerating form, whose scalar registers are all taken, keeps the conversions (0.353 against 0.360 ms with the arguments, which it
+// re-loads in every iteration; from a table in LDS: 0.357, and the lockstep kernel 0.675).
+template <typename R, bool ARGS_F32 = true>
 __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& cl, uint32_t gpix, uint32_t px, uint32_t py, uint32_t sl,
                                        typename Q4<R>::T& ra, typename Q2<R>::T& rb)
 {
     const uint64_t path = (uint64_t)gpix * (uint64_t)a.spp + (uint64_t)(a.s0 + sl);
     const uint32_t key = (uint32_t)path;
     if (sizeof(R) == 4) {
-        const float cs = fmaf(u01(0.f, rng_draw(a.rng_stream, key, 0)), (float)(2. * a.aspect * a.tan_half * a.inv_W), (float)cl.cs0);
-        const float ct = fmaf(u01(0.f, rng_draw(a.rng_stream, key, 1)), (float)(2. * a.tan_half * a.inv_H), (float)cl.ct0);
-        const V3<float> dir = mk<float>((float)a.fwd[0] + cs * (float)a.right[0] - ct * (float)a.up[0],
-                                        (float)a.fwd[1] + cs * (float)a.right[1] - ct * (float)a.up[1],
-                                        (float)a.fwd[2] + cs * (float)a.right[2] - ct * (float)a.up[2]);
+        const float cs_step = ARGS_F32 ? a.cs_step_f : (float)(2. * a.aspect * a.tan_half * a.inv_W);
+        const float ct_step = ARGS_F32 ? a.ct_step_f : (float)(2. * a.tan_half * a.inv_H);
+        const V3<float> eye = ARGS_F32 ? mk<float>(a.eye_f[0], a.eye_f[1], a.eye_f[2]) : mk<float>((float)a.eye[0], (float)a.eye[1], (float)a.eye[2]);
+        const V3<float> fw = ARGS_F32 ? mk<float>(a.fwd_f[0], a.fwd_f[1], a.fwd_f[2]) : mk<float>((float)a.fwd[0], (float)a.fwd[1], (float)a.fwd[2]);
+        const V3<float> rt = ARGS_F32 ? mk<float>(a.right_f[0], a.right_f[1], a.right_f[2]) : mk<float>((float)a.right[0], (float)a.right[1], (float)a.right[2]);
+        const V3<float> upv = ARGS_F32 ? mk<float>(a.up_f[0], a.up_f[1], a.up_f[2]) : mk<float>((float)a.up[0], (float)a.up[1], (float)a.up[2]);
+        const float cs = fmaf(u01(0.f, rng_draw(a.rng_stream, key, 0)), cs_step, (float)cl.cs0);
+        const float ct = fmaf(u01(0.f, rng_draw(a.rng_stream, key, 1)), ct_step, (float)cl.ct0);
+        const V3<float> dir = mk<float>(fw.x + cs * rt.x - ct * upv.x, fw.y + cs * rt.y - ct * upv.y, fw.z + cs * rt.z - ct * upv.z);
         const V3<float> dn = normalize(dir);
-        ra.x = (R)a.eye[0]; ra.y = (R)a.eye[1]; ra.z = (R)a.eye[2]; ra.w = (R)dn.x;
+        ra.x = (R)eye.x; ra.y = (R)eye.y; ra.z = (R)eye.z; ra.w = (R)dn.x;
         rb.x = (R)dn.y; rb.y = (R)dn.z;
     } else {                                          // f64 verification mode: the reference's own sequence, in double
         const double u1 = (double)rng_draw(a.rng_stream, key, 0) / DRT_RAND_MAX_D;
@@ -665,7 +679,7 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
         py = gpix / (uint32_t)a.W;
         px = gpix - py * (uint32_t)a.W;
     }
-    return path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+    return path_camera<R, false>(a, cl, gpix, px, py, sl, ra, rb);
 }
 
 // blocks per CU (= waves per SIMD) a k_path instantiation is compiled for (its register budget); the knobs are above
@@ -753,7 +767,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     CameraLane<R> cl;
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
-    const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
+    const R pk_rr = (sizeof(R) == 4 && !REGEN) ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = (sizeof(R) == 4 && !REGEN) ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
     ProgRecs<SG::n, R> recs;
     // (the kind-sorted program's 1.3 KB only where it runs: with the kinds compiled in they are what stands between the
     //  regenerating kernel and a sixth block per CU)
@@ -1089,7 +1103,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     CameraLane<R> cl;
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
-    const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
+    const R pk_rr = sizeof(R) == 4 ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = sizeof(R) == 4 ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
     ProgRecs<SG::n, R> recs;
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;

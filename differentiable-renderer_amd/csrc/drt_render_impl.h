@@ -580,11 +580,17 @@ int path_batch(Shard<R>& s)
     pa.descend_min = a.bvh_descend_min;
     pa.p_rr = 1.0 - rp->absorb;
     pa.inv_p_rr = rp->absorb < 1.0 ? 1.0 / (1.0 - rp->absorb) : 0.0;   // (never used when every path ends at min_bounces)
+    pa.p_rr_f = (float)pa.p_rr; pa.inv_p_rr_f = (float)pa.inv_p_rr;
     for (int i = 0; i < 3; ++i) {
         pa.eye[i] = a.eye[i]; pa.fwd[i] = a.fwd[i]; pa.right[i] = a.right[i]; pa.up[i] = a.up[i];
     }
     pa.tan_half = a.tan_half; pa.aspect = a.aspect;
     pa.inv_W = 1.0 / (double)a.W; pa.inv_H = 1.0 / (double)a.H;
+    for (int i = 0; i < 3; ++i) {
+        pa.eye_f[i] = (float)pa.eye[i]; pa.fwd_f[i] = (float)pa.fwd[i]; pa.right_f[i] = (float)pa.right[i]; pa.up_f[i] = (float)pa.up[i];
+    }
+    pa.cs_step_f = (float)(2. * pa.aspect * pa.tan_half * pa.inv_W);
+    pa.ct_step_f = (float)(2. * pa.tan_half * pa.inv_H);
     pa.gimg_param = s.gimg_param;
     pa.gen_rows = s.gen_rows; pa.gen_clog2 = s.gen_clog2;
     // the general form's vertex history: a word per four vertices and thread, in dynamic shared memory
