@@ -241,17 +241,17 @@ struct Tangents {
 // A zero channel (red = (0.5, 0, 0), render.cpp:26): vertex j's own factor is the only zero of the channel iff zc_ch == 1, and
 // then d/dc of that channel is T_ch (the product WITHOUT the zero factor, which is what the lane's T holds) -- else 0.
 #define DRT_NP_ANY (-1)
+// Blocks per CU (= waves per SIMD) the f32 lockstep k_path is compiled for, form by form (ms per launch on config 3's frame, the builds
+// alternating in one process: profiles/r06_waves_per_simd.txt; five against six: r06_scratch_vs_waves.txt)
 #ifndef DRT_LOCKSTEP_MIN_BLOCKS
-#define DRT_LOCKSTEP_MIN_BLOCKS 7    // blocks per CU the f32 lockstep diffuse k_path of <= 4 parameters is compiled for: 72 registers + 60 bytes of scratch
-                                     // per lane.  Config 3's frame, ms per launch, builds alternating in one process: five (96 registers, no scratch)
-                                     // 0.716, six (80 + 24 B) 0.695-0.702, seven 0.673, eight (64 + 96 B) 0.694: profiles/r06_scratch_vs_waves.txt
+#define DRT_LOCKSTEP_MIN_BLOCKS 7       // diffuse, <= 4 parameters: 72 registers.  Five (96 registers) 0.716, six (80) 0.695-0.702, seven 0.673, eight (64 + scratch) 0.694-0.702
 #endif
 #ifndef DRT_LOCKSTEP_GEN_MIN_BLOCKS
-#define DRT_LOCKSTEP_GEN_MIN_BLOCKS 6   // ... its general form (any number of parameters): 80 registers + 32 B; seven 0.735 -> 0.743, eight 0.777
+#define DRT_LOCKSTEP_GEN_MIN_BLOCKS 6   // its general form (any number of parameters): 77-80 registers; seven 0.725 -> 0.736
 #endif
 #ifndef DRT_LOCKSTEP_SPEC_MIN_BLOCKS
-#define DRT_LOCKSTEP_SPEC_MIN_BLOCKS 6  // ... the kernels of <= 4 parameters that carry the glossy lobe (config 5): 80 registers + 32 B; config 5's shape
-                                        // (2048 x 2048, depth 16), ms per launch at 16 spp: five 7.92, six 7.79, seven 7.81 (tools/ab_config5.py)
+#define DRT_LOCKSTEP_SPEC_MIN_BLOCKS 6  // with the glossy lobe (config 5), <= 4 parameters: 78-80 registers; config 5's shape (2048 x 2048 x 16, depth 16): five 7.92, six 7.79,
+                                        // seven 7.81 (tools/ab_kernel.py)
 #endif
 #ifndef DRT_REGEN_MIN_BLOCKS
 #define DRT_REGEN_MIN_BLOCKS 5       // blocks per CU the f32 regenerating diffuse k_path is compiled for
@@ -633,7 +633,10 @@ __device__ inline void path_bounce(const PathArgs& a, const PathSceneLds<R>& lds
 // the lockstep kernel was compiled for seven waves per SIMD).  Config 3's frame: 0.666 -> 0.659 ms, an albedo per shape 0.733 -> 0.725.  The
 // regenerating form, whose scalar registers are all taken, keeps the conversions (0.353 against 0.360 ms with the arguments, which it
 // re-loads in every iteration; from a table in LDS: 0.357, and the lockstep kernel 0.675).
-template <typename R, bool ARGS_F32 = true>
+#ifndef DRT_CAMERA_ARGS_F32
+#define DRT_CAMERA_ARGS_F32 1
+#endif
+template <typename R, bool ARGS_F32 = (DRT_CAMERA_ARGS_F32 != 0)>
 __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& cl, uint32_t gpix, uint32_t px, uint32_t py, uint32_t sl,
                                        typename Q4<R>::T& ra, typename Q2<R>::T& rb)
 {
@@ -682,13 +685,21 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
     return path_camera<R, false>(a, cl, gpix, px, py, sl, ra, rb);
 }
 
-// blocks per CU (= waves per SIMD) a k_path instantiation is compiled for (its register budget); the knobs are above
+// blocks per CU (= waves per SIMD) a k_path instantiation is compiled for (its register budget); the knobs are above.
+// A kernel hiprtc makes for a scene of MANY shapes (their records in scalar registers, their tests unrolled) needs the registers: rooms of
+// 15 / 31 shapes, 4 parameters, ms per launch on config 3's frame at six waves with converted constants / seven / six with the constants as
+// arguments / seven with them: 0.858 / 0.849 / 0.847 / 1.039 and 2.21 / 2.50 / 2.37 / 2.61 -- so the seventh wave and the float arguments
+// (path_camera) are for kernels of up to DRT_LEAN_MAX_SHAPES compiled-in shapes (the reference's scene has 9) and for the run-time program.
+#ifndef DRT_LEAN_MAX_SHAPES
+#define DRT_LEAN_MAX_SHAPES 10
+#endif
 template <size_t RB, bool SPEC, int NP, int NSG, bool REGEN>
 constexpr int path_min_blocks()
 {
     if (RB == 4 && NP <= 4) {
         if (!REGEN)
-            return SPEC ? (NP == DRT_NP_ANY ? 5 : DRT_LOCKSTEP_SPEC_MIN_BLOCKS) : (NP == DRT_NP_ANY ? DRT_LOCKSTEP_GEN_MIN_BLOCKS : DRT_LOCKSTEP_MIN_BLOCKS);
+            return SPEC ? ((NP == DRT_NP_ANY || NSG > DRT_LEAN_MAX_SHAPES) ? 5 : DRT_LOCKSTEP_SPEC_MIN_BLOCKS)
+                        : (NP == DRT_NP_ANY ? DRT_LOCKSTEP_GEN_MIN_BLOCKS : (NSG <= DRT_LEAN_MAX_SHAPES ? DRT_LOCKSTEP_MIN_BLOCKS : DRT_LOCKSTEP_GEN_MIN_BLOCKS));
         return (NP == DRT_NP_ANY && NSG == 0) ? 4             // (general form + the kind-sorted program: 34 KB of LDS)
                                               : (SPEC ? 5 : DRT_REGEN_MIN_BLOCKS);
     }
@@ -767,7 +778,8 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     CameraLane<R> cl;
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
-    const R pk_rr = (sizeof(R) == 4 && !REGEN) ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = (sizeof(R) == 4 && !REGEN) ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
+    constexpr bool ARGS_F32 = sizeof(R) == 4 && !REGEN && DRT_CAMERA_ARGS_F32 != 0 && SG::n <= DRT_LEAN_MAX_SHAPES;   // (see path_camera)
+    const R pk_rr = ARGS_F32 ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = ARGS_F32 ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
     ProgRecs<SG::n, R> recs;
     // (the kind-sorted program's 1.3 KB only where it runs: with the kinds compiled in they are what stands between the
     //  regenerating kernel and a sixth block per CU)
@@ -790,7 +802,7 @@ k_path(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict__ par
     for (uint32_t sl = s_begin; sl < s_end; ++sl) {
         R4 ra;
         R2 rb;
-        const uint32_t key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+        const uint32_t key = path_camera<R, ARGS_F32>(a, cl, gpix, px, py, sl, ra, rb);
         // pathtracer.hpp:128 at depth 0
         bool live = have && a.depth_cap > 0 && !(a.min_bounces <= 0 && rng_draw(a.rng_stream, key, 2) < a.rr_threshold);
         V3<R> T = mk<R>(R(1), R(1), R(1)), L = mk<R>(R(0), R(0), R(0));
@@ -1103,7 +1115,8 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
     CameraLane<R> cl;
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
-    const R pk_rr = sizeof(R) == 4 ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = sizeof(R) == 4 ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
+    constexpr bool ARGS_F32 = sizeof(R) == 4 && DRT_CAMERA_ARGS_F32 != 0 && SG::n <= DRT_LEAN_MAX_SHAPES;   // (see path_camera)
+    const R pk_rr = ARGS_F32 ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = ARGS_F32 ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
     ProgRecs<SG::n, R> recs;
     __shared__ ProgLds s_prog;
     recs.lds = &s_prog;
@@ -1126,7 +1139,7 @@ k_path_unbiased(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restr
         for (uint32_t sl = s_begin; sl < s_end; ++sl) {
             R4 ra;
             R2 rb;
-            const uint32_t key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+            const uint32_t key = path_camera<R, ARGS_F32>(a, cl, gpix, px, py, sl, ra, rb);
             uint32_t nd = 2;                                  // the camera's two draws
             bool live = have && a.depth_cap > 0;
             if (rr_drawn(0)) {                                // pathtracer.hpp:128 at depth 0

@@ -97,7 +97,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
     CameraLane<R> cl;                                     // (see k_path)
     cl.cs0 = (R)((2. * (double)px * a.inv_W - 1.) * a.aspect * a.tan_half);
     cl.ct0 = (R)((2. * (double)py * a.inv_H - 1.) * a.tan_half);
-    const R pk_rr = sizeof(R) == 4 ? (R)a.p_rr_f : (R)a.p_rr, inv_p_rr = sizeof(R) == 4 ? (R)a.inv_p_rr_f : (R)a.inv_p_rr;
+    const R pk_rr = (R)a.p_rr, inv_p_rr = (R)a.inv_p_rr;
     const int n_shapes = lds.sc.n_shapes;
     const int first_rr = a.min_bounces > 1 ? a.min_bounces : 1;
     const V3<R> blo = mk<R>(bvh.lo[0], bvh.lo[1], bvh.lo[2]), bhi = mk<R>(bvh.hi[0], bvh.hi[1], bvh.hi[2]);
@@ -226,7 +226,7 @@ k_path_mesh(PathArgs a, const DevScene<R>* __restrict__ sc, const R* __restrict_
                     if (start) {
                         R4 ra;
                         R2 rb;
-                        key = path_camera<R>(a, cl, gpix, px, py, sl, ra, rb);
+                        key = path_camera<R, false>(a, cl, gpix, px, py, sl, ra, rb);   // (camera code inside the loop, scalar registers all taken: see path_camera)
                         ++sl;
                         kk = 0;
                         o = mk<R>(ra.x, ra.y, ra.z);
