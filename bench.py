@@ -499,8 +499,16 @@ def main():
     # The instruction count is a STORED figure (profiles/traffic.json): it describes this run only if the kernel is still the
     # one that was profiled.  The profile also recorded the kernel's launch time: where the live time is off by more than 5 %
     # (boxes of the pool differ by ~3 %) the count is withheld instead of being divided by a time it does not belong to.
+    # Better than a time: the profile records WHICH kernels it counted (a hash of the device sources the library was built from) and the
+    # work of a launch (segments: a pure function of workload and seed).  Same sources and same work = the same instructions, whatever the
+    # box's clock does today; the time check remains for profiles that carry no hash.
     stale = None
-    if pmc.get("valu_insts_per_launch") and pmc.get("avg_launch_us") and launch_ms > 0 and not pmc_note:
+    same_kernels = None
+    if pmc.get("kernel_sources_sha16") and not pmc_note:
+        live_units = dk.get("units_per_step", 0) / max(1, dk["launches_per_step"]) if dk.get("units_per_step") else None
+        same_kernels = (pmc["kernel_sources_sha16"] == entry.kernel_sources_sha16() and live_units is not None
+                        and pmc.get("units_per_launch") is not None and float(pmc["units_per_launch"]) == float(live_units))
+    if pmc.get("valu_insts_per_launch") and pmc.get("avg_launch_us") and launch_ms > 0 and not pmc_note and not same_kernels:
         off = launch_ms * 1e3 / float(pmc["avg_launch_us"]) - 1.0
         if abs(off) > 0.05:
             stale = (f"profiles/traffic.json holds k_{dominant} at {float(pmc['avg_launch_us']):.1f} us per launch, this run measures "
@@ -514,6 +522,9 @@ def main():
                      "frac_of_measured_issue_roof": round(ginst / VALU_MEASURED_GINST, 4),
                      "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
                      "salu_insts_per_launch": pmc.get("salu_insts_per_launch"),
+                     "count_valid_because": ("the profile was taken of these very kernels (hash of the device sources "
+                                             f"{pmc.get('kernel_sources_sha16')}) on the same work per launch" if same_kernels else
+                                             "the profile's own launch time is within 5 % of the live one"),
                      "note": "SQ_INSTS_VALU per launch (profiles/traffic.json, rocprofv3 --pmc on this workload) / live launch "
                              "time; peak = one wave64 VALU op per 2 cycles per SIMD-32, 256 CUs x 4 SIMDs x 2.4 GHz"}
     # The top-level achieved / peak / unit / frac describe the roof that BOUNDS the dominant kernel: HBM bytes for the

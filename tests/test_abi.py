@@ -111,3 +111,19 @@ def test_product_code_never_touches_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "drt_oracle" not in open(os.path.join(dirpath, f), errors="ignore").read()
+
+
+def test_stored_instruction_counts_name_the_kernels_they_were_taken_of():
+    """bench.py divides a STORED rocprofv3 instruction count (profiles/traffic.json) by a LIVE launch time: it may only do so for the
+    kernels the count was taken of.  Every entry tools/summarize_profile.py writes carries a hash of the device sources; the hash is a
+    pure function of csrc/ + include/drt_hip.h (not of the build directory, the clock or the box)."""
+    import json
+    import re
+    import __graft_entry__ as entry
+    sha = entry.kernel_sources_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", sha) and sha == entry.kernel_sources_sha16()
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    hashed = [k for w in tj["workloads"].values() for k in w.values() if isinstance(k, dict) and "kernel_sources_sha16" in k]
+    assert hashed and all(re.fullmatch(r"[0-9a-f]{16}", k["kernel_sources_sha16"]) and "units_per_launch" in k for k in hashed)
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    assert "kernel_sources_sha16" in text and "same_kernels" in text

@@ -109,4 +109,14 @@ try:
             tj[name]["units_per_launch"] = kd["units_per_step"] / kd["launches_per_step"]
 except Exception:
     pass
+# which kernels these counts belong to: the sources the library on this box was built from (bench.py compares before it quotes a count)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as _entry
+    sha = _entry.kernel_sources_sha16()
+    for name in list(tj):
+        if isinstance(tj[name], dict):
+            tj[name]["kernel_sources_sha16"] = sha
+except Exception:
+    pass
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
