@@ -506,8 +506,17 @@ def main():
     same_kernels = None
     if pmc.get("kernel_sources_sha16") and not pmc_note:
         live_units = dk.get("units_per_step", 0) / max(1, dk["launches_per_step"]) if dk.get("units_per_step") else None
-        same_kernels = (pmc["kernel_sources_sha16"] == entry.kernel_sources_sha16() and live_units is not None
-                        and pmc.get("units_per_launch") is not None and float(pmc["units_per_launch"]) == float(live_units))
+        same_kernels = (pmc["kernel_sources_sha16"] == entry.kernel_sources_sha16() and bool(live_units) and bool(pmc.get("units_per_launch")))
+        if same_kernels and float(pmc["units_per_launch"]) != float(live_units):
+            # the same kernels on the same scene, depth and mode, but another share of the frame (a rank of an N-GPU run renders other
+            # rows at N x the samples: a few segments more or less): instructions and bytes per SEGMENT are what carries over
+            scale = float(live_units) / float(pmc["units_per_launch"])
+            if 0.8 <= scale <= 1.25:
+                pmc = {k2: (v2 * scale if isinstance(v2, (int, float)) and (k2.endswith("_per_launch") or k2 in ("fetch_raw_bytes", "write_bytes")) else v2)
+                       for k2, v2 in pmc.items()}
+                traffic = round(pmc["bytes_per_launch"] / (launch_ms * 1e-3) * 1e-9, 1) if pmc.get("bytes_per_launch") and launch_ms > 0 else None
+            else:
+                same_kernels = False
     if pmc.get("valu_insts_per_launch") and pmc.get("avg_launch_us") and launch_ms > 0 and not pmc_note and not same_kernels:
         off = launch_ms * 1e3 / float(pmc["avg_launch_us"]) - 1.0
         if abs(off) > 0.05:
