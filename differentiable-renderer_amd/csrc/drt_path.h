@@ -690,8 +690,14 @@ __device__ inline uint32_t path_camera(const PathArgs& a, const CameraLane<R>& c
 // 15 / 31 shapes, 4 parameters, ms per launch on config 3's frame at six waves with converted constants / seven / six with the constants as
 // arguments / seven with them: 0.858 / 0.849 / 0.847 / 1.039 and 2.21 / 2.50 / 2.37 / 2.61 -- so the seventh wave and the float arguments
 // (path_camera) are for kernels of up to DRT_LEAN_MAX_SHAPES compiled-in shapes (the reference's scene has 9) and for the run-time program.
+// Kernels that carry caller-defined kinds (DRT_USER_SHAPES: the caller's own intersect / normal / BxDF bodies inlined) keep the wider budgets too:
+// a power-cosine lobe from source lost 5-8 % at six waves (1.84 -> 1.93 ms, with a disc 1.94 -> 2.09).
 #ifndef DRT_LEAN_MAX_SHAPES
+#ifdef DRT_USER_SHAPES
+#define DRT_LEAN_MAX_SHAPES (-1)
+#else
 #define DRT_LEAN_MAX_SHAPES 10
+#endif
 #endif
 template <size_t RB, bool SPEC, int NP, int NSG, bool REGEN>
 constexpr int path_min_blocks()
