@@ -14,8 +14,9 @@ bash tools/profile.sh ${T}_roulette cornell:512x512x64:rr0.5b1:fwdbwd --absorb 0
 bash tools/profile.sh ${T}_unbiased cornell:512x512x64:d8:unbiased --unbiased >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_fwd cornell:512x512x64:d8:fwd --config 2 >> "$E/prof.log" 2>&1
 bash tools/profile.sh ${T}_unbiased_mesh mesh160x160:512x512x64:d8:unbiased  --scene mesh160x160 --unbiased >> "$E/prof.log" 2>&1
+bash tools/profile.sh ${T}_many_params cornell_shapes:512x512x64:d8:fwdbwd --scene cornell_shapes >> "$E/prof.log" 2>&1
 # bench.py quotes PMC numbers only for the workloads profiled above (one entry each)
-python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_config4/traffic.json gpurun_out/prof_${T}_roulette/traffic.json gpurun_out/prof_${T}_unbiased/traffic.json gpurun_out/prof_${T}_unbiased_mesh/traffic.json gpurun_out/prof_${T}_fwd/traffic.json >> "$E/prof.log" 2>&1
+python3 tools/merge_traffic.py profiles/traffic.json gpurun_out/prof_$T/traffic.json gpurun_out/prof_${T}_mesh/traffic.json gpurun_out/prof_${T}_config5/traffic.json gpurun_out/prof_${T}_config4/traffic.json gpurun_out/prof_${T}_roulette/traffic.json gpurun_out/prof_${T}_unbiased/traffic.json gpurun_out/prof_${T}_unbiased_mesh/traffic.json gpurun_out/prof_${T}_fwd/traffic.json gpurun_out/prof_${T}_many_params/traffic.json >> "$E/prof.log" 2>&1
 cp profiles/traffic.json "$E/traffic_merged.json"
 python3 tools/parity_report.py --big > "$E/parity_report.txt" 2> "$E/parity_report.err"
 # (--store-n1: profiles/n1_reference.json is re-stored at this binary, so the first N > 1 run compares against today's value)
@@ -63,11 +64,11 @@ python3 bench.py --single-process --gpus 2 --same-gpu 2>> "$E/bench.err" | grep 
 # round 6: what the number of scene parameters costs (the general form of the one-launch kernels); many-parameter bench lines;
 # the f64 route's kernel time
 python3 tools/param_cliff.py 2>&1 | grep -v amdgpu > "$E/param_cliff.txt"
-for sc in cornell_shapes params16 params64; do python3 bench.py --scene $sc --no-extra-views --no-cpu-baseline > "$E/bench_$sc.json" 2>> "$E/bench.err"; done
+for sc in cornell_shapes params16 params32 params64; do python3 bench.py --scene $sc --no-extra-views --no-cpu-baseline > "$E/bench_$sc.json" 2>> "$E/bench.err"; done
 python3 tools/f64_frames.py 10 2>&1 | grep -v amdgpu > "$E/f64_frames.txt"
 python3 tools/walk_diag.py - mesh160x160 64 > "$E/walk_by_depth.txt" 2>&1
 [ -f build/lib_stats.so ] && python3 tools/bvh_stats.py build/lib_stats.so > "$E/bvh_stats.txt" 2>&1
-for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh ${T}_fwd; do
+for t in $T ${T}_streaming ${T}_mesh ${T}_config5 ${T}_config4 ${T}_roulette ${T}_unbiased ${T}_unbiased_mesh ${T}_fwd ${T}_many_params; do
   P=gpurun_out/prof_$t
   cp $P/summary.txt "$E/${t}_rocprofv3_summary.txt"
   cp $P/traffic.json "$E/${t}_traffic.json"
