@@ -41,7 +41,10 @@ def test_specialised_program_is_bit_identical_to_the_run_time_program(pkg, name)
 
 
 def test_specialised_program_for_a_scene_of_many_shapes(pkg):
-    """more than 16 shapes: the signature's second and third word; the records no longer fit the scalar registers"""
+    """more than 16 shapes: the signature's second and third word; the records no longer fit the scalar registers.
+    (Also what pins the camera's constants: the run-time program takes them as the floats the HOST made of the double arguments
+    (PathArgs::eye_f ..., round 6), a kernel made for more than DRT_LEAN_MAX_SHAPES shapes converts the doubles itself with
+    v_cvt_f32_f64 -- the same bits, or no pixel of the two frames would agree.)"""
     scene = pkg.random_scene(4, n_spheres=36)
     assert 40 < len(scene.shapes) <= 64
     cam = pkg.cornell_camera(64, 48)
